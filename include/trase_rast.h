@@ -1,0 +1,174 @@
+/*
+ * trase_rast.h -- C ABI of the MI355X-native TRASE rasterizer path.
+ *
+ * Drop-in boundary for the one hot path of yunjinli/TRASE: the native operator
+ * behind gaussian_renderer.render().  The reference binds this path through a
+ * pybind11/torch CUDA extension (un-vendored submodule, .gitmodules:4-6):
+ *
+ *   diff_gaussian_rasterization.GaussianRasterizationSettings   gaussian_renderer/__init__.py:58-71
+ *   diff_gaussian_rasterization.GaussianRasterizer.forward      gaussian_renderer/__init__.py:137-146
+ *   (its autograd backward, triggered by loss.backward())       train.py:299
+ *   simple_knn._C.distCUDA2                                     scene/gaussian_model.py:237
+ *
+ * This header is the C-level equivalent: plain pointers and sizes, no torch
+ * types.  All pointers named "device" are HIP device pointers valid on
+ * `settings.device`; every call enqueues work on the caller's `stream` and
+ * returns without synchronising unless stated.  The library allocates nothing
+ * persistent and keeps no global state; it is re-entrant (PyTorch calls the
+ * backward entry point from an autograd worker thread).
+ *
+ * Return codes: 0 ok; <0 invalid argument / HIP error (see trase_strerror);
+ * >0 is never returned by enqueue calls (capacity overflow is reported through
+ * trase_rast_status, because it is only known on the device).
+ */
+#ifndef TRASE_RAST_H
+#define TRASE_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* trase_stream_t; /* hipStream_t */
+
+enum {
+  TRASE_OK = 0,
+  TRASE_ERR_INVALID = -1,     /* bad argument combination (mirrors the reference's ValueError cases) */
+  TRASE_ERR_UNSUPPORTED = -2, /* e.g. feature width not compiled in */
+  TRASE_ERR_WORKSPACE = -3,   /* workspace too small */
+  TRASE_ERR_HIP = -4          /* a HIP call failed; message via trase_last_error() */
+};
+
+/* GaussianRasterizationSettings (12 fields, gaussian_renderer/__init__.py:58-71).
+ * The tensors of the reference record (bg, viewmatrix, projmatrix, campos) stay
+ * on the device and are read by the kernels -- no D2H copy.  Matrices are the
+ * transposed (row-vector) forms of scene/cameras.py:76-78: flat[4*col+row]. */
+typedef struct TraseRastSettings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  const float* bg;         /* device, 3 floats  */
+  float scale_modifier;
+  const float* viewmatrix; /* device, 16 floats */
+  const float* projmatrix; /* device, 16 floats */
+  int32_t sh_degree;       /* active degree 0..3 */
+  const float* campos;     /* device, 3 floats  */
+  int32_t prefiltered;
+  int32_t debug;           /* !=0: synchronise + check after every kernel */
+  int32_t device;          /* HIP device ordinal of all pointers and of `stream` */
+  int32_t variant;         /* kernel variant selector for A/B ablation; 0 = default */
+} TraseRastSettings;
+
+/* Inputs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:137-146).
+ * Exactly one of shs/colors_precomp and one of (scales,rotations)/cov3D_precomp
+ * is non-NULL, as in the reference.  All contiguous float32. */
+typedef struct TraseRastInputs {
+  int32_t P;                   /* number of Gaussians */
+  int32_t M;                   /* SH coefficients stored per Gaussian (16 for degree 3); 0 if shs NULL */
+  int32_t F;                   /* feature channels of sh_objs (32 in TRASE); 0 if sh_objs NULL */
+  const float* means3D;        /* (P,3)   */
+  const float* shs;            /* (P,M,3) coefficient-major */
+  const float* sh_objs;        /* (P,1,F) */
+  const float* colors_precomp; /* (P,3)   */
+  const float* opacities;      /* (P,1)   */
+  const float* scales;         /* (P,3)   */
+  const float* rotations;      /* (P,4) (r,x,y,z), NOT assumed unit length */
+  const float* cov3D_precomp;  /* (P,6)   */
+} TraseRastInputs;
+
+/* Outputs: the reference's 4-tuple (image, radii, feats, depth), channel-planar. */
+typedef struct TraseRastOutputs {
+  float* image;   /* (3,H,W) */
+  int32_t* radii; /* (P,)    */
+  float* feats;   /* (F,H,W) or NULL when F == 0 */
+  float* depth;   /* (1,H,W) */
+} TraseRastOutputs;
+
+/* Caller-owned workspaces.  geom/bin/img are saved by the caller between
+ * forward and backward (the reference saves geomBuffer/binningBuffer/imgBuffer
+ * the same way).  pre is stage-1 scratch that must survive until stage 2 (its
+ * size depends on P only); tmp is stage-2 scratch (size depends on capacity) and
+ * doubles as the backward's scratch (bwd_tmp_bytes).  Only geom/bin/img sizes
+ * depend on nothing else, so a caller may run stage 1, read the pair count with
+ * trase_rast_status and only then allocate bin/tmp. */
+typedef struct TraseRastWorkspace {
+  void* geom; size_t geom_bytes;
+  void* bin;  size_t bin_bytes;
+  void* img;  size_t img_bytes;
+  void* pre;  size_t pre_bytes;
+  void* tmp;  size_t tmp_bytes;
+  int64_t capacity;            /* max (tile,Gaussian) pairs `bin`/`tmp` were sized for */
+} TraseRastWorkspace;
+
+typedef struct TraseRastSizes {
+  size_t geom_bytes, bin_bytes, img_bytes, pre_bytes, tmp_bytes, bwd_tmp_bytes;
+} TraseRastSizes;
+
+/* Cotangents in, gradients out (A4).  NULL cotangent == that output was unused
+ * (ctx.set_materialize_grads(False) semantics); NULL gradient == not needed. */
+typedef struct TraseRastGrads {
+  const float* dL_dimage;   /* (3,H,W) or NULL */
+  const float* dL_dfeats;   /* (F,H,W) or NULL */
+  const float* dL_ddepth;   /* (1,H,W) or NULL (lineage: ignored unless settings.variant bit says so) */
+  float* dL_dmeans3D;       /* (P,3)   */
+  float* dL_dmeans2D;       /* (P,3) x,y = NDC-scaled screen gradient, z = 0 */
+  float* dL_dshs;           /* (P,M,3) */
+  float* dL_dsh_objs;       /* (P,1,F) */
+  float* dL_dcolors;        /* (P,3)   */
+  float* dL_dopacities;     /* (P,1)   */
+  float* dL_dscales;        /* (P,3)   */
+  float* dL_drotations;     /* (P,4)   */
+  float* dL_dcov3D;         /* (P,6)   */
+} TraseRastGrads;
+
+/* Sizes of every workspace for P Gaussians, a W x H image, F feature channels
+ * and room for `capacity` (tile,Gaussian) pairs. */
+int trase_rast_sizes(int32_t P, int32_t W, int32_t H, int32_t F, int64_t capacity, TraseRastSizes* out);
+
+/* Stage 1: per-Gaussian projection / EWA / colour + tile counting + depth sort.
+ * Writes out->radii and the geom workspace (incl. the device-side pair count). */
+int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                          const TraseRastWorkspace* ws, trase_stream_t stream);
+
+/* Blocking read of {num_rendered, overflow, num_rendered_culled} from the geom
+ * workspace (the reference's forward returns num_rendered the same way). */
+int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream);
+
+/* Stage 2: binning (tile lists in depth order) + alpha compositing. */
+int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                      const TraseRastWorkspace* ws, trase_stream_t stream);
+
+/* Stage 1 + 2 back to back, no host synchronisation. */
+int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                       const TraseRastWorkspace* ws, trase_stream_t stream);
+
+/* Backward of trase_rast_forward; ws->tmp must hold bwd_tmp_bytes. */
+int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                        const TraseRastWorkspace* ws, const TraseRastGrads* g, trase_stream_t stream);
+
+/* simple_knn._C.distCUDA2 (scene/gaussian_model.py:237): mean squared distance
+ * to the 3 nearest neighbours.  ws_bytes from trase_knn_sizes. */
+int trase_knn_sizes(int32_t N, size_t* ws_bytes);
+int trase_knn_dist2(const float* points, int32_t N, float* out, void* ws, size_t ws_bytes, int32_t device,
+                    trase_stream_t stream);
+
+/* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
+ * roofline leg).  enable=1 starts recording, the report call synchronises the
+ * events and returns averaged milliseconds per kernel name. */
+int trase_prof_enable(int enable);
+int trase_prof_report(char* buf, size_t buf_bytes); /* JSON object {"kernel": {"ms":..,"n":..}, ...} */
+
+/* On-device self test of the wave64 primitives the kernels rely on
+ * (DPP reductions, ballots, MFMA fragment layouts).  Returns 0 when all pass. */
+int trase_selftest(int32_t device, trase_stream_t stream, char* msg, size_t msg_bytes);
+
+const char* trase_last_error(void);
+const char* trase_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRASE_RAST_H */

@@ -1,0 +1,391 @@
+"""TEST INFRASTRUCTURE ONLY -- float64 CPU oracle of the TRASE rasterizer path.
+
+What it restates (reference file:line it follows):
+
+* call contract of ``GaussianRasterizer(raster_settings)(means3D, means2D, shs,
+  sh_objs, colors_precomp, opacities, scales, rotations, cov3D_precomp) ->
+  (image, radii, feats, depth)`` -- gaussian_renderer/__init__.py:58-73,137-146
+* matrix conventions (row-vector, transposed storage) -- scene/cameras.py:76-79,
+  utils/graphics_utils.py:38-71
+* SH basis constants / polynomial order -- utils/sh_utils.py:26-43,57-112 and
+  the ``+0.5, clamp_min 0`` colour rule -- gaussian_renderer/__init__.py:105-108
+* quaternion (r,x,y,z) -> rotation matrix and Sigma = R S S^T R^T --
+  utils/general_utils.py:122-154, scene/gaussian_model.py:37-41
+* everything that lives inside the absent CUDA extension follows SURVEY.md
+  Appendix A (public 3DGS lineage + gaussian-grouping ``sh_objs`` channels +
+  Deformable-3DGS blended depth).  PARITY UNPINNED for that part: no source,
+  no tests, no golden vectors exist in /root/reference.
+
+Every lineage assumption is a keyword switch of :class:`OracleOptions`.
+
+Gradients come from ``torch.autograd`` on this restatement (float64); the two
+places where the lineage's hand-written backward is *not* the derivative of
+its forward are reproduced with detach tricks (see ``lineage_grads``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+TILE = 16  # the lineage's BLOCK_X == BLOCK_Y == 16; part of the visible semantics
+            # because tile-rect membership decides which Gaussians a pixel sees.
+
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+         0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
+
+
+@dataclass
+class OracleOptions:
+    # Appendix A switches -----------------------------------------------------
+    near_cull_z: float = 0.2          # cull if view-space z <= this
+    lowpass: float = 0.3              # added to both diagonal entries of cov2D
+    alpha_max: float = 0.99
+    alpha_min: float = 1.0 / 255.0
+    t_stop: float = 1e-4
+    feats_bg: bool = False            # features get no background term
+    depth_normalised: bool = False    # depth is NOT divided by accumulated alpha
+    lineage_grads: bool = True        # straight-through 0.99 clamp; frozen clamped tx/tz
+    # fragility margins (relative) used to flag pixels whose discrete decisions
+    # may legitimately flip between float32 and float64 arithmetic
+    frag_rel: float = 2e-5
+
+
+def _f64(x):
+    return None if x is None else x.to(torch.float64)
+
+
+def build_rotation_unnormalised(q: torch.Tensor) -> torch.Tensor:
+    """Entries as utils/general_utils.py:134-142, but the quaternion is used as
+    given (Appendix A.3: the CUDA path does not normalise)."""
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(-1, 3, 3)
+
+
+def cov3d_from_scale_rot(scales, rotations, scale_modifier):
+    """Sigma = R S S R^T, stored as (xx,xy,xz,yy,yz,zz) like strip_lowerdiag
+    (utils/general_utils.py:108-119)."""
+    R = build_rotation_unnormalised(rotations)
+    L = R * (scale_modifier * scales)[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=-1)
+
+
+def eval_sh_colors(deg: int, shs: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """shs: (N, M, 3) coefficient-major (scene/gaussian_model.py:194-197);
+    same polynomial as utils/sh_utils.py:74-100.  Returns (N,3) before +0.5."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    res = SH_C0 * shs[:, 0]
+    if deg > 0:
+        res = res - SH_C1 * y * shs[:, 1] + SH_C1 * z * shs[:, 2] - SH_C1 * x * shs[:, 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            res = (res + SH_C2[0] * xy * shs[:, 4] + SH_C2[1] * yz * shs[:, 5]
+                   + SH_C2[2] * (2.0 * zz - xx - yy) * shs[:, 6]
+                   + SH_C2[3] * xz * shs[:, 7] + SH_C2[4] * (xx - yy) * shs[:, 8])
+            if deg > 2:
+                res = (res + SH_C3[0] * y * (3 * xx - yy) * shs[:, 9]
+                       + SH_C3[1] * xy * z * shs[:, 10]
+                       + SH_C3[2] * y * (4 * zz - xx - yy) * shs[:, 11]
+                       + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12]
+                       + SH_C3[4] * x * (4 * zz - xx - yy) * shs[:, 13]
+                       + SH_C3[5] * z * (xx - yy) * shs[:, 14]
+                       + SH_C3[6] * x * (xx - 3 * yy) * shs[:, 15])
+    return res
+
+
+@dataclass
+class Geom:
+    """Per-Gaussian forward state (float64, differentiable where meaningful)."""
+    valid: torch.Tensor        # (N,) bool: survives all culls
+    radii: torch.Tensor        # (N,) int32 (0 where culled)
+    xy: torch.Tensor           # (N,2) pixel-space centre
+    depth: torch.Tensor        # (N,) view-space z
+    conic: torch.Tensor        # (N,3) (A,B,C) of the inverse 2D covariance
+    rgb: torch.Tensor          # (N,3)
+    rect: torch.Tensor         # (N,4) int64 tile rect x0,y0,x1,y1 (half-open)
+    tiles_touched: torch.Tensor
+    frag_gauss: torch.Tensor   # (N,) bool: a discrete preprocess decision is borderline
+    cov3d: torch.Tensor        # (N,6)
+    ndc: torch.Tensor          # (N,2) NDC centre; carries the means2D gradient hook
+
+
+def preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotations,
+               cov3D_precomp, means2D=None, opt: OracleOptions = OracleOptions()) -> Geom:
+    """Appendix A 'Preprocess' items 1-9."""
+    W, H = int(settings.image_width), int(settings.image_height)
+    vm = _f64(settings.viewmatrix).reshape(4, 4)      # stored transposed (row-vector form)
+    pm = _f64(settings.projmatrix).reshape(4, 4)
+    campos = _f64(settings.campos).reshape(3)
+    tanx, tany = float(settings.tanfovx), float(settings.tanfovy)
+    fx, fy = W / (2.0 * tanx), H / (2.0 * tany)
+    p = means3D
+    N = p.shape[0]
+    # 1. view space (row-vector convention == column-major read of the flat matrix)
+    t = p @ vm[:3, :3] + vm[3, :3]
+    in_front = t[:, 2] > opt.near_cull_z
+    # 2. clip space
+    ph = p @ pm[:3, :] + pm[3, :]
+    pw = 1.0 / (ph[:, 3] + 1e-7)
+    ndc = ph[:, :2] * pw[:, None]
+    if means2D is not None:
+        # means2D is the zero dummy whose .grad must receive dL/d(ndc)
+        # (gaussian_renderer/__init__.py:48-52; Appendix A 'Render bwd')
+        ndc = ndc + means2D[:, :2]
+    # 3. covariance
+    if cov3D_precomp is not None:
+        cov3d = cov3D_precomp
+    else:
+        cov3d = cov3d_from_scale_rot(scales, rotations, float(settings.scale_modifier))
+    Sig = torch.stack([cov3d[:, 0], cov3d[:, 1], cov3d[:, 2],
+                       cov3d[:, 1], cov3d[:, 3], cov3d[:, 4],
+                       cov3d[:, 2], cov3d[:, 4], cov3d[:, 5]], dim=-1).reshape(N, 3, 3)
+    # 4. EWA
+    tz = t[:, 2]
+    tz_safe = torch.where(in_front, tz, torch.ones_like(tz))
+    limx, limy = 1.3 * tanx, 1.3 * tany
+    txtz, tytz = t[:, 0] / tz_safe, t[:, 1] / tz_safe
+    cx = (txtz < -limx) | (txtz > limx)
+    cy = (tytz < -limy) | (tytz > limy)
+    txc = txtz.clamp(-limx, limx) * tz_safe
+    tyc = tytz.clamp(-limy, limy) * tz_safe
+    if opt.lineage_grads:
+        # the lineage replaces t.x by the clamped value and then treats it as an
+        # independent variable with zero incoming gradient when clamped
+        txc = torch.where(cx, txc.detach(), t[:, 0])
+        tyc = torch.where(cy, tyc.detach(), t[:, 1])
+    zero = torch.zeros_like(tz_safe)
+    J = torch.stack([fx / tz_safe, zero, -fx * txc / (tz_safe * tz_safe),
+                     zero, fy / tz_safe, -fy * tyc / (tz_safe * tz_safe)], dim=-1).reshape(N, 2, 3)
+    Wm = vm[:3, :3].T                                   # math rotation: t = Wm p + trans
+    A = J @ Wm
+    cov2 = A @ Sig @ A.transpose(1, 2)
+    a = cov2[:, 0, 0] + opt.lowpass
+    b = cov2[:, 0, 1]
+    c = cov2[:, 1, 1] + opt.lowpass
+    # 5. conic + radius
+    det = a * c - b * b
+    det_ok = det != 0
+    det_safe = torch.where(det_ok, det, torch.ones_like(det))
+    conic = torch.stack([c / det_safe, -b / det_safe, a / det_safe], dim=-1)
+    mid = 0.5 * (a + c)
+    lam = mid + torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
+    r_real = 3.0 * torch.sqrt(torch.clamp_min(lam, 0.0))
+    radius = torch.ceil(r_real.detach())
+    # 6. pixel centre and tile rect
+    px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5
+    py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    pxd, pyd = px.detach(), py.detach()
+
+    def _rect(lo_real, hi_real, g):
+        lo = torch.trunc(lo_real / TILE).clamp(0, g)
+        hi = torch.trunc(hi_real / TILE).clamp(0, g)
+        return lo.to(torch.int64), hi.to(torch.int64)
+
+    x0, x1 = _rect(pxd - radius, pxd + radius + (TILE - 1), gx)
+    y0, y1 = _rect(pyd - radius, pyd + radius + (TILE - 1), gy)
+    area = (x1 - x0) * (y1 - y0)
+    finite = torch.isfinite(r_real.detach()) & torch.isfinite(pxd) & torch.isfinite(pyd)
+    valid = in_front & det_ok & (area > 0) & finite
+    radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
+    # fragility of the discrete decisions: distance of the real-valued quantities
+    # from the integer boundaries that ceil()/trunc() cut at
+    eps = opt.frag_rel
+    rr = r_real.detach()
+    frag = (torch.abs(rr - torch.round(rr)) < eps * torch.clamp_min(rr, 1.0))
+    for v in ((pxd - radius) / TILE, (pxd + radius + (TILE - 1)) / TILE,
+              (pyd - radius) / TILE, (pyd + radius + (TILE - 1)) / TILE):
+        frag = frag | (torch.abs(v - torch.round(v)) < eps * torch.clamp_min(v.abs(), 1.0))
+    frag = frag | (torch.abs(tz.detach() - opt.near_cull_z) < eps)
+    frag = frag & in_front & finite
+    # 7. colour
+    if colors_precomp is not None:
+        rgb = colors_precomp
+    else:
+        d = p - campos[None, :]
+        d = d / torch.sqrt((d * d).sum(-1, keepdim=True))
+        rgb = torch.clamp_min(eval_sh_colors(int(settings.sh_degree), shs, d) + 0.5, 0.0)
+    rect = torch.stack([x0, y0, x1, y1], dim=-1)
+    rect = torch.where(valid[:, None], rect, torch.zeros_like(rect))
+    return Geom(valid=valid, radii=radii, xy=torch.stack([px, py], -1), depth=tz, conic=conic,
+                rgb=rgb, rect=rect, tiles_touched=torch.where(valid, area, torch.zeros_like(area)),
+                frag_gauss=frag, cov3d=cov3d, ndc=ndc)
+
+
+def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions):
+    """Appendix A 'Render fwd' for one tile.
+
+    xy (G,2), conic (G,3), opac (G,), depth (G,), chans (G,Cc) already in blend
+    order; pixx/pixy (P,) pixel coordinates.  Returns (out (P,Cc), T_final (P,),
+    n_contrib (P,), fragile (P,) bool)."""
+    G = xy.shape[0]
+    P = pixx.shape[0]
+    dx = xy[:, 0:1] - pixx[None, :]
+    dy = xy[:, 1:2] - pixy[None, :]
+    power = -0.5 * (conic[:, 0:1] * dx * dx + conic[:, 2:3] * dy * dy) - conic[:, 1:2] * dx * dy
+    keep_p = power <= 0
+    raw = opac[:, None] * torch.exp(torch.where(keep_p, power, torch.zeros_like(power)))
+    if opt.lineage_grads:
+        alpha = raw + (torch.clamp_max(raw, opt.alpha_max) - raw).detach()   # straight-through clamp
+    else:
+        alpha = torch.clamp_max(raw, opt.alpha_max)
+    keep = keep_p & (alpha.detach() >= opt.alpha_min)
+    a_eff = torch.where(keep, alpha, torch.zeros_like(alpha))
+    one_m = 1.0 - a_eff
+    cp = torch.cumprod(one_m, dim=0)                       # test_T after each Gaussian
+    alive = cp.detach() >= opt.t_stop                       # prefix property (cp is monotone)
+    T_excl = torch.cat([torch.ones(1, P, dtype=cp.dtype), cp[:-1]], dim=0)
+    w = torch.where(alive & keep, a_eff * T_excl, torch.zeros_like(a_eff))
+    out = w.transpose(0, 1) @ chans                         # (P,Cc)
+    T_final = torch.where(alive, cp, torch.ones_like(cp)).amin(dim=0) if G > 0 else torch.ones(P, dtype=torch.float64)
+    idx = torch.arange(1, G + 1, dtype=torch.int64)[:, None]
+    n_contrib = torch.where(alive & keep, idx, torch.zeros_like(idx)).amax(dim=0) if G > 0 else torch.zeros(P, dtype=torch.int64)
+    # fragility: decisions that may flip under float32 evaluation, only where they matter
+    # (before the pixel is done)
+    rel = opt.frag_rel
+    live_before = torch.cat([torch.ones(1, P, dtype=torch.bool), alive[:-1]], dim=0)
+    ad = alpha.detach()
+    f_alpha = (torch.abs(ad - opt.alpha_min) < 4 * rel * opt.alpha_min) & keep_p
+    f_pow = (torch.abs(power.detach()) < 1e-6) & (opac[:, None].detach() >= opt.alpha_min)
+    f_stop = (torch.abs(cp.detach() - opt.t_stop) < 8 * rel * opt.t_stop) & keep
+    f_clamp = torch.zeros_like(f_alpha)  # clamp at 0.99 is continuous in value; not fragile
+    fragile = ((f_alpha | f_pow | f_stop | f_clamp) & live_before).any(dim=0)
+    return out, T_final, n_contrib, fragile
+
+
+@dataclass
+class OracleOut:
+    image: torch.Tensor      # (3,H,W)
+    radii: torch.Tensor      # (N,) int32
+    feats: torch.Tensor      # (F,H,W)
+    depth: torch.Tensor      # (1,H,W)
+    fragile: torch.Tensor    # (H,W) bool: pixel has a borderline discrete decision
+    frag_gauss: torch.Tensor # (N,) bool
+    num_rendered: int        # R = sum of tiles touched (lineage definition)
+    geom: Geom
+    final_T: torch.Tensor    # (H,W)
+    n_contrib: torch.Tensor  # (H,W)
+
+
+def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_precomp=None,
+              opacities=None, scales=None, rotations=None, cov3D_precomp=None,
+              opt: OracleOptions = OracleOptions(), sort_depth: Optional[torch.Tensor] = None,
+              radii_override: Optional[torch.Tensor] = None) -> OracleOut:
+    """Full forward.  All float inputs are promoted to float64 (gradients flow
+    back to the caller's leaves through the promotion).
+
+    sort_depth: optional (N,) float32 keys defining the blend order (e.g. the
+    device's own view-space depths) -- removes order flips between float32 and
+    float64 depth evaluation from the comparison.
+    radii_override: optional (N,) int radii from the device, used *only* for
+    Gaussians the oracle marks fragile."""
+    if (shs is None) == (colors_precomp is None):
+        raise ValueError("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+       ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    W, H = int(settings.image_width), int(settings.image_height)
+    means3D = _f64(means3D)
+    N = means3D.shape[0]
+    shs, colors_precomp, opacities = _f64(shs), _f64(colors_precomp), _f64(opacities)
+    scales, rotations, cov3D_precomp = _f64(scales), _f64(rotations), _f64(cov3D_precomp)
+    means2D = _f64(means2D)
+    F = 0 if sh_objs is None else sh_objs.shape[-1]
+    feats_in = None if sh_objs is None else _f64(sh_objs).reshape(N, F)
+    g = preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotations,
+                   cov3D_precomp, means2D, opt)
+    if radii_override is not None and bool(g.frag_gauss.any()):
+        g = _apply_radii_override(g, radii_override, W, H)
+    bg = _f64(settings.bg).reshape(3)
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    C = 3 + F + 1
+    out = torch.zeros(H, W, C, dtype=torch.float64)
+    out[..., :3] = out[..., :3] + bg              # pixels of empty tiles show background
+    final_T = torch.ones(H, W, dtype=torch.float64)
+    n_contrib = torch.zeros(H, W, dtype=torch.int64)
+    fragile = torch.zeros(H, W, dtype=torch.bool)
+    opac = opacities.reshape(N)
+    chans_all = torch.cat([g.rgb] + ([feats_in] if F else []) + [g.depth[:, None]], dim=-1)
+    key = g.depth.detach() if sort_depth is None else sort_depth.to(torch.float64)
+    key32 = key.to(torch.float32)
+    rect = g.rect
+    vidx = torch.nonzero(g.valid).reshape(-1)
+    for ty in range(gy):
+        in_row = vidx[(rect[vidx, 1] <= ty) & (rect[vidx, 3] > ty)]
+        if in_row.numel() == 0:
+            continue
+        for tx in range(gx):
+            ids = in_row[(rect[in_row, 0] <= tx) & (rect[in_row, 2] > tx)]
+            if ids.numel() == 0:
+                continue
+            # stable sort on the float32 depth bits, ties -> ascending Gaussian index
+            order = torch.sort(key32[ids], stable=True).indices
+            ids = ids[order]
+            x_lo, y_lo = tx * TILE, ty * TILE
+            x_hi, y_hi = min(x_lo + TILE, W), min(y_lo + TILE, H)
+            ys, xs = torch.meshgrid(torch.arange(y_lo, y_hi), torch.arange(x_lo, x_hi), indexing="ij")
+            pixx = xs.reshape(-1).to(torch.float64)
+            pixy = ys.reshape(-1).to(torch.float64)
+            o, Tf, nc, fr = blend_tile(g.xy[ids], g.conic[ids], opac[ids], g.depth[ids],
+                                       chans_all[ids], pixx, pixy, opt)
+            hh, ww = y_hi - y_lo, x_hi - x_lo
+            o = o.reshape(hh, ww, C)
+            Tf2 = Tf.reshape(hh, ww)
+            o = torch.cat([o[..., :3] + Tf2[..., None] * bg, o[..., 3:]], dim=-1)
+            out[y_lo:y_hi, x_lo:x_hi] = o          # CopySlices: differentiable, O(tile)
+            final_T[y_lo:y_hi, x_lo:x_hi] = Tf2.detach()
+            n_contrib[y_lo:y_hi, x_lo:x_hi] = nc.reshape(hh, ww)
+            # depth-order fragility: near-equal float32 keys of neighbours in the list
+            k = key[ids]
+            if k.numel() > 1:
+                near = (k[1:] - k[:-1]).abs() < 4e-7 * k[1:].abs().clamp_min(1e-3)
+                if sort_depth is None and bool(near.any()):
+                    # only matters if both neighbours are seen before the pixel is done
+                    pos = torch.nonzero(near).reshape(-1) + 1      # 1-based index of the first of the pair
+                    fr = fr | (nc >= pos.min())
+            fragile[y_lo:y_hi, x_lo:x_hi] = fr.reshape(hh, ww)
+            # pixels touched by a fragile Gaussian inherit fragility
+            if bool(g.frag_gauss[ids].any()) and radii_override is None:
+                fragile[y_lo:y_hi, x_lo:x_hi] = True
+    canvas = out
+    if opt.feats_bg or opt.depth_normalised:
+        raise NotImplementedError("non-default lineage switches are not wired into assembly yet")
+    img = canvas[..., :3].permute(2, 0, 1)
+    feats = canvas[..., 3:3 + F].permute(2, 0, 1)
+    depth = canvas[..., 3 + F:].permute(2, 0, 1)
+    return OracleOut(image=img, radii=g.radii, feats=feats, depth=depth, fragile=fragile,
+                     frag_gauss=g.frag_gauss, num_rendered=int(g.tiles_touched.sum()), geom=g,
+                     final_T=final_T, n_contrib=n_contrib)
+
+
+def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:
+    ro = radii_override.to(torch.float64)
+    radius = torch.where(g.frag_gauss, ro, g.radii.to(torch.float64))
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    pxd, pyd = g.xy[:, 0].detach(), g.xy[:, 1].detach()
+    x0 = torch.trunc((pxd - radius) / TILE).clamp(0, gx).to(torch.int64)
+    x1 = torch.trunc((pxd + radius + (TILE - 1)) / TILE).clamp(0, gx).to(torch.int64)
+    y0 = torch.trunc((pyd - radius) / TILE).clamp(0, gy).to(torch.int64)
+    y1 = torch.trunc((pyd + radius + (TILE - 1)) / TILE).clamp(0, gy).to(torch.int64)
+    area = (x1 - x0) * (y1 - y0)
+    valid = torch.where(g.frag_gauss, (ro > 0) & (area > 0), g.valid)
+    rect = torch.stack([x0, y0, x1, y1], -1)
+    rect = torch.where(valid[:, None], rect, torch.zeros_like(rect))
+    g.valid = valid
+    g.rect = rect
+    g.radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
+    g.tiles_touched = torch.where(valid, area, torch.zeros_like(area))
+    return g

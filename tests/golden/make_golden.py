@@ -1,0 +1,152 @@
+"""Generates the golden fixtures in this directory from the *imported reference* (Python parts of
+yunjinli/TRASE at /root/reference).  Runs only in the build container; the reference never
+travels to the GPU box -- only the .npz files written here do.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  G1 sh_eval.npz        utils/sh_utils.py:57-112 eval_sh, + the colour rule gaussian_renderer/__init__.py:105-108
+  G2 cov3d.npz          utils/general_utils.py:122-154 build_scaling_rotation + strip_symmetric (scene/gaussian_model.py:37-41)
+  G3 camera.npz         utils/graphics_utils.py:45-77 getWorld2View2/getProjectionMatrix + scene/cameras.py:76-79
+  G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
+  G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name in ("plyfile", "pytorch3d", "pytorch3d.ops", "simple_knn", "simple_knn._C",
+                 "diff_gaussian_rasterization", "torchvision", "torchvision.models", "torchvision.utils",
+                 "cv2", "imageio"):
+        if name not in sys.modules:
+            _stub(name)
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    sys.modules["pytorch3d.ops"].knn_points = None
+    sys.modules["pytorch3d"].ops = sys.modules["pytorch3d.ops"]
+    sys.modules["torchvision.utils"].save_image = None
+    sys.modules["pytorch3d.ops"].ball_query = None
+    sys.modules["plyfile"].PlyData = None
+    sys.modules["plyfile"].PlyElement = None
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizationSettings = None
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizer = None
+
+
+class no_cuda_kwarg:
+    """Drops device='cuda' from torch factory calls while reference code runs on the CPU."""
+
+    def __enter__(self):
+        self.saved = {}
+        for fn in ("zeros", "ones", "empty", "tensor", "zeros_like", "rand"):
+            orig = getattr(torch, fn)
+            self.saved[fn] = orig
+
+            def wrap(*a, __orig=orig, **k):
+                if str(k.get("device", "")).startswith("cuda"):
+                    k.pop("device")
+                return __orig(*a, **k)
+            setattr(torch, fn, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for fn, orig in self.saved.items():
+            setattr(torch, fn, orig)
+
+
+def main():
+    import_reference()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    from utils.sh_utils import eval_sh
+    from utils.general_utils import build_scaling_rotation, strip_symmetric
+    from utils.graphics_utils import getWorld2View2, getProjectionMatrix
+
+    # ---- G1
+    n = 257
+    shs = torch.randn(n, 16, 3) * 0.4            # (N,16,3) as stored by GaussianModel.get_features
+    xyz = torch.randn(n, 3) * 2.0
+    campos = torch.tensor([0.3, -0.2, 4.0])
+    out = {}
+    for deg in range(4):
+        shs_view = shs.transpose(1, 2).view(-1, 3, 16)     # gaussian_renderer/__init__.py:104
+        dir_pp = xyz - campos.repeat(n, 1)
+        dir_n = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        sh2rgb = eval_sh(deg, shs_view, dir_n)
+        out[f"rgb_deg{deg}"] = torch.clamp_min(sh2rgb + 0.5, 0.0).numpy()
+        out[f"raw_deg{deg}"] = sh2rgb.numpy()
+    np.savez_compressed(os.path.join(HERE, "sh_eval.npz"), shs=shs.numpy(), xyz=xyz.numpy(), campos=campos.numpy(), **out)
+
+    # ---- G2
+    s = torch.rand(n, 3) * 0.2 + 0.01
+    q = torch.nn.functional.normalize(torch.randn(n, 4))
+    with no_cuda_kwarg():
+        L = build_scaling_rotation(1.3 * s, q)
+        cov = strip_symmetric(L @ L.transpose(1, 2))
+    np.savez_compressed(os.path.join(HERE, "cov3d.npz"), scales=s.numpy(), rotations=q.numpy(), modifier=np.float32(1.3),
+                        cov6=cov.numpy())
+
+    # ---- G3
+    ang = 0.7
+    R = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]], dtype=np.float64)
+    T = np.array([0.1, -0.3, 4.2])
+    fovx, fovy = 0.9, 0.6
+    w2v = getWorld2View2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)
+    wvt = torch.tensor(w2v).transpose(0, 1)
+    proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+    center = wvt.inverse()[3, :3]
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), R=R, T=T, fovx=fovx, fovy=fovy, world_view_transform=wvt.numpy(),
+                        projection_matrix=proj.numpy(), full_proj_transform=full.numpy(), camera_center=center.numpy())
+
+    # ---- G4
+    from utils.time_utils import DeformNetwork
+    torch.manual_seed(1)
+    net = DeformNetwork(D=8, W=256, multires=10, is_blender=False, is_6dof=False)
+    m = 96
+    x = (torch.rand(m, 3) * 2 - 1).requires_grad_(False)
+    t = torch.full((m, 1), 0.37)
+    d_xyz, d_rot, d_scale = net(x, t)
+    gx, gr, gs = torch.randn_like(d_xyz), torch.randn_like(d_rot), torch.randn_like(d_scale)
+    loss = (d_xyz * gx).sum() + (d_rot * gr).sum() + (d_scale * gs).sum()
+    loss.backward()
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    grads = {"grad_" + k: p.grad.detach().numpy() for k, p in net.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "deform_mlp.npz"), x=x.numpy(), t=t.numpy(), d_xyz=d_xyz.detach().numpy(),
+                        d_rotation=d_rot.detach().numpy(), d_scaling=d_scale.detach().numpy(), gx=gx.numpy(),
+                        gr=gr.numpy(), gs=gs.numpy(), **{"w_" + k: v for k, v in sd.items()}, **grads)
+
+    # ---- G5
+    from utils.loss_utils import l1_loss, ssim
+    a = torch.rand(3, 48, 64)
+    b = (a + 0.1 * torch.randn(3, 48, 64)).clamp(0, 1)
+    a.requires_grad_(True)
+    l1 = l1_loss(a, b)
+    ss = ssim(a, b)
+    total = (1.0 - 0.2) * l1 + 0.2 * (1.0 - ss)            # train.py:235-238
+    total.backward()
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=ss.item(),
+                        total=total.item(), grad_a=a.grad.numpy())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

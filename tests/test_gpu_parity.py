@@ -1,0 +1,245 @@
+"""Parity of the HIP path (through the C-ABI library and the reference-shaped Python operator)
+against the float64 oracle.  Tolerances: maps 1e-4 abs; gradients
+rtol 1e-3 + atol 1e-5 * max|grad| -- fp32 atomics reorder the per-Gaussian sums."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from tests.util import settings_for, small_case
+
+pytestmark = pytest.mark.gpu
+
+MAP_ATOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def _gpu_call(act, st_cpu, colors=None, cov=None, need_grad=True):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    st = GaussianRasterizationSettings(**{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in st_cpu._asdict().items()})
+    leaves = {}
+    for k in ("means3D", "opacities", "scales", "rotations", "shs", "sh_objs"):
+        v = act.get(k)
+        leaves[k] = None if v is None else v.to(dev).clone().requires_grad_(need_grad)
+    if colors is not None:
+        leaves["colors_precomp"] = colors.to(dev).clone().requires_grad_(need_grad)
+        leaves["shs"] = None
+    if cov is not None:
+        leaves["cov3D_precomp"] = cov.to(dev).clone().requires_grad_(need_grad)
+        leaves["scales"] = leaves["rotations"] = None
+    n = act["means3D"].shape[0]
+    means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+    leaves["means2D"] = means2D
+    rast = GaussianRasterizer(raster_settings=st)
+    out = rast(means3D=leaves["means3D"], means2D=means2D, shs=leaves.get("shs"), sh_objs=leaves.get("sh_objs"),
+               colors_precomp=leaves.get("colors_precomp"), opacities=leaves["opacities"], scales=leaves.get("scales"),
+               rotations=leaves.get("rotations"), cov3D_precomp=leaves.get("cov3D_precomp"))
+    return out, leaves
+
+
+def _oracle_call(act, st_cpu, colors=None, cov=None):
+    leaves = {}
+    for k in ("means3D", "opacities", "scales", "rotations", "shs", "sh_objs"):
+        v = act.get(k)
+        leaves[k] = None if v is None else v.double().clone().requires_grad_(True)
+    if colors is not None:
+        leaves["colors_precomp"] = colors.double().clone().requires_grad_(True)
+        leaves["shs"] = None
+    if cov is not None:
+        leaves["cov3D_precomp"] = cov.double().clone().requires_grad_(True)
+        leaves["scales"] = leaves["rotations"] = None
+    n = act["means3D"].shape[0]
+    leaves["means2D"] = torch.zeros(n, 3, dtype=torch.float64, requires_grad=True)
+    out = ro.rasterize(st_cpu, leaves["means3D"], leaves["means2D"], shs=leaves.get("shs"), sh_objs=leaves.get("sh_objs"),
+                       colors_precomp=leaves.get("colors_precomp"), opacities=leaves["opacities"],
+                       scales=leaves.get("scales"), rotations=leaves.get("rotations"),
+                       cov3D_precomp=leaves.get("cov3D_precomp"))
+    return out, leaves
+
+
+def _check_maps(gpu_out, o, frag_budget=0.03):
+    image, radii, feats, depth = [t.detach().cpu() for t in gpu_out]
+    okg = ~o.frag_gauss
+    assert torch.equal(radii[okg], o.radii[okg]), "radii mismatch on non-fragile Gaussians"
+    ok = ~o.fragile
+    assert ok.float().mean() > 1 - frag_budget, f"too many fragile pixels: {1 - ok.float().mean():.4f}"
+    for name, a, b in (("image", image, o.image), ("feats", feats, o.feats), ("depth", depth, o.depth)):
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        if a.numel() == 0:
+            continue
+        err = (a.double() - b.detach()).abs()
+        assert err[:, ok].max().item() < MAP_ATOL, f"{name}: max abs err {err[:, ok].max().item():.3e}"
+        # even where a discrete gate may flip the damage is bounded by one alpha_min-sized contribution
+        scale = max(1.0, b.detach().abs().max().item())
+        assert err.max().item() < 0.05 * scale, f"{name}: fragile-pixel error {err.max().item():.3e}"
+
+
+def _excluded_gaussians(o):
+    """Gaussians whose tiles contain a fragile pixel (their gradients may legitimately differ)."""
+    H, W = o.fragile.shape
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    bad_tile = torch.zeros(gy, gx, dtype=torch.bool)
+    ys, xs = torch.nonzero(o.fragile, as_tuple=True)
+    bad_tile[ys // 16, xs // 16] = True
+    rect = o.geom.rect
+    ex = o.frag_gauss.clone()
+    for i in torch.nonzero(o.geom.valid).reshape(-1).tolist():
+        x0, y0, x1, y1 = rect[i].tolist()
+        if bad_tile[y0:y1, x0:x1].any():
+            ex[i] = True
+    return ex
+
+
+def _check_grads(gl, ol, ex, names, rtol=1e-3, atol_rel=1e-5):
+    keep = ~ex
+    assert keep.sum() > 0.5 * keep.numel(), "too many Gaussians excluded as fragile"
+    for k in names:
+        a, b = gl[k].grad, ol[k].grad
+        assert a is not None, f"no gradient for {k}"
+        a = a.detach().cpu().double().reshape(a.shape[0], -1)[keep]
+        b = b.reshape(b.shape[0], -1)[keep]
+        tol = rtol * b.abs() + atol_rel * max(b.abs().max().item(), 1e-12) + 1e-9
+        bad = (a - b).abs() > tol
+        assert not bad.any(), (f"{k}: {int(bad.sum())} / {bad.numel()} entries off; worst "
+                               f"{((a - b).abs() / (b.abs() + 1e-12)).max().item():.3e} rel, {(a - b).abs().max().item():.3e} abs")
+
+
+def test_selftest_wave_primitives():
+    from trase_amd.rasterizer import selftest
+    print(selftest())
+
+
+@pytest.mark.parametrize("n,w,h,feat,seed,scale", [(400, 96, 64, 32, 0, 0.9), (1500, 160, 112, 32, 1, 0.7),
+                                                    (300, 100, 70, 16, 2, 1.5), (1000, 128, 128, 0, 3, 0.6)])
+def test_forward_backward_parity(n, w, h, feat, seed, scale):
+    act, cam = small_case(n=n, w=w, h=h, feat=feat, seed=seed, scale_mult=scale, d_rot=0.05)
+    st = settings_for(cam, bg=(0.1, 0.25, 0.4))
+    o, ol = _oracle_call(act, st)
+    g, gl = _gpu_call(act, st)
+    _check_maps(g, o)
+    gen = torch.Generator().manual_seed(seed)
+    gi = torch.randn(3, h, w, generator=gen)
+    gf = torch.randn(feat, h, w, generator=gen)
+    (o.image * gi.double()).sum().add((o.feats * gf.double()).sum()).backward()
+    torch.autograd.backward([g[0], g[2]] if feat else [g[0]], [gi.cuda(), gf.cuda()] if feat else [gi.cuda()])
+    names = ["means3D", "means2D", "opacities", "scales", "rotations", "shs"] + (["sh_objs"] if feat else [])
+    _check_grads(gl, ol, _excluded_gaussians(o), names)
+
+
+def test_precomputed_colour_and_covariance_inputs():
+    act, cam = small_case(n=500, w=96, h=96, feat=32, seed=4, scale_mult=1.0)
+    st = settings_for(cam, bg=(1.0, 1.0, 1.0))
+    colors = torch.rand(500, 3)
+    cov = ro.cov3d_from_scale_rot(act["scales"].double(), act["rotations"].double(), 1.0).float()
+    o, ol = _oracle_call(act, st, colors=colors, cov=cov)
+    g, gl = _gpu_call(act, st, colors=colors, cov=cov)
+    _check_maps(g, o)
+    gi = torch.randn(3, 96, 96)
+    (o.image * gi.double()).sum().backward()
+    g[0].backward(gi.cuda())
+    _check_grads(gl, ol, _excluded_gaussians(o), ["means3D", "means2D", "opacities", "colors_precomp", "cov3D_precomp"])
+    # feature map unused by the loss: its input gets exact zeros (or no gradient)
+    assert gl["sh_objs"].grad is None or float(gl["sh_objs"].grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_lower_sh_degrees(deg):
+    act, cam = small_case(n=300, w=80, h=64, feat=0, seed=10 + deg)
+    st = settings_for(cam, sh_degree=deg)
+    o, _ = _oracle_call(act, st)
+    g, _ = _gpu_call(act, st, need_grad=False)
+    _check_maps(g, o)
+
+
+def test_feature_only_loss_feature_state():
+    """FEATURE state of train.py:244-296: only sh_objs requires grad, image cotangent absent."""
+    act, cam = small_case(n=600, w=112, h=80, feat=32, seed=6, scale_mult=1.0)
+    st = settings_for(cam)
+    o, ol = _oracle_call(act, st)
+    g, gl = _gpu_call(act, st)
+    gf = torch.randn(32, 80, 112)
+    (o.feats * gf.double()).sum().backward()
+    g[2].backward(gf.cuda())
+    _check_grads(gl, ol, _excluded_gaussians(o), ["sh_objs", "opacities", "means3D", "means2D"])
+
+
+def test_edge_cases_empty_culled_and_huge():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    act, cam = small_case(n=64, w=50, h=34, feat=32, seed=8)
+    st = settings_for(cam, bg=(0.3, 0.6, 0.9), device=dev)
+    rast = GaussianRasterizer(raster_settings=st)
+    # (a) no Gaussians at all
+    e = lambda *s: torch.empty(*s, device=dev)
+    img, radii, feats, depth = rast(means3D=e(0, 3), means2D=e(0, 3), shs=e(0, 16, 3), sh_objs=e(0, 1, 32),
+                                    opacities=e(0, 1), scales=e(0, 3), rotations=e(0, 4))
+    assert radii.numel() == 0 and float(feats.abs().max()) == 0 and float(depth.abs().max()) == 0
+    np.testing.assert_allclose(img.mean(dim=(1, 2)).cpu().numpy(), [0.3, 0.6, 0.9], rtol=1e-6)
+    # (b) everything behind the camera
+    a = {k: (v.to(dev) if v is not None else None) for k, v in act.items()}
+    behind = a["means3D"] + torch.tensor([0.0, 0.0, 0.0], device=dev) + 20.0 * cam.camera_center.to(dev) / cam.camera_center.norm()
+    img, radii, feats, depth = rast(means3D=behind, means2D=torch.zeros_like(behind), shs=a["shs"], sh_objs=a["sh_objs"],
+                                    opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"])
+    assert int(radii.max()) == 0 and float(depth.abs().max()) == 0
+    # (c) one huge opaque Gaussian covering the whole (ragged, non-multiple-of-16) image
+    big = dict(means3D=torch.zeros(1, 3), shs=torch.zeros(1, 16, 3), sh_objs=torch.ones(1, 1, 32),
+               opacities=torch.full((1, 1), 0.999), scales=torch.full((1, 3), 5.0), rotations=torch.tensor([[1.0, 0, 0, 0]]))
+    st_cpu = settings_for(cam, bg=(0.3, 0.6, 0.9))
+    o, _ = _oracle_call(big, st_cpu)
+    g, _ = _gpu_call(big, st_cpu, need_grad=False)
+    _check_maps(g, o)
+    assert float(g[2].min()) > 0.9
+
+
+def test_argument_errors_match_reference_wording():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    act, cam = small_case(n=8, w=32, h=32)
+    rast = GaussianRasterizer(raster_settings=settings_for(cam, device=dev))
+    a = {k: v.to(dev) for k, v in act.items()}
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=a["means3D"], means2D=torch.zeros(8, 3, device=dev), opacities=a["opacities"], scales=a["scales"],
+             rotations=a["rotations"], sh_objs=a["sh_objs"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=a["means3D"], means2D=torch.zeros(8, 3, device=dev), opacities=a["opacities"], shs=a["shs"],
+             sh_objs=a["sh_objs"])
+
+
+def test_nosync_capacity_policy_and_overflow_flag():
+    from trase_amd import rasterizer as R
+    act, cam = small_case(n=800, w=128, h=96, feat=32, seed=12)
+    st = settings_for(cam)
+    try:
+        R.set_sync(True)
+        g_sync, _ = _gpu_call(act, st, need_grad=False)
+        n_pairs = R.last_status()[0]
+        R.set_sync(False, capacity=int(n_pairs * 1.5) + 16)
+        g_async, _ = _gpu_call(act, st, need_grad=False)
+        assert R.last_status()[:2] == (n_pairs, 0)
+        for a, b in zip(g_sync, g_async):
+            assert torch.equal(a, b)
+        R.set_sync(False, capacity=max(n_pairs // 2, 1))
+        _gpu_call(act, st, need_grad=False)
+        assert R.last_status()[1] == 1, "overflow must be flagged when the pair buffer is too small"
+    finally:
+        R.set_sync(True)
+
+
+def test_distcuda2_matches_kdtree():
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(0)
+    for pts in (rng.uniform(-1.3, 1.3, size=(20000, 3)), rng.normal(size=(5000, 3)) * [1.0, 0.05, 2.0],
+                np.concatenate([rng.uniform(size=(500, 3)), rng.uniform(size=(500, 3)) * 1e-3 + 5.0])):
+        pts = pts.astype(np.float32)
+        d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+        want = (d[:, 1:] ** 2).mean(axis=1)
+        got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-10)

@@ -1,0 +1,348 @@
+// api.hip -- C-ABI entry points of include/trase_rast.h: argument validation, workspace carving,
+// kernel sequencing on the caller's stream.  No torch types, no persistent allocations.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace trase {
+
+// ---- error reporting ------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return TRASE_ERR_HIP;
+}
+
+// ---- opt-in profiler (the only global state; off by default) -----------------------------------------
+struct ProfRec { std::string name; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec*> g_prof_recs;
+
+bool prof_on() { return g_prof_on; }
+
+ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), rec(nullptr) {
+  if (!g_prof_on) return;
+  ProfRec* r = new ProfRec();
+  r->name = n;
+  if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) { delete r; return; }
+  hipEventRecord(r->e0, s);
+  rec = r;
+}
+
+ProfScope::~ProfScope() {
+  if (!rec) return;
+  ProfRec* r = (ProfRec*)rec;
+  hipEventRecord(r->e1, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_recs.push_back(r);
+}
+
+// ---- workspace layout ---------------------------------------------------------------------------------
+static inline int rs_blocks(size_t n) { return (int)((n + 2047) / 2048); }
+
+size_t geom_bytes(int P) {
+  const size_t p = (size_t)P;
+  return align_up(sizeof(uint32_t) * HDR_WORDS) + align_up(sizeof(float2) * p) + align_up(sizeof(float4) * p) * 2 +
+         align_up(sizeof(uint32_t) * p) * 2;
+}
+GeomBuf carve_geom(void* ptr, int P) {
+  const size_t p = (size_t)P;
+  char* c = (char*)ptr;
+  GeomBuf g;
+  g.hdr = (uint32_t*)c; c += align_up(sizeof(uint32_t) * HDR_WORDS);
+  g.xy = (float2*)c; c += align_up(sizeof(float2) * p);
+  g.conic_o = (float4*)c; c += align_up(sizeof(float4) * p);
+  g.rgbd = (float4*)c; c += align_up(sizeof(float4) * p);
+  g.tiles = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
+  g.clamped = (uint32_t*)c;
+  return g;
+}
+size_t bin_bytes(int64_t cap, int T) { return align_up(sizeof(uint32_t) * (size_t)cap) + align_up(sizeof(uint2) * (size_t)T); }
+BinBuf carve_bin(void* ptr, int64_t cap, int T) {
+  char* c = (char*)ptr;
+  BinBuf b;
+  b.point_list = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (size_t)cap);
+  b.ranges = (uint2*)c;
+  (void)T;
+  return b;
+}
+size_t img_bytes(int W, int H) { return align_up(sizeof(float) * (size_t)W * H) * 2; }
+ImgBuf carve_img(void* ptr, int W, int H) {
+  char* c = (char*)ptr;
+  ImgBuf i;
+  i.final_T = (float*)c; c += align_up(sizeof(float) * (size_t)W * H);
+  i.n_contrib = (uint32_t*)c;
+  return i;
+}
+static size_t sort_bytes_common(size_t n) {   // hist + digit_total
+  return align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n)) + align_up(sizeof(uint32_t) * 256 * 8);
+}
+size_t pre_bytes(int P) {
+  const size_t p = (size_t)(P > 0 ? P : 1);
+  return align_up(sizeof(uint32_t) * p) * 5 + align_up(sizeof(uint32_t) * (p / 1024 + 2)) + sort_bytes_common(p);
+}
+PreBuf carve_pre(void* ptr, int P) {
+  const size_t p = (size_t)(P > 0 ? P : 1);
+  char* c = (char*)ptr;
+  PreBuf t;
+  for (int i = 0; i < 2; ++i) { t.sort.keys[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
+  for (int i = 0; i < 2; ++i) { t.sort.vals[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
+  t.offsets = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
+  t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2));
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
+  t.sort.digit_total = (uint32_t*)c;
+  t.sort.nb_max = rs_blocks(p);
+  return t;
+}
+size_t tmp_bytes(int64_t cap) {
+  const size_t n = (size_t)cap;
+  return align_up(sizeof(uint32_t) * n) * 3 + sort_bytes_common(n);
+}
+PairBuf carve_tmp(void* ptr, int64_t cap) {
+  const size_t n = (size_t)cap;
+  char* c = (char*)ptr;
+  PairBuf t;
+  for (int i = 0; i < 2; ++i) { t.sort.keys[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n); }
+  t.spare_vals = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n);
+  t.sort.vals[0] = t.sort.vals[1] = nullptr;
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n));
+  t.sort.digit_total = (uint32_t*)c;
+  t.sort.nb_max = rs_blocks(n);
+  return t;
+}
+size_t bwd_tmp_bytes(int P) { return align_up(sizeof(float) * BWD_ACC * (size_t)P); }
+
+static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
+  if (!s || !in) { set_error("null settings/inputs"); return TRASE_ERR_INVALID; }
+  if (in->P < 0 || s->image_width <= 0 || s->image_height <= 0) { set_error("bad sizes"); return TRASE_ERR_INVALID; }
+  if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
+    set_error("Please provide excatly one of either SHs or precomputed colors!");   // wording of the lineage's wrapper
+    return TRASE_ERR_INVALID;
+  }
+  const bool sr = in->scales != nullptr || in->rotations != nullptr;
+  if ((sr && in->cov3D_precomp) || (!sr && !in->cov3D_precomp) || (sr && (!in->scales || !in->rotations))) {
+    set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return TRASE_ERR_INVALID;
+  }
+  if (!in->means3D || !in->opacities) { set_error("means3D/opacities are required"); return TRASE_ERR_INVALID; }
+  if (s->sh_degree < 0 || s->sh_degree > 3) { set_error("sh_degree %d outside 0..3", s->sh_degree); return TRASE_ERR_INVALID; }
+  if (in->shs && (in->M < (s->sh_degree + 1) * (s->sh_degree + 1) || in->M > 16)) {
+    set_error("shs holds %d coefficients, degree %d needs %d (max 16)", in->M, s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1));
+    return TRASE_ERR_INVALID;
+  }
+  if (in->F != 0 && in->F != 16 && in->F != 32) { set_error("feature width %d not compiled in (0,16,32)", in->F); return TRASE_ERR_UNSUPPORTED; }
+  if (in->F > 0 && !in->sh_objs) { set_error("F>0 but sh_objs is null"); return TRASE_ERR_INVALID; }
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) { set_error("bg/viewmatrix/projmatrix/campos are required"); return TRASE_ERR_INVALID; }
+  return TRASE_OK;
+}
+
+enum { WS_GEOM = 1, WS_PRE = 2, WS_BIN = 4, WS_IMG = 8, WS_TMP = 16 };
+static int check_ws(const TraseRastInputs* in, const TraseRastSettings* s, const TraseRastWorkspace* ws, int need) {
+  if (!ws) { set_error("null workspace"); return TRASE_ERR_WORKSPACE; }
+  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  if ((need & WS_GEOM) && (!ws->geom || ws->geom_bytes < geom_bytes(in->P))) { set_error("geom workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
+  if ((need & WS_PRE) && (!ws->pre || ws->pre_bytes < pre_bytes(in->P))) { set_error("pre workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
+  if (need & (WS_BIN | WS_TMP)) {
+    if (ws->capacity < 1 || ws->capacity > 0xfffffff0ll) { set_error("capacity out of range"); return TRASE_ERR_WORKSPACE; }
+  }
+  if ((need & WS_BIN) && (!ws->bin || ws->bin_bytes < bin_bytes(ws->capacity, gx * gy))) { set_error("bin workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
+  if ((need & WS_IMG) && (!ws->img || ws->img_bytes < img_bytes(s->image_width, s->image_height))) { set_error("img workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
+  if ((need & WS_TMP) && (!ws->tmp || ws->tmp_bytes < tmp_bytes(ws->capacity))) { set_error("tmp workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
+  return TRASE_OK;
+}
+
+}  // namespace trase
+
+using namespace trase;
+
+extern "C" {
+
+const char* trase_last_error(void) { return g_err; }
+const char* trase_version(void) { return "trase_amd 0.1 (gfx950)"; }
+
+int trase_rast_sizes(int32_t P, int32_t W, int32_t H, int32_t F, int64_t capacity, TraseRastSizes* out) {
+  (void)F;
+  if (!out || P < 0 || W <= 0 || H <= 0 || capacity < 1) { set_error("trase_rast_sizes: bad arguments"); return TRASE_ERR_INVALID; }
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  out->geom_bytes = geom_bytes(P);
+  out->bin_bytes = bin_bytes(capacity, gx * gy);
+  out->img_bytes = img_bytes(W, H);
+  out->pre_bytes = pre_bytes(P);
+  out->tmp_bytes = tmp_bytes(capacity);
+  out->bwd_tmp_bytes = bwd_tmp_bytes(P);
+  return TRASE_OK;
+}
+
+int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                          const TraseRastWorkspace* ws, trase_stream_t stream_) {
+  int rc = validate(s, in);
+  if (rc) return rc;
+  if (!out || !out->radii) { set_error("radii output required"); return TRASE_ERR_INVALID; }
+  rc = check_ws(in, s, ws, WS_GEOM | WS_PRE);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  GeomBuf g = carve_geom(ws->geom, in->P);
+  PreBuf t = carve_pre(ws->pre, in->P);
+  TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
+  if (in->P == 0) return TRASE_OK;
+  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[0]);
+  if (rc) return rc;
+  // depth order of the Gaussians: stable sort of float32 depth bits, ids generated on the fly
+  int idx = 0;
+  rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)in->P, 0, 32, true, &idx);
+  if (rc) return rc;
+  if (idx != 0) {   // 4 passes: the sorted ids are back in vals[0], where stage 2 reads them
+    set_error("internal: depth sort ended in buffer %d", idx);
+    return TRASE_ERR_INVALID;
+  }
+  // the pair count is compared against the capacity later (stage 2 knows it); 0xffffffff = no limit yet
+  return launch_scan_tiles(c, g, t.sort.vals[0], in->P, t, 0xffffffffu);
+}
+
+int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream_) {
+  if (!ws || !ws->geom || !status) { set_error("trase_rast_status: bad arguments"); return TRASE_ERR_INVALID; }
+  uint32_t h[4];
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipMemcpyAsync(h, ws->geom, sizeof(h), hipMemcpyDeviceToHost, stream));
+  TRASE_CHECK(hipStreamSynchronize(stream));
+  status[0] = h[HDR_R]; status[1] = h[HDR_OVERFLOW]; status[2] = h[HDR_R_EFF];
+  return TRASE_OK;
+}
+
+int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                      const TraseRastWorkspace* ws, trase_stream_t stream_) {
+  int rc = validate(s, in);
+  if (rc) return rc;
+  if (!out || !out->image || !out->depth || !out->radii || (in->F > 0 && !out->feats)) { set_error("null output"); return TRASE_ERR_INVALID; }
+  rc = check_ws(in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG | WS_TMP);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  const int T = gx * gy;
+  GeomBuf g = carve_geom(ws->geom, in->P);
+  BinBuf b = carve_bin(ws->bin, ws->capacity, T);
+  ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
+  PreBuf pre = carve_pre(ws->pre, in->P);
+  PairBuf t = carve_tmp(ws->tmp, ws->capacity);
+  const uint32_t cap = (uint32_t)ws->capacity;
+  if (in->P > 0) {
+    int bits = 1;
+    while ((1 << bits) < T) ++bits;
+    // arrange the value ping-pong so that the last pass lands in the saved point list
+    const int passes = radix_passes(0, bits);
+    const int final_idx = passes & 1;
+    t.sort.vals[final_idx] = b.point_list;
+    t.sort.vals[final_idx ^ 1] = t.spare_vals;
+    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.sort.vals[0], cap);
+    if (rc) return rc;
+    int idx = 0;
+    rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R, cap, 0, bits, false, &idx);
+    if (rc) return rc;
+    if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
+    rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R, cap, b.ranges, T);
+    if (rc) return rc;
+  } else {
+    TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, stream));
+  }
+  return launch_render_fwd(c, *s, *in, *out, g, b, im);
+}
+
+int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                       const TraseRastWorkspace* ws, trase_stream_t stream) {
+  int rc = trase_rast_preprocess(s, in, out, ws, stream);
+  if (rc) return rc;
+  return trase_rast_render(s, in, out, ws, stream);
+}
+
+int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                        const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
+  int rc = validate(s, in);
+  if (rc) return rc;
+  if (!gr || !out || !out->radii) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
+  rc = check_ws(in, s, ws, WS_GEOM | WS_BIN | WS_IMG);
+  if (rc) return rc;
+  if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in->P)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  GeomBuf g = carve_geom(ws->geom, in->P);
+  BinBuf b = carve_bin(ws->bin, ws->capacity, gx * gy);
+  ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
+  float* acc = (float*)ws->tmp;
+  if (in->P == 0) return TRASE_OK;
+  TRASE_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * BWD_ACC * (size_t)in->P, stream));
+  if (gr->dL_dsh_objs && in->F > 0)
+    TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
+  TraseRastGrads g2 = *gr;
+  if (!(s->variant & 0x100)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
+  TraseRastInputs in2 = *in;
+  if (!g2.dL_dfeats || !g2.dL_dsh_objs) {
+    // feature map unused by the loss (GAUSSIAN state) or features frozen: the feature channels
+    // contribute nothing we need unless their cotangent also drives alpha
+    if (!g2.dL_dfeats) { in2.F = 0; g2.dL_dsh_objs = nullptr; }
+  }
+  rc = launch_render_bwd(c, *s, in2, g, b, im, g2, acc);
+  if (rc) return rc;
+  return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);
+}
+
+int trase_prof_enable(int enable) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = enable != 0;
+  if (enable) {
+    for (ProfRec* r : g_prof_recs) { hipEventDestroy(r->e0); hipEventDestroy(r->e1); delete r; }
+    g_prof_recs.clear();
+  }
+  return TRASE_OK;
+}
+
+int trase_prof_report(char* buf, size_t buf_bytes) {
+  if (!buf || buf_bytes < 4) return TRASE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::map<std::string, std::pair<double, int>> agg;
+  for (ProfRec* r : g_prof_recs) {
+    if (hipEventSynchronize(r->e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r->e0, r->e1) != hipSuccess) continue;
+    auto& a = agg[r->name];
+    a.first += ms; a.second += 1;
+  }
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char tmp[256];
+    snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"ms\": %.6f, \"n\": %d}", first ? "" : ", ", kv.first.c_str(),
+             kv.second.first / (kv.second.second > 0 ? kv.second.second : 1), kv.second.second);
+    js += tmp;
+    first = false;
+  }
+  js += "}";
+  for (ProfRec* r : g_prof_recs) { hipEventDestroy(r->e0); hipEventDestroy(r->e1); delete r; }
+  g_prof_recs.clear();
+  if (js.size() + 1 > buf_bytes) { set_error("profile report buffer too small"); return TRASE_ERR_WORKSPACE; }
+  memcpy(buf, js.c_str(), js.size() + 1);
+  return TRASE_OK;
+}
+
+}  // extern "C"

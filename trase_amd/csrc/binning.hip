@@ -1,0 +1,357 @@
+// binning.hip -- builds the per-tile, depth-ordered Gaussian lists.
+//
+// Replaces the lineage's duplicateWithKeys + 64-bit cub::DeviceRadixSort +
+// identifyTileRanges (SURVEY.md 2.2 kernel inventory) with a decomposition that
+// moves ~4x fewer bytes and yields the *identical* order:
+//   1. stable radix sort of the P Gaussians by float32 depth bits (ties keep
+//      ascending Gaussian index)                       -- 4 passes over P items
+//   2. inclusive scan of tiles-touched in depth-rank order
+//   3. emit (tile, id) pairs rank-major                 -- R pairs, already depth-ordered
+//   4. stable radix sort of the pairs by tile id only   -- 2 passes over R items
+// A stable sort by tile of a depth-ordered sequence is exactly the lineage's
+// (tile<<32 | depth) order.  All kernels take the pair count from device memory
+// so the host never has to synchronise.
+#include "common.h"
+
+namespace trase {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 2048 items per workgroup
+constexpr int RS_SEG = WAVE * RS_ITEMS;          // 512 contiguous items per wave
+
+__device__ __forceinline__ uint32_t dev_n(const uint32_t* n_ptr, uint32_t cap) {
+  const uint32_t n = *n_ptr;
+  return n < cap ? n : cap;
+}
+
+// ---- pass kernel 1: per-workgroup digit histograms --------------------------------------------
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                                int shift, uint32_t mask, uint32_t* __restrict__ hist,
+                                                                uint32_t* __restrict__ digit_total, int nb_max) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  const uint32_t base = blockIdx.x * RS_TILE;
+  if (base >= n) return;
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = h[threadIdx.x];
+  hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = c;
+  if (c) atomicAdd(&digit_total[threadIdx.x], c);
+}
+
+// ---- pass kernel 2: one workgroup per digit scans its row of the histogram --------------------
+__global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                         uint32_t* __restrict__ hist,
+                                                         const uint32_t* __restrict__ digit_total, int nb_max) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  const int nb = (int)((n + RS_TILE - 1) / RS_TILE);
+  const int d = blockIdx.x;
+  __shared__ uint32_t sh[256];
+  __shared__ uint32_t carry;
+  // base = number of items with a smaller digit
+  sh[threadIdx.x] = (threadIdx.x < (unsigned)d) ? digit_total[threadIdx.x] : 0u;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < (unsigned)s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) carry = sh[0];
+  __syncthreads();
+  uint32_t* row = hist + (size_t)d * nb_max;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    const uint32_t v = (b < nb) ? row[b] : 0u;
+    // inclusive Hillis-Steele scan in LDS
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+      const uint32_t add = (threadIdx.x >= (unsigned)s) ? sh[threadIdx.x - s] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint32_t incl = sh[threadIdx.x];
+    const uint32_t c0 = carry;
+    if (b < nb) row[b] = c0 + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = c0 + incl;
+    __syncthreads();
+  }
+}
+
+// ---- pass kernel 3: stable scatter -------------------------------------------------------------
+// Each wave owns a contiguous 512-item segment and ranks it 64 items at a time with ballots:
+// lanes holding the same digit find each other through 8 bit-plane ballots; the rank inside the
+// round is the number of lower lanes in the peer set, the rank across rounds comes from a
+// per-wave running counter in LDS.
+template <bool IOTA>
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
+    const uint32_t* __restrict__ hist, int nb_max) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  const uint32_t base = blockIdx.x * RS_TILE;
+  if (base >= n) return;
+  __shared__ uint32_t wcount[RS_WAVES][256];
+  __shared__ uint32_t wbase[RS_WAVES][256];
+  const int wave = threadIdx.x >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  for (int w = 0; w < RS_WAVES; ++w) wcount[w][threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t k[RS_ITEMS], v[RS_ITEMS], rk[RS_ITEMS];
+  const unsigned long long lt = lanemask_lt();
+  volatile uint32_t* cnt = wcount[wave];
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
+    const bool valid = idx < n;
+    k[i] = valid ? keys_in[idx] : 0xffffffffu;
+    v[i] = valid ? (IOTA ? idx : vals_in[idx]) : 0u;
+    const uint32_t dg = (k[i] >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool set = (dg >> bit) & 1u;
+      const unsigned long long bal = __ballot(set);
+      peers &= set ? bal : ~bal;
+    }
+    const uint32_t in_round = (uint32_t)__popcll(peers & lt);
+    const uint32_t total = (uint32_t)__popcll(peers);
+    uint32_t old = 0;
+    if (valid) {
+      old = cnt[dg];                         // every peer reads before the leader's update (in-order LDS)
+      if (in_round == 0) cnt[dg] = old + total;
+    }
+    rk[i] = old + in_round;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    uint32_t run = hist[(size_t)d * nb_max + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) {
+      wbase[w][d] = run;
+      run += wcount[w][d];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
+    if (idx < n) {
+      const uint32_t dg = (k[i] >> shift) & mask;
+      const uint32_t dst = wbase[wave][dg] + rk[i];
+      keys_out[dst] = k[i];
+      vals_out[dst] = v[i];
+    }
+  }
+}
+
+int radix_passes(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
+
+int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
+                     bool vals_are_iota, int* out_idx) {
+  int cur = 0;
+  const int nb = (int)((n_cap + RS_TILE - 1) / RS_TILE);
+  if (nb > t.nb_max) { set_error("radix_sort_pairs: nb %d > nb_max %d", nb, t.nb_max); return TRASE_ERR_WORKSPACE; }
+  const int passes = radix_passes(bit_lo, bit_hi);
+  if (passes > 8) return TRASE_ERR_INVALID;
+  TRASE_CHECK(hipMemsetAsync(t.digit_total, 0, sizeof(uint32_t) * 256 * 8, c.stream));
+  for (int p = 0; p < passes; ++p) {
+    const int shift = bit_lo + 8 * p;
+    const int nbits = (bit_hi - shift) < 8 ? (bit_hi - shift) : 8;
+    const uint32_t mask = (1u << nbits) - 1u;
+    uint32_t* dt = t.digit_total + 256 * p;
+    uint32_t* vout = t.vals[cur ^ 1];
+    {
+      ProfScope ps("radix_hist", c.stream);
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], n_ptr, n_cap, shift,
+                         mask, t.hist, dt, t.nb_max);
+    }
+    TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
+    {
+      ProfScope ps("radix_scan", c.stream);
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
+    }
+    TRASE_POST_LAUNCH("radix_scan", c.stream, c.debug);
+    {
+      ProfScope ps("radix_scatter", c.stream);
+      if (vals_are_iota && p == 0)
+        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
+                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, t.nb_max);
+      else
+        hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
+                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, t.nb_max);
+    }
+    TRASE_POST_LAUNCH("radix_scatter", c.stream, c.debug);
+    cur ^= 1;
+  }
+  *out_idx = cur;
+  return TRASE_OK;
+}
+
+// ---- inclusive scan of tiles touched, taken in depth-rank order --------------------------------
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 4;
+constexpr int SC_TILE = SC_THREADS * SC_ITEMS;
+
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* sh /*[SC_THREADS]*/) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 1; s < SC_THREADS; s <<= 1) {
+    const uint32_t add = (threadIdx.x >= (unsigned)s) ? sh[threadIdx.x - s] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  return sh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t* __restrict__ tiles,
+                                                                  const uint32_t* __restrict__ ids, int P,
+                                                                  uint32_t* __restrict__ offsets,
+                                                                  uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t sh[SC_THREADS];
+  const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  uint32_t v[SC_ITEMS];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    const int r = base + i;
+    v[i] = (r < P) ? tiles[ids[r]] : 0u;
+    sum += v[i];
+    v[i] = sum;
+  }
+  const uint32_t incl = block_incl_scan(sum, sh);
+  const uint32_t excl = incl - sum;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    const int r = base + i;
+    if (r < P) offsets[r] = excl + v[i];
+  }
+  if (threadIdx.x == SC_THREADS - 1) block_sums[blockIdx.x] = incl;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks,
+                                                               uint32_t* __restrict__ hdr, uint32_t cap) {
+  __shared__ uint32_t sh[SC_THREADS];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nblocks; b0 += SC_THREADS) {
+    const int b = b0 + threadIdx.x;
+    const uint32_t v = (b < nblocks) ? block_sums[b] : 0u;
+    const uint32_t incl = block_incl_scan(v, sh);
+    const uint32_t c0 = carry;
+    if (b < nblocks) block_sums[b] = c0 + incl - v;   // exclusive prefix of each block
+    __syncthreads();
+    if (threadIdx.x == SC_THREADS - 1) carry = c0 + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t R = carry;
+    hdr[HDR_R] = R;
+    hdr[HDR_R_EFF] = R;
+    hdr[HDR_OVERFLOW] = (R > cap) ? 1u : 0u;
+  }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __restrict__ offsets, int P,
+                                                                const uint32_t* __restrict__ block_sums) {
+  const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    const int r = base + i;
+    if (r < P) offsets[r] += add;
+  }
+}
+
+int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap) {
+  const int nblocks = (P + SC_TILE - 1) / SC_TILE;
+  {
+    ProfScope ps("scan_tiles", c.stream);
+    hipLaunchKernelGGL(scan_partial_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, sorted_ids, P,
+                       t.offsets, t.block_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums);
+  }
+  TRASE_POST_LAUNCH("scan_tiles", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- emit (tile, id) pairs in depth-rank order --------------------------------------------------
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ sorted_ids, int P,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const float2* __restrict__ xy, const int32_t* __restrict__ radii,
+                                                         const uint32_t* __restrict__ tiles, int gx, int gy,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                         uint32_t cap, uint32_t* __restrict__ hdr) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0 && hdr[HDR_R] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
+  if (r >= P) return;
+  const uint32_t id = sorted_ids[r];
+  const uint32_t nt = tiles[id];
+  if (nt == 0) return;
+  uint32_t off = offsets[r] - nt;
+  const float2 p = xy[id];
+  int x0, y0, x1, y1;
+  tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      if (off < cap) {
+        keys[off] = (uint32_t)(y * gx + x);
+        vals[off] = id;
+      }
+      ++off;
+    }
+}
+
+int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* vals, uint32_t cap) {
+  const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+  {
+    ProfScope ps("emit_pairs", c.stream);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
+                       radii, g.tiles, gx, gy, keys, vals, cap, g.hdr);
+  }
+  TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- tile ranges ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                          uint2* __restrict__ ranges) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t t = keys[i];
+    if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
+    if (i == n - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
+  }
+}
+
+int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T) {
+  TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
+  int blocks = (int)((cap + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  {
+    ProfScope ps("tile_ranges", c.stream);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges);
+  }
+  TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+}  // namespace trase

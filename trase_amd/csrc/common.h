@@ -1,0 +1,166 @@
+// common.h -- shared device helpers and host-side launch plumbing (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/trase_rast.h"
+#include "gs_math.h"
+
+namespace trase {
+
+// ----------------------------------------------------------------------------------------------
+// wave64 primitives
+// ----------------------------------------------------------------------------------------------
+constexpr int WAVE = 64;
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v) {
+  // lanes with no source (or rows masked off) receive 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
+// GFX9 DPP: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += dpp_f<0x111>(v);
+  v += dpp_f<0x112>(v);
+  v += dpp_f<0x114>(v);
+  v += dpp_f<0x118>(v);
+  v += dpp_f<0x142, 0xa>(v);
+  v += dpp_f<0x143, 0xc>(v);
+  return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) { return readlane_f(wave_sum_lane63(v), 63); }
+
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  const unsigned l = lane_id();
+  return (l == 0) ? 0ull : (~0ull >> (64 - l));
+}
+
+// float atomic add that must lower to global_atomic_add_f32 (no CAS loop)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ----------------------------------------------------------------------------------------------
+// host-side plumbing
+// ----------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// profiling scopes: when enabled, brackets a launch with two events on `stream`
+struct ProfScope {
+  ProfScope(const char* name, hipStream_t stream);
+  ~ProfScope();
+  const char* name; hipStream_t stream; void* rec;
+};
+bool prof_on();
+
+#define TRASE_CHECK(expr)                                  \
+  do {                                                     \
+    int _rc = ::trase::check_hip((expr), #expr);           \
+    if (_rc != 0) return _rc;                              \
+  } while (0)
+
+// after a kernel launch: always catch launch errors; in debug mode also synchronise
+#define TRASE_POST_LAUNCH(name, stream, debug)                                          \
+  do {                                                                                  \
+    int _rc = ::trase::check_hip(hipGetLastError(), name);                              \
+    if (_rc != 0) return _rc;                                                           \
+    if (debug) {                                                                        \
+      _rc = ::trase::check_hip(hipStreamSynchronize(stream), name " (debug sync)");     \
+      if (_rc != 0) return _rc;                                                         \
+    }                                                                                   \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ----------------------------------------------------------------------------------------------
+// workspace carving (must match trase_rast_sizes)
+// ----------------------------------------------------------------------------------------------
+enum { HDR_R = 0, HDR_OVERFLOW = 1, HDR_R_EFF = 2, HDR_WORDS = 64 };
+
+struct GeomBuf {           // saved between forward and backward
+  uint32_t* hdr;           // HDR_WORDS counters
+  float2* xy;              // (P) pixel centre
+  float4* conic_o;         // (P) conic a,b,c + opacity
+  float4* rgbd;            // (P) colour + view depth
+  uint32_t* tiles;         // (P) tiles touched (0 == culled)
+  uint32_t* clamped;       // (P) colour clamp bits
+};
+struct BinBuf {            // saved between forward and backward
+  uint32_t* point_list;    // (capacity) Gaussian ids, tile-major, depth-ordered
+  uint2* ranges;           // (T) [start,end) per tile
+};
+struct ImgBuf {            // saved between forward and backward
+  float* final_T;          // (H*W)
+  uint32_t* n_contrib;     // (H*W)
+};
+struct SortBufs {          // ping-pong storage of one radix sort
+  uint32_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;          // (256 * nb_max)
+  uint32_t* digit_total;   // (256 * 8) one row per radix pass
+  int nb_max;
+};
+struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
+  SortBufs sort;           // depth sort; sorted ids end in sort.vals[0]
+  uint32_t* offsets;       // (P) inclusive scan of tiles in depth-rank order
+  uint32_t* block_sums;    // scan partials
+};
+struct PairBuf {           // stage-2 scratch (capacity-sized)
+  SortBufs sort;           // vals[] = {spare, point_list} arranged by the caller
+  uint32_t* spare_vals;
+};
+struct BwdTmp {            // backward scratch: per-Gaussian accumulators filled by atomics
+  float* acc;              // (P, BWD_ACC) : d_ndc(2) d_conic(3) d_opacity(1) d_rgb(3) d_depth(1) pad
+};
+constexpr int BWD_ACC = 12;
+enum { ACC_NDCX = 0, ACC_NDCY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8, ACC_D = 9 };
+
+size_t geom_bytes(int P);
+size_t bin_bytes(int64_t cap, int T);
+size_t img_bytes(int W, int H);
+size_t pre_bytes(int P);
+size_t tmp_bytes(int64_t cap);
+size_t bwd_tmp_bytes(int P);
+GeomBuf carve_geom(void* p, int P);
+BinBuf carve_bin(void* p, int64_t cap, int T);
+ImgBuf carve_img(void* p, int W, int H);
+PreBuf carve_pre(void* p, int P);
+PairBuf carve_tmp(void* p, int64_t cap);
+
+// ----------------------------------------------------------------------------------------------
+// kernel launchers (one per .hip file)
+// ----------------------------------------------------------------------------------------------
+struct LaunchCtx { hipStream_t stream; int debug; int variant; };
+
+int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
+                          const GeomBuf& g, uint32_t* depth_keys);
+int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
+                          const GeomBuf& g, const float* acc, const TraseRastGrads& gr);
+
+// stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
+// from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
+int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
+                     bool vals_are_iota, int* out_idx);
+int radix_passes(int bit_lo, int bit_hi);
+
+int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap);
+int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* vals, uint32_t cap);
+int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
+
+int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
+                      const GeomBuf& g, const BinBuf& b, const ImgBuf& im);
+int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                      const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
+
+}  // namespace trase

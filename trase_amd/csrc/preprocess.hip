@@ -1,0 +1,198 @@
+// preprocess.hip -- per-Gaussian forward (projection, EWA covariance, conic, SH colour, tile
+// count, depth key) and its backward.  One thread per Gaussian; the arithmetic lives in
+// gs_math.h.  Replaces the lineage's preprocessCUDA / computeCov2DCUDA+preprocessCUDA backward
+// (SURVEY.md 2.2); call-site contract gaussian_renderer/__init__.py:137-146.
+#include "common.h"
+
+namespace trase {
+
+__device__ __forceinline__ void load_view(const float* __restrict__ vm, const float* __restrict__ pm,
+                                          const float* __restrict__ cam, View& v) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v.V[i] = vm[i]; v.PM[i] = pm[i]; }
+  v.cam[0] = cam[0]; v.cam[1] = cam[1]; v.cam[2] = cam[2];
+}
+
+struct PreArgs {
+  const float* means3D; const float* shs; const float* colors; const float* opac; const float* scales;
+  const float* rots; const float* cov3d; const float* vm; const float* pm; const float* cam;
+  int P, M, deg, W, H;
+  float tanx, tany, mod;
+};
+
+__device__ __forceinline__ void fill_view(const PreArgs& a, View& v) {
+  load_view(a.vm, a.pm, a.cam, v);
+  v.tanx = a.tanx; v.tany = a.tany;
+  v.fx = (float)a.W / (2.0f * a.tanx); v.fy = (float)a.H / (2.0f * a.tany);
+  v.mod = a.mod; v.W = a.W; v.H = a.H;
+  v.gx = (a.W + TILE - 1) / TILE; v.gy = (a.H + TILE - 1) / TILE;
+  v.deg = a.deg;
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t* __restrict__ radii,
+                                                             float2* __restrict__ xy, float4* __restrict__ conic_o,
+                                                             float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
+                                                             uint32_t* __restrict__ clamped,
+                                                             uint32_t* __restrict__ depth_keys,
+                                                             uint32_t* __restrict__ hdr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;   // device-resident copy of P for the depth sort
+  if (i >= a.P) return;
+  View v;
+  fill_view(a, v);
+  const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
+  float sc[3], q[4], cv[6];
+  const float* cov_in = nullptr;
+  if (a.cov3d) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cv[k] = a.cov3d[6 * i + k];
+    cov_in = cv;
+  } else {
+    sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+    const float4 qq = reinterpret_cast<const float4*>(a.rots)[i];
+    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+  }
+  float shl[48];
+  const float* sh = nullptr;
+  float col[3];
+  const float* color = nullptr;
+  if (a.shs) {
+    const int n = ncoef(a.deg);
+    const float* src = a.shs + (size_t)i * a.M * 3;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * n) ? src[k] : 0.f;
+    sh = shl;
+  } else {
+    col[0] = a.colors[3 * i]; col[1] = a.colors[3 * i + 1]; col[2] = a.colors[3 * i + 2];
+    color = col;
+  }
+  Splat o;
+  const bool vis = splat_forward(v, p, sc, q, cov_in, sh, color, o);
+  radii[i] = vis ? o.radius : 0;
+  tiles[i] = vis ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
+  depth_keys[i] = vis ? __float_as_uint(o.depth) : 0xffffffffu;
+  if (vis) {
+    xy[i] = make_float2(o.px, o.py);
+    conic_o[i] = make_float4(o.ca, o.cb, o.cc, a.opac[i]);
+    rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    clamped[i] = o.clamped;
+  }
+}
+
+int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
+                          const GeomBuf& g, uint32_t* depth_keys) {
+  PreArgs a;
+  a.means3D = in.means3D; a.shs = in.shs; a.colors = in.colors_precomp; a.opac = in.opacities;
+  a.scales = in.scales; a.rots = in.rotations; a.cov3d = in.cov3D_precomp;
+  a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
+  a.P = in.P; a.M = in.M; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
+  a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  {
+    ProfScope ps("preprocess_fwd", c.stream);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((in.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.xy,
+                       g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr);
+  }
+  TRASE_POST_LAUNCH("preprocess_fwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+struct PreBwdOut {
+  float* d_means3D; float* d_means2D; float* d_shs; float* d_colors; float* d_opac; float* d_scales;
+  float* d_rots; float* d_cov3d;
+};
+
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreArgs a, const int32_t* __restrict__ radii,
+                                                             const uint32_t* __restrict__ clamped,
+                                                             const float* __restrict__ acc, PreBwdOut o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.P) return;
+  const bool vis = radii[i] > 0;
+  SplatGradOut go;
+  float dsh[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+  SplatGradIn gi;
+  gi.d_ndcx = gi.d_ndcy = gi.d_ca = gi.d_cb = gi.d_cc = gi.d_depth = 0.f;
+  gi.d_rgb[0] = gi.d_rgb[1] = gi.d_rgb[2] = 0.f;
+  float d_op = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { go.d_p[k] = 0.f; go.d_scale[k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) go.d_quat[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) go.d_cov[k] = 0.f;
+  if (vis) {
+    const float* r = acc + (size_t)i * BWD_ACC;
+    gi.d_ndcx = r[ACC_NDCX]; gi.d_ndcy = r[ACC_NDCY];
+    gi.d_ca = r[ACC_CA]; gi.d_cb = r[ACC_CB]; gi.d_cc = r[ACC_CC];
+    d_op = r[ACC_OP];
+    gi.d_rgb[0] = r[ACC_R]; gi.d_rgb[1] = r[ACC_G]; gi.d_rgb[2] = r[ACC_B];
+    gi.d_depth = r[ACC_D];
+    View v;
+    fill_view(a, v);
+    const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
+    float sc[3], q[4], cv[6];
+    const float* cov_in = nullptr;
+    if (a.cov3d) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cv[k] = a.cov3d[6 * i + k];
+      cov_in = cv;
+    } else {
+      sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
+      const float4 qq = reinterpret_cast<const float4*>(a.rots)[i];
+      q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+    }
+    float shl[48];
+    const float* sh = nullptr;
+    if (a.shs) {
+      const int n = ncoef(a.deg);
+      const float* src = a.shs + (size_t)i * a.M * 3;
+#pragma unroll
+      for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * n) ? src[k] : 0.f;
+      sh = shl;
+    }
+    splat_backward(v, p, sc, q, cov_in, sh, a.shs ? clamped[i] : 0u, gi, go, a.shs ? dsh : nullptr);
+  }
+  if (o.d_means3D) { o.d_means3D[3 * i] = go.d_p[0]; o.d_means3D[3 * i + 1] = go.d_p[1]; o.d_means3D[3 * i + 2] = go.d_p[2]; }
+  if (o.d_means2D) { o.d_means2D[3 * i] = gi.d_ndcx; o.d_means2D[3 * i + 1] = gi.d_ndcy; o.d_means2D[3 * i + 2] = 0.f; }
+  if (o.d_opac) o.d_opac[i] = d_op;
+  if (o.d_scales) { o.d_scales[3 * i] = go.d_scale[0]; o.d_scales[3 * i + 1] = go.d_scale[1]; o.d_scales[3 * i + 2] = go.d_scale[2]; }
+  if (o.d_rots) reinterpret_cast<float4*>(o.d_rots)[i] = make_float4(go.d_quat[0], go.d_quat[1], go.d_quat[2], go.d_quat[3]);
+  if (o.d_cov3d) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.d_cov3d[6 * i + k] = go.d_cov[k];
+  }
+  if (o.d_colors) { o.d_colors[3 * i] = gi.d_rgb[0]; o.d_colors[3 * i + 1] = gi.d_rgb[1]; o.d_colors[3 * i + 2] = gi.d_rgb[2]; }
+  if (o.d_shs) {
+    float* dst = o.d_shs + (size_t)i * a.M * 3;
+    const int m3 = a.M * 3;
+#pragma unroll
+    for (int k = 0; k < 48; ++k)
+      if (k < m3) dst[k] = dsh[k];
+  }
+}
+
+int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
+                          const GeomBuf& g, const float* acc, const TraseRastGrads& gr) {
+  PreArgs a;
+  a.means3D = in.means3D; a.shs = in.shs; a.colors = in.colors_precomp; a.opac = in.opacities;
+  a.scales = in.scales; a.rots = in.rotations; a.cov3d = in.cov3D_precomp;
+  a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
+  a.P = in.P; a.M = in.M; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
+  a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  PreBwdOut o;
+  o.d_means3D = gr.dL_dmeans3D; o.d_means2D = gr.dL_dmeans2D; o.d_shs = in.shs ? gr.dL_dshs : nullptr;
+  o.d_colors = in.colors_precomp ? gr.dL_dcolors : nullptr; o.d_opac = gr.dL_dopacities;
+  o.d_scales = in.cov3D_precomp ? nullptr : gr.dL_dscales; o.d_rots = in.cov3D_precomp ? nullptr : gr.dL_drotations;
+  o.d_cov3d = in.cov3D_precomp ? gr.dL_dcov3D : nullptr;
+  {
+    ProfScope ps("preprocess_bwd", c.stream);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((in.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped,
+                       acc, o);
+  }
+  TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+}  // namespace trase

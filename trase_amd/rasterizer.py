@@ -1,0 +1,325 @@
+"""Host-side mirror of the reference's operator interface for the rasterizer path.
+
+Same names, argument meaning, return order and error behaviour as the
+``diff_gaussian_rasterization`` extension the reference imports at
+gaussian_renderer/__init__.py:21 and calls at :58-73 / :137-146 (also
+gui_standalone.py:59,390-478): ``GaussianRasterizationSettings`` (12-field
+record) and ``GaussianRasterizer(raster_settings)(means3D, means2D, shs,
+sh_objs, colors_precomp, opacities, scales, rotations, cov3D_precomp) ->
+(image, radii, feats, depth)``.
+
+All compute goes through the C-ABI HIP library (include/trase_rast.h); PyTorch
+only provides device memory, the current stream and the autograd hook.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# --------------------------------------------------------------------------------------
+# capacity policy for the (tile, Gaussian) pair buffers
+# --------------------------------------------------------------------------------------
+class _Policy:
+    # sync=True : like the reference, read the pair count back after stage 1 and allocate exactly.
+    # sync=False: no host synchronisation; buffers are sized from `capacity` (grown from the last
+    #             observed count); overflow is detected by `last_status()` / at the next call.
+    sync = os.environ.get("TRASE_RAST_SYNC", "1") != "0"
+    capacity = 0
+    variant = int(os.environ.get("TRASE_RAST_VARIANT", "0"), 0)
+    last_geom: Optional[torch.Tensor] = None
+    last_capacity = 0
+
+
+def set_sync(flag: bool, capacity: int = 0):
+    """Choose the capacity policy; capacity (pairs) is only used when flag is False."""
+    _Policy.sync = bool(flag)
+    _Policy.capacity = int(capacity)
+
+
+def set_variant(v: int):
+    _Policy.variant = int(v)
+
+
+def last_status():
+    """(num_rendered, overflow, num_rendered_after_culling) of the most recent forward. Synchronises."""
+    if _Policy.last_geom is None:
+        return None
+    lib = _lib.load()
+    ws = _lib.RastWorkspace()
+    ws.geom = _lib.ptr(_Policy.last_geom)
+    ws.geom_bytes = _Policy.last_geom.numel()
+    st = (C.c_int64 * 3)()
+    _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), _stream(_Policy.last_geom.device)), "trase_rast_status")
+    return int(st[0]), int(st[1]), int(st[2])
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise ValueError(f"{name} must live on {device}, got {t.device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+
+
+def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _lib.RastSettings:
+    s = _lib.RastSettings()
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    s.scale_modifier = float(rs.scale_modifier)
+    s.sh_degree = int(rs.sh_degree)
+    s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    s.device = device.index if device.index is not None else torch.cuda.current_device()
+    s.variant = _Policy.variant
+    for name in ("bg", "viewmatrix", "projmatrix", "campos"):
+        t = _prep(getattr(rs, name), name, device)
+        if t is None:
+            raise ValueError(f"raster_settings.{name} is required")
+        keep.append(t)
+        setattr(s, name, t.data_ptr())
+    return s
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        lib = _lib.load()
+        device = means3D.device
+        if device.type != "cuda":
+            raise RuntimeError("trase_amd rasterizer runs on the GPU only (there is no CPU path); "
+                               f"means3D is on {device}")
+        means3D = _prep(means3D, "means3D", device)
+        P = means3D.shape[0] if means3D is not None else 0
+        if means3D is None:
+            means3D = torch.empty(0, 3, device=device)
+        sh = _prep(sh, "shs", device)
+        sh_objs = _prep(sh_objs, "sh_objs", device)
+        colors_precomp = _prep(colors_precomp, "colors_precomp", device)
+        opacities = _prep(opacities, "opacities", device)
+        scales = _prep(scales, "scales", device)
+        rotations = _prep(rotations, "rotations", device)
+        cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp", device)
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        M = sh.shape[1] if sh is not None else 0
+        F = sh_objs.shape[-1] if sh_objs is not None else 0
+
+        keep: list = []
+        s = _fill_settings(raster_settings, device, keep)
+        inp = _lib.RastInputs()
+        inp.P, inp.M, inp.F = P, M, F
+        inp.means3D = _lib.ptr(means3D)
+        inp.shs, inp.sh_objs, inp.colors_precomp = _lib.ptr(sh), _lib.ptr(sh_objs), _lib.ptr(colors_precomp)
+        inp.opacities, inp.scales, inp.rotations = _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations)
+        inp.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
+
+        image = torch.empty(3, H, W, device=device)
+        feats = torch.empty(F, H, W, device=device)
+        depth = torch.empty(1, H, W, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        out = _lib.RastOutputs()
+        out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
+        out.feats = _lib.ptr(feats) if F > 0 else None
+
+        sizes = _lib.RastSizes()
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, 1, C.byref(sizes)), "trase_rast_sizes")
+        geom = _bytes(sizes.geom_bytes, device)
+        pre = _bytes(sizes.pre_bytes, device)
+        img = _bytes(sizes.img_bytes, device)
+        ws = _lib.RastWorkspace()
+        ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
+        ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
+        ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
+        stream = _stream(device)
+
+        _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
+                   "trase_rast_preprocess")
+        if _Policy.sync:
+            st = (C.c_int64 * 3)()
+            _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
+            capacity = max(int(st[0]), 1)
+        else:
+            capacity = max(int(_Policy.capacity), 1)
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
+        binb = _bytes(sizes.bin_bytes, device)
+        tmp = _bytes(sizes.tmp_bytes, device)
+        ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
+        ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
+        ws.capacity = capacity
+        _lib.check(lib.trase_rast_render(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
+                   "trase_rast_render")
+        _Policy.last_geom, _Policy.last_capacity = geom, capacity
+
+        ctx.raster_settings = raster_settings
+        ctx.capacity = capacity
+        ctx.dims = (P, M, F, H, W)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        ctx.save_for_backward(means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
+                              cov3Ds_precomp, radii, geom, binb, img)
+        return image, radii, feats, depth
+
+    @staticmethod
+    def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
+        lib = _lib.load()
+        (means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+         radii, geom, binb, img) = ctx.saved_tensors
+        P, M, F, H, W = ctx.dims
+        device = means3D.device
+        keep: list = []
+        s = _fill_settings(ctx.raster_settings, device, keep)
+        inp = _lib.RastInputs()
+        inp.P, inp.M, inp.F = P, M, F
+        inp.means3D = _lib.ptr(means3D)
+        inp.shs, inp.sh_objs, inp.colors_precomp = _lib.ptr(sh), _lib.ptr(sh_objs), _lib.ptr(colors_precomp)
+        inp.opacities, inp.scales, inp.rotations = _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations)
+        inp.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
+        out = _lib.RastOutputs()
+        out.radii = _lib.ptr(radii)
+
+        sizes = _lib.RastSizes()
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")
+        tmp = _bytes(sizes.bwd_tmp_bytes, device)
+        ws = _lib.RastWorkspace()
+        ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
+        ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
+        ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
+        ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
+        ws.capacity = ctx.capacity
+
+        grad_image = _prep(grad_image, "grad_image", device)
+        grad_feats = _prep(grad_feats, "grad_feats", device) if F > 0 else None
+        grad_depth = _prep(grad_depth, "grad_depth", device)
+        need = ctx.needs_input_grad   # order of forward()'s arguments
+
+        def alloc(flag, present, *shape):
+            return torch.empty(*shape, device=device) if (flag and present) else None
+
+        # means3D / means2D gradients are always produced: the reference reads
+        # viewspace_points.grad for densification (scene/gaussian_model.py:637-639)
+        d_means3D = torch.empty(P, 3, device=device)
+        d_means2D = torch.empty(P, 3, device=device)
+        d_sh = alloc(need[2], sh is not None, P, M, 3)
+        d_sh_objs = alloc(need[3], sh_objs is not None, *(sh_objs.shape if sh_objs is not None else (0,)))
+        d_colors = alloc(need[4], colors_precomp is not None, P, 3)
+        d_opac = alloc(need[5], True, *opacities.shape)
+        d_scales = alloc(need[6], scales is not None, P, 3)
+        d_rot = alloc(need[7], rotations is not None, P, 4)
+        d_cov = alloc(need[8], cov3Ds_precomp is not None, P, 6)
+
+        g = _lib.RastGrads()
+        g.dL_dimage, g.dL_dfeats, g.dL_ddepth = _lib.ptr(grad_image), _lib.ptr(grad_feats), _lib.ptr(grad_depth)
+        g.dL_dmeans3D, g.dL_dmeans2D = _lib.ptr(d_means3D), _lib.ptr(d_means2D)
+        g.dL_dshs, g.dL_dsh_objs, g.dL_dcolors = _lib.ptr(d_sh), _lib.ptr(d_sh_objs), _lib.ptr(d_colors)
+        g.dL_dopacities, g.dL_dscales, g.dL_drotations = _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rot)
+        g.dL_dcov3D = _lib.ptr(d_cov)
+        _lib.check(lib.trase_rast_backward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(g),
+                                           _stream(device)), "trase_rast_backward")
+        if d_sh_objs is not None and grad_feats is None:
+            d_sh_objs.zero_()      # feature map unused by the loss: exact zeros, not uninitialised memory
+        return (d_means3D if need[0] else None, d_means2D if need[1] else None, d_sh, d_sh_objs, d_colors,
+                d_opac, d_scales, d_rot, d_cov, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test of the lineage API (unused by TRASE): view-space z > 0.2."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix
+            z = positions @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, sh_objs=None, colors_precomp=None,
+                scales=None, rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+           ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, sh_objs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, rs)
+
+
+# --------------------------------------------------------------------------------------
+# simple_knn._C.distCUDA2 (scene/gaussian_model.py:237)
+# --------------------------------------------------------------------------------------
+def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    if points.device.type != "cuda":
+        raise RuntimeError("distCUDA2 runs on the GPU only (there is no CPU path)")
+    pts = points.detach().float().contiguous()
+    n = pts.shape[0]
+    out = torch.empty(n, device=pts.device)
+    nbytes = C.c_size_t()
+    _lib.check(lib.trase_knn_sizes(n, C.byref(nbytes)), "trase_knn_sizes")
+    ws = _bytes(nbytes.value, pts.device)
+    dev = pts.device.index if pts.device.index is not None else torch.cuda.current_device()
+    _lib.check(lib.trase_knn_dist2(_lib.ptr(pts), n, _lib.ptr(out), _lib.ptr(ws), ws.numel(), dev,
+                                   _stream(pts.device)), "trase_knn_dist2")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg
+# --------------------------------------------------------------------------------------
+def profile_enable(flag: bool):
+    _lib.check(_lib.load().trase_prof_enable(1 if flag else 0), "trase_prof_enable")
+
+
+def profile_report() -> dict:
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(_lib.load().trase_prof_report(buf, len(buf)), "trase_prof_report")
+    return json.loads(buf.value.decode())
+
+
+def selftest(device=None) -> str:
+    dev = torch.cuda.current_device() if device is None else device
+    buf = C.create_string_buffer(4096)
+    rc = _lib.load().trase_selftest(dev, _stream(torch.device("cuda", dev)), buf, len(buf))
+    msg = buf.value.decode()
+    if rc != 0:
+        raise RuntimeError(f"trase_selftest failed ({rc}):\n{msg}\n{_lib.last_error()}")
+    return msg

@@ -1,0 +1,144 @@
+"""Seeded synthetic scenes + cameras shaped like the reference's inputs.
+
+No datasets exist on the GPU box, so bench/tests render synthetic Gaussians with
+the value distributions SURVEY.md 8(d) prescribes.  The camera record carries
+exactly the fields ``gaussian_renderer.render()`` reads from a reference
+``Camera`` (scene/cameras.py:70-79): transposed (row-vector) matrices,
+``FoVx/FoVy``, ``image_width/height``, ``camera_center``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+SH_C0 = 0.28209479177387814
+
+
+def rgb2sh(rgb):
+    """utils/sh_utils.py:114-115"""
+    return (rgb - 0.5) / SH_C0
+
+
+def world2view(Rc2w: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """Restates getWorld2View2 with zero translate / unit scale
+    (utils/graphics_utils.py:45-57): R is stored camera-to-world, t world-to-camera."""
+    Rt = torch.zeros(4, 4, dtype=torch.float64)
+    Rt[:3, :3] = Rc2w.T
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    return Rt.to(torch.float32)
+
+
+def projection_matrix(znear, zfar, fovx, fovy) -> torch.Tensor:
+    """Restates getProjectionMatrix (utils/graphics_utils.py:59-77)."""
+    ty, tx = math.tan(fovy / 2), math.tan(fovx / 2)
+    top, right = ty * znear, tx * znear
+    bottom, left = -top, -right
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+@dataclass
+class SynthCamera:
+    image_width: int
+    image_height: int
+    FoVx: float
+    FoVy: float
+    world_view_transform: torch.Tensor   # (4,4) transposed
+    projection_matrix: torch.Tensor      # (4,4) transposed
+    full_proj_transform: torch.Tensor    # (4,4)
+    camera_center: torch.Tensor          # (3,)
+    fid: torch.Tensor                    # (1,) time in [0,1]
+    znear: float = 0.01
+    zfar: float = 100.0
+
+    def to(self, device):
+        return SynthCamera(self.image_width, self.image_height, self.FoVx, self.FoVy,
+                           self.world_view_transform.to(device), self.projection_matrix.to(device),
+                           self.full_proj_transform.to(device), self.camera_center.to(device),
+                           self.fid.to(device), self.znear, self.zfar)
+
+
+def orbit_camera(width: int, height: int, angle: float = 0.0, radius: float = 4.0,
+                 elevation: float = 0.15, focal_mult: float = 1.2, fid: float = 0.0) -> SynthCamera:
+    """Camera on an orbit looking at the origin; focal = focal_mult * W."""
+    focal = focal_mult * width
+    fovx = 2 * math.atan(width / (2 * focal))
+    fovy = 2 * math.atan(height / (2 * focal))
+    eye = torch.tensor([radius * math.cos(elevation) * math.sin(angle),
+                        radius * math.sin(elevation),
+                        radius * math.cos(elevation) * math.cos(angle)], dtype=torch.float64)
+    fwd = -eye / eye.norm()                      # camera +z looks at the origin
+    up = torch.tensor([0.0, -1.0, 0.0], dtype=torch.float64)   # image y points down
+    right = torch.linalg.cross(up, fwd)
+    right = right / right.norm()
+    down = torch.linalg.cross(fwd, right)
+    Rc2w = torch.stack([right, down, fwd], dim=1)          # columns = camera axes in world
+    t = -(Rc2w.T @ eye)
+    wvt = world2view(Rc2w, t).transpose(0, 1).contiguous()
+    proj = projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).contiguous()
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
+    center = wvt.inverse()[3, :3].contiguous()
+    return SynthCamera(width, height, fovx, fovy, wvt, proj, full, center,
+                       torch.tensor([fid], dtype=torch.float32))
+
+
+@dataclass
+class SynthScene:
+    """Raw (pre-activation) parameters laid out like scene/gaussian_model.py:56-63."""
+    xyz: torch.Tensor            # (N,3)
+    features_dc: torch.Tensor    # (N,1,3)
+    features_rest: torch.Tensor  # (N,15,3)
+    scaling: torch.Tensor        # (N,3) log-scale
+    rotation: torch.Tensor       # (N,4) raw quaternion
+    opacity: torch.Tensor        # (N,1) logit
+    gaussian_features: torch.Tensor  # (N,1,F)
+
+    def to(self, device):
+        return SynthScene(*[getattr(self, k).to(device) for k in
+                            ("xyz", "features_dc", "features_rest", "scaling", "rotation",
+                             "opacity", "gaussian_features")])
+
+    # activations exactly as scene/gaussian_model.py:43-51,183-205
+    def activated(self, norm_features: bool = True):
+        scales = torch.exp(self.scaling)
+        rot = torch.nn.functional.normalize(self.rotation)
+        opac = torch.sigmoid(self.opacity)
+        shs = torch.cat((self.features_dc, self.features_rest), dim=1)
+        f = self.gaussian_features
+        if norm_features:
+            f = f / (f.norm(dim=2, keepdim=True) + 1e-9)   # gaussian_renderer/__init__.py:120-121
+        return dict(means3D=self.xyz, scales=scales, rotations=rot, opacities=opac, shs=shs, sh_objs=f)
+
+
+def make_scene(n: int, feat_dim: int = 32, seed: int = 0, extent: float = 1.3,
+               scale_mult: float = 0.3, opacity_mode: str = "trained") -> SynthScene:
+    """xyz ~ U(-extent, extent)^3 (scene/dataset_readers.py:409), scales from the mean
+    point spacing (stand-in for log(sqrt(distCUDA2)), scene/gaussian_model.py:237-238)
+    jittered by +-0.5 in log space, normalised N(0,1) quaternions, opacity logits
+    N(0,2) ('trained') or inverse_sigmoid(0.1) ('init'), SH dc = RGB2SH(U(0,1)),
+    rest ~ N(0,0.05), features = RGB2SH(U(0,1)) (scene/gaussian_model.py:232)."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * extent
+    spacing = ((2 * extent) ** 3 / max(n, 1)) ** (1.0 / 3.0)
+    base = math.log(scale_mult * spacing)
+    scaling = base + (torch.rand(n, 3, generator=g) - 0.5)
+    rotation = torch.randn(n, 4, generator=g)
+    if opacity_mode == "trained":
+        opacity = torch.randn(n, 1, generator=g) * 2.0
+    else:
+        opacity = torch.full((n, 1), math.log(0.1 / 0.9))
+    dc = rgb2sh(torch.rand(n, 1, 3, generator=g))
+    rest = torch.randn(n, 15, 3, generator=g) * 0.05
+    feats = rgb2sh(torch.rand(n, 1, feat_dim, generator=g))
+    return SynthScene(xyz.float(), dc.float(), rest.float(), scaling.float(), rotation.float(),
+                      opacity.float(), feats.float())
