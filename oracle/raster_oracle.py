@@ -120,6 +120,9 @@ class Geom:
     frag_gauss: torch.Tensor   # (N,) bool: a discrete preprocess decision is borderline
     cov3d: torch.Tensor        # (N,6)
     ndc: torch.Tensor          # (N,2) NDC centre; carries the means2D gradient hook
+    frag_radius: torch.Tensor = None   # (N,) bool: ceil() of the radius is borderline
+    frag_rect: torch.Tensor = None     # (N,) bool: a tile-rect edge / the near cull is borderline
+    r_real: torch.Tensor = None        # (N,) un-rounded radius
 
 
 def preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotations,
@@ -201,16 +204,20 @@ def preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotati
     finite = torch.isfinite(r_real.detach()) & torch.isfinite(pxd) & torch.isfinite(pyd)
     valid = in_front & det_ok & (area > 0) & finite
     radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
-    # fragility of the discrete decisions: distance of the real-valued quantities
-    # from the integer boundaries that ceil()/trunc() cut at
-    eps = opt.frag_rel
+    # fragility of the discrete decisions: distance of the real-valued quantities from the integer
+    # boundaries that ceil()/trunc() cut at, measured against a float32 error model
+    # (pixel centre: a few ulp of the NDC value scaled by W/2; radius: a few ulp, relative)
     rr = r_real.detach()
-    frag = (torch.abs(rr - torch.round(rr)) < eps * torch.clamp_min(rr, 1.0))
-    for v in ((pxd - radius) / TILE, (pxd + radius + (TILE - 1)) / TILE,
-              (pyd - radius) / TILE, (pyd + radius + (TILE - 1)) / TILE):
-        frag = frag | (torch.abs(v - torch.round(v)) < eps * torch.clamp_min(v.abs(), 1.0))
-    frag = frag | (torch.abs(tz.detach() - opt.near_cull_z) < eps)
-    frag = frag & in_front & finite
+    frag_radius = torch.abs(rr - torch.round(rr)) < (4e-6 * rr + 1e-6)
+    err_px = 6e-7 * max(W, H) + 1e-6
+    frag_rect = torch.zeros_like(frag_radius)
+    for v in (pxd - radius, pxd + radius + (TILE - 1), pyd - radius, pyd + radius + (TILE - 1)):
+        q = v / TILE
+        frag_rect = frag_rect | (torch.abs(q - torch.round(q)) < err_px / TILE)
+    frag_rect = frag_rect | (torch.abs(tz.detach() - opt.near_cull_z) < 1e-6)
+    frag_radius = frag_radius & in_front & finite
+    frag_rect = frag_rect & in_front & finite
+    frag = frag_radius | frag_rect
     # 7. colour
     if colors_precomp is not None:
         rgb = colors_precomp
@@ -222,7 +229,7 @@ def preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotati
     rect = torch.where(valid[:, None], rect, torch.zeros_like(rect))
     return Geom(valid=valid, radii=radii, xy=torch.stack([px, py], -1), depth=tz, conic=conic,
                 rgb=rgb, rect=rect, tiles_touched=torch.where(valid, area, torch.zeros_like(area)),
-                frag_gauss=frag, cov3d=cov3d, ndc=ndc)
+                frag_gauss=frag, cov3d=cov3d, ndc=ndc, frag_radius=frag_radius, frag_rect=frag_rect, r_real=rr)
 
 
 def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions):
@@ -263,7 +270,7 @@ def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions):
     f_stop = (torch.abs(cp.detach() - opt.t_stop) < 8 * rel * opt.t_stop) & keep
     f_clamp = torch.zeros_like(f_alpha)  # clamp at 0.99 is continuous in value; not fragile
     fragile = ((f_alpha | f_pow | f_stop | f_clamp) & live_before).any(dim=0)
-    return out, T_final, n_contrib, fragile
+    return out, T_final, n_contrib, fragile, (alive & keep)
 
 
 @dataclass
@@ -307,7 +314,7 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     feats_in = None if sh_objs is None else _f64(sh_objs).reshape(N, F)
     g = preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotations,
                    cov3D_precomp, means2D, opt)
-    if radii_override is not None and bool(g.frag_gauss.any()):
+    if radii_override is not None and bool(g.frag_radius.any()):
         g = _apply_radii_override(g, radii_override, W, H)
     bg = _f64(settings.bg).reshape(3)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
@@ -339,7 +346,7 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
             ys, xs = torch.meshgrid(torch.arange(y_lo, y_hi), torch.arange(x_lo, x_hi), indexing="ij")
             pixx = xs.reshape(-1).to(torch.float64)
             pixy = ys.reshape(-1).to(torch.float64)
-            o, Tf, nc, fr = blend_tile(g.xy[ids], g.conic[ids], opac[ids], g.depth[ids],
+            o, Tf, nc, fr, contrib = blend_tile(g.xy[ids], g.conic[ids], opac[ids], g.depth[ids],
                                        chans_all[ids], pixx, pixy, opt)
             hh, ww = y_hi - y_lo, x_hi - x_lo
             o = o.reshape(hh, ww, C)
@@ -353,12 +360,12 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
             if k.numel() > 1:
                 near = (k[1:] - k[:-1]).abs() < 4e-7 * k[1:].abs().clamp_min(1e-3)
                 if sort_depth is None and bool(near.any()):
-                    # only matters if both neighbours are seen before the pixel is done
-                    pos = torch.nonzero(near).reshape(-1) + 1      # 1-based index of the first of the pair
-                    fr = fr | (nc >= pos.min())
+                    # swapping two neighbours only changes pixels that blend both of them
+                    for j in torch.nonzero(near).reshape(-1).tolist():
+                        fr = fr | (contrib[j] & contrib[j + 1])
             fragile[y_lo:y_hi, x_lo:x_hi] = fr.reshape(hh, ww)
             # pixels touched by a fragile Gaussian inherit fragility
-            if bool(g.frag_gauss[ids].any()) and radii_override is None:
+            if bool(g.frag_gauss[ids].any()):
                 fragile[y_lo:y_hi, x_lo:x_hi] = True
     canvas = out
     if opt.feats_bg or opt.depth_normalised:
@@ -372,8 +379,13 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
 
 
 def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:
-    ro = radii_override.to(torch.float64)
-    radius = torch.where(g.frag_gauss, ro, g.radii.to(torch.float64))
+    """For Gaussians whose ceil() is borderline adopt the device's radius, provided it is one of
+    the two admissible neighbours; their fragility is then resolved."""
+    ro = radii_override.to(torch.float64).cpu()
+    own = torch.ceil(g.r_real)
+    admissible = ((ro - own).abs() <= 1.0) & (ro > 0)
+    take = g.frag_radius & admissible & g.valid
+    radius = torch.where(take, ro, g.radii.to(torch.float64))
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     pxd, pyd = g.xy[:, 0].detach(), g.xy[:, 1].detach()
     x0 = torch.trunc((pxd - radius) / TILE).clamp(0, gx).to(torch.int64)
@@ -381,11 +393,10 @@ def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:
     y0 = torch.trunc((pyd - radius) / TILE).clamp(0, gy).to(torch.int64)
     y1 = torch.trunc((pyd + radius + (TILE - 1)) / TILE).clamp(0, gy).to(torch.int64)
     area = (x1 - x0) * (y1 - y0)
-    valid = torch.where(g.frag_gauss, (ro > 0) & (area > 0), g.valid)
     rect = torch.stack([x0, y0, x1, y1], -1)
-    rect = torch.where(valid[:, None], rect, torch.zeros_like(rect))
-    g.valid = valid
+    rect = torch.where(take[:, None], rect, g.rect)
     g.rect = rect
-    g.radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
-    g.tiles_touched = torch.where(valid, area, torch.zeros_like(area))
+    g.radii = torch.where(take, radius, g.radii.to(torch.float64)).to(torch.int32)
+    g.tiles_touched = torch.where(take, area, g.tiles_touched)
+    g.frag_gauss = g.frag_rect | (g.frag_radius & ~take)
     return g

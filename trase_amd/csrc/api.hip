@@ -131,6 +131,9 @@ size_t bwd_tmp_bytes(int P) { return align_up(sizeof(float) * BWD_ACC * (size_t)
 static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
   if (!s || !in) { set_error("null settings/inputs"); return TRASE_ERR_INVALID; }
   if (in->P < 0 || s->image_width <= 0 || s->image_height <= 0) { set_error("bad sizes"); return TRASE_ERR_INVALID; }
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) { set_error("bg/viewmatrix/projmatrix/campos are required"); return TRASE_ERR_INVALID; }
+  if (in->F != 0 && in->F != 16 && in->F != 32) { set_error("feature width %d not compiled in (0,16,32)", in->F); return TRASE_ERR_UNSUPPORTED; }
+  if (in->P == 0) return TRASE_OK;   // nothing to validate: empty tensors carry null pointers
   if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
     set_error("Please provide excatly one of either SHs or precomputed colors!");   // wording of the lineage's wrapper
     return TRASE_ERR_INVALID;
@@ -146,9 +149,7 @@ static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
     set_error("shs holds %d coefficients, degree %d needs %d (max 16)", in->M, s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1));
     return TRASE_ERR_INVALID;
   }
-  if (in->F != 0 && in->F != 16 && in->F != 32) { set_error("feature width %d not compiled in (0,16,32)", in->F); return TRASE_ERR_UNSUPPORTED; }
   if (in->F > 0 && !in->sh_objs) { set_error("F>0 but sh_objs is null"); return TRASE_ERR_INVALID; }
-  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) { set_error("bg/viewmatrix/projmatrix/campos are required"); return TRASE_ERR_INVALID; }
   return TRASE_OK;
 }
 
@@ -193,7 +194,7 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
                           const TraseRastWorkspace* ws, trase_stream_t stream_) {
   int rc = validate(s, in);
   if (rc) return rc;
-  if (!out || !out->radii) { set_error("radii output required"); return TRASE_ERR_INVALID; }
+  if (!out || (in->P > 0 && !out->radii)) { set_error("radii output required"); return TRASE_ERR_INVALID; }
   rc = check_ws(in, s, ws, WS_GEOM | WS_PRE);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -231,7 +232,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
                       const TraseRastWorkspace* ws, trase_stream_t stream_) {
   int rc = validate(s, in);
   if (rc) return rc;
-  if (!out || !out->image || !out->depth || !out->radii || (in->F > 0 && !out->feats)) { set_error("null output"); return TRASE_ERR_INVALID; }
+  if (!out || !out->image || !out->depth || (in->P > 0 && !out->radii) || (in->F > 0 && !out->feats)) { set_error("null output"); return TRASE_ERR_INVALID; }
   rc = check_ws(in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG | WS_TMP);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -278,7 +279,7 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
   int rc = validate(s, in);
   if (rc) return rc;
-  if (!gr || !out || !out->radii) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
+  if (!gr || !out || (in->P > 0 && !out->radii)) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
   rc = check_ws(in, s, ws, WS_GEOM | WS_BIN | WS_IMG);
   if (rc) return rc;
   if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in->P)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }

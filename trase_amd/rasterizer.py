@@ -80,7 +80,7 @@ def _stream(device) -> C.c_void_p:
 
 
 def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
-    if t is None or t.numel() == 0:
+    if t is None:
         return None
     if t.device != device:
         raise ValueError(f"{name} must live on {device}, got {t.device}")
@@ -121,9 +121,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("trase_amd rasterizer runs on the GPU only (there is no CPU path); "
                                f"means3D is on {device}")
         means3D = _prep(means3D, "means3D", device)
-        P = means3D.shape[0] if means3D is not None else 0
-        if means3D is None:
-            means3D = torch.empty(0, 3, device=device)
+        P = means3D.shape[0]
         sh = _prep(sh, "shs", device)
         sh_objs = _prep(sh_objs, "sh_objs", device)
         colors_precomp = _prep(colors_precomp, "colors_precomp", device)
@@ -134,6 +132,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         M = sh.shape[1] if sh is not None else 0
         F = sh_objs.shape[-1] if sh_objs is not None else 0
+        if F == 0:
+            sh_objs = None
 
         keep: list = []
         s = _fill_settings(raster_settings, device, keep)
@@ -246,8 +246,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         g.dL_dcov3D = _lib.ptr(d_cov)
         _lib.check(lib.trase_rast_backward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), C.byref(g),
                                            _stream(device)), "trase_rast_backward")
-        if d_sh_objs is not None and grad_feats is None:
-            d_sh_objs.zero_()      # feature map unused by the loss: exact zeros, not uninitialised memory
+        if P == 0:
+            for t in (d_means3D, d_means2D, d_sh, d_sh_objs, d_colors, d_opac, d_scales, d_rot, d_cov):
+                if t is not None:
+                    t.zero_()
         return (d_means3D if need[0] else None, d_means2D if need[1] else None, d_sh, d_sh_objs, d_colors,
                 d_opac, d_scales, d_rot, d_cov, None)
 
