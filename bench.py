@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""views/sec (fwd+bwd) of the rasterizer path on synthetic S4 input (BASELINE.json metric):
+N = 300 000 Gaussians, 1920x1080, 32 feature channels, SH degree 3.
+
+A "step" is one pass of the hot path over one view: activations of the raw parameters
+(gaussian_renderer/__init__.py:82-121) -> GaussianRasterizer forward -> backward with fixed
+cotangents on the RGB image and the 32-channel feature map (the window the reference times at
+train.py:157-303, minus its loss heads).  For --gpus N > 1 every rank renders a different view
+(data parallel over camera views) and the step ends with one RCCL all-reduce of the flat
+Gaussian-gradient buffer.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from trase_amd import rasterizer as R  # noqa: E402
+from trase_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
+from trase_amd.synthetic import make_scene, orbit_camera  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+C_RGB = 3
+
+
+def algorithmic_bytes(kernel: str, n: int, r: int, p: int, f: int) -> float:
+    """SURVEY.md 8(d) per-kernel algorithmic bytes (general F)."""
+    if kernel == "render_bwd":
+        return (4 * (C_RGB + f) + 8) * p + (44 + 4 * f) * r + (36 + 4 * f) * n
+    if kernel == "render_fwd":
+        return (44 + 4 * f) * r + (4 * (C_RGB + f + 1) + 8) * p
+    if kernel == "preprocess_fwd":
+        return 284 * n
+    if kernel == "preprocess_bwd":
+        return 648 * n
+    return 36 * r   # binning family
+
+
+def view_bytes(n, r, p, f):
+    """A_view = (840+8F) N + (124+8F) R + (44+8F) P  (= 1096 N + 380 R + 300 P at F=32)."""
+    return (840 + 8 * f) * n + (124 + 8 * f) * r + (44 + 8 * f) * p
+
+
+def settings_for(cam, device):
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width,
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=device), scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform.to(device), projmatrix=cam.full_proj_transform.to(device),
+        sh_degree=3, campos=cam.camera_center.to(device), prefiltered=False, debug=False)
+
+
+def cpu_baseline(scene_cpu, cam, feat, tile_step, budget_s):
+    """The oracle ("port") timed on the host cores on a bounded sample of the same workload:
+    full per-Gaussian preprocess + compositing fwd+bwd of every tile_step-th tile until the
+    forward time budget is spent; extrapolated by the (tile,Gaussian) pair count."""
+    from oracle import raster_oracle as ro
+    st = settings_for(cam, "cpu")
+    act = scene_cpu.activated()
+    leaves = {k: v.double().clone().requires_grad_(True) for k, v in act.items()}
+    t0 = time.perf_counter()
+    o = ro.rasterize(st, leaves["means3D"], None, shs=leaves["shs"], sh_objs=leaves["sh_objs"],
+                     opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                     tile_step=tile_step, max_seconds=budget_s)
+    loss = o.image.sum() + o.feats.sum()
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return dt, o.num_rendered, o.pairs_done
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=300_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--feat", type=int, default=32)
+    ap.add_argument("--scale-mult", type=float, default=0.27)
+    ap.add_argument("--variant", type=lambda s: int(s, 0), default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-step", type=int, default=37)
+    ap.add_argument("--cpu-budget-s", type=float, default=6.0, help="forward wall-time budget of the CPU sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16)")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    if args.variant is not None:
+        R.set_variant(args.variant)
+
+    N, W, H, F = args.gaussians, args.width, args.height, args.feat
+    P = W * H
+    scene_cpu = make_scene(N, feat_dim=F, seed=0, scale_mult=args.scale_mult)
+    scene = scene_cpu.to(device)
+    names = ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity", "gaussian_features")
+    params = [getattr(scene, k).requires_grad_(True) for k in names]
+    # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
+    flat = torch.zeros(sum(p.numel() for p in params), device=device)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+
+    n_views = 16
+    cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
+    settings = [settings_for(c, device) for c in cams]
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    g_img = torch.randn(3, H, W, generator=g).to(device) / P
+    g_feat = torch.randn(F, H, W, generator=g).to(device) / P
+
+    def step(i):
+        flat.zero_()
+        st = settings[i % n_views]
+        xyz, f_dc, f_rest, scaling, rotation, opacity, gfeat = params
+        means2D = torch.zeros_like(xyz, requires_grad=True)            # gaussian_renderer/__init__.py:48
+        scales = torch.exp(scaling)
+        rots = torch.nn.functional.normalize(rotation)
+        opac = torch.sigmoid(opacity)
+        shs = torch.cat((f_dc, f_rest), dim=1)
+        sh_objs = gfeat / (gfeat.norm(dim=2, keepdim=True) + 1e-9)
+        img, radii, feats, depth = GaussianRasterizer(raster_settings=st)(
+            means3D=xyz, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=None, opacities=opac,
+            scales=scales, rotations=rots, cov3D_precomp=None)
+        torch.autograd.backward([img, feats], [g_img, g_feat])
+        if world > 1:
+            dist.all_reduce(flat)
+        return radii
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    # ---- sizing pass (synchronising policy): measure the pair count of every view
+    log(f"scene ready: N={N} {W}x{H} F={F}")
+    R.set_sync(True)
+    r_list = []
+    for i in range(n_views):
+        step(i)
+        r_list.append(R.last_status()[0])
+    r_max, r_mean = max(r_list), sum(r_list) / len(r_list)
+    R.set_sync(False, capacity=int(r_max * 1.25) + 1024)
+    log(f"pairs per view: mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f})")
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    R.profile_enable(2)          # HIP events around the compositing kernels only, on the launch stream
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    prof = R.profile_report()
+    R.profile_enable(0)
+    status = R.last_status()
+    assert status[1] == 0, "pair buffer overflowed inside the timed region; result invalid"
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    views_per_s = world * args.steps / elapsed
+    log(f"timed: {ms_per_step:.3f} ms/step, {views_per_s:.1f} views/s")
+
+    breakdown = None
+    if args.kernel_breakdown or True:
+        R.profile_enable(1)
+        for i in range(min(4, n_views)):
+            step(i)
+        torch.cuda.synchronize()
+        breakdown = {k: round(v["ms"] * v["n"] / min(4, n_views), 4) for k, v in R.profile_report().items()}
+        R.profile_enable(0)
+
+    if rank == 0:
+        r_used = sum(r_list[i % n_views] for i in range(args.steps)) / args.steps
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"] * kv[1]["n"])[0] if prof else "render_bwd"
+        dom_ms = prof[dom]["ms"] if prof else float("nan")
+        a_bytes = algorithmic_bytes(dom, N, r_used, P, F)
+        achieved = a_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat",
+            "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S4 headline: {N} Gaussians, {W}x{H}, F={F}, SH deg 3, one view per step per GPU"
+                                   + (", view-DP + RCCL all-reduce of Gaussian grads" if world > 1 else ""),
+                       "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
+                       "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
+                         "view_frac": round(view_bytes(N, r_used, P, F) * views_per_s / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernels_ms_per_view": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            host = os.cpu_count() or 1
+            threads = args.cpu_threads or min(host, 16)
+            torch.set_num_threads(threads)
+            print(f"[bench] cpu baseline: oracle on {threads} of {host} host cores ...", file=sys.stderr, flush=True)
+            dt, r_cpu, pairs = cpu_baseline(scene_cpu, cams[0], F, args.cpu_tile_step, args.cpu_budget_s)
+            est_full = dt * r_cpu / max(pairs, 1)
+            out["cpu_baseline"] = {"value": round(1.0 / est_full, 6), "unit": "views/s", "cores": threads,
+                                   "kind": "port", "host_cores": host,
+                                   "sample": f"float64 oracle fwd+bwd on view 0: all {N} Gaussians preprocessed, "
+                                             f"{pairs} of {r_cpu} (tile,Gaussian) pairs composited "
+                                             f"(every {args.cpu_tile_step}th tile, {dt:.1f} s measured, extrapolated by pair count)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -285,12 +285,14 @@ class OracleOut:
     geom: Geom
     final_T: torch.Tensor    # (H,W)
     n_contrib: torch.Tensor  # (H,W)
+    pairs_done: int = 0      # (tile,Gaussian) pairs actually composited (== num_rendered unless sampled)
 
 
 def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_precomp=None,
               opacities=None, scales=None, rotations=None, cov3D_precomp=None,
               opt: OracleOptions = OracleOptions(), sort_depth: Optional[torch.Tensor] = None,
-              radii_override: Optional[torch.Tensor] = None) -> OracleOut:
+              radii_override: Optional[torch.Tensor] = None, tile_step: int = 1,
+              max_seconds: Optional[float] = None) -> OracleOut:
     """Full forward.  All float inputs are promoted to float64 (gradients flow
     back to the caller's leaves through the promotion).
 
@@ -298,7 +300,11 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     device's own view-space depths) -- removes order flips between float32 and
     float64 depth evaluation from the comparison.
     radii_override: optional (N,) int radii from the device, used *only* for
-    Gaussians the oracle marks fragile."""
+    Gaussians the oracle marks fragile.
+    tile_step: render only every tile_step-th tile (bounded sample for bench.py's
+    cpu_baseline timing); skipped tiles keep the background.
+    max_seconds: stop compositing further tiles once this much wall time has been
+    spent in the tile loop (bounded sample); OracleOut.pairs_done says how far it got."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -330,14 +336,26 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     key32 = key.to(torch.float32)
     rect = g.rect
     vidx = torch.nonzero(g.valid).reshape(-1)
+    import time as _time
+    t_loop = _time.perf_counter()
+    pairs_done = 0
+    stop = False
     for ty in range(gy):
+        if stop:
+            break
         in_row = vidx[(rect[vidx, 1] <= ty) & (rect[vidx, 3] > ty)]
         if in_row.numel() == 0:
             continue
         for tx in range(gx):
+            if tile_step > 1 and (ty * gx + tx) % tile_step != 0:
+                continue
             ids = in_row[(rect[in_row, 0] <= tx) & (rect[in_row, 2] > tx)]
             if ids.numel() == 0:
                 continue
+            if max_seconds is not None and _time.perf_counter() - t_loop > max_seconds:
+                stop = True
+                break
+            pairs_done += int(ids.numel())
             # stable sort on the float32 depth bits, ties -> ascending Gaussian index
             order = torch.sort(key32[ids], stable=True).indices
             ids = ids[order]
@@ -375,7 +393,7 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     depth = canvas[..., 3 + F:].permute(2, 0, 1)
     return OracleOut(image=img, radii=g.radii, feats=feats, depth=depth, fragile=fragile,
                      frag_gauss=g.frag_gauss, num_rendered=int(g.tiles_touched.sum()), geom=g,
-                     final_T=final_T, n_contrib=n_contrib)
+                     final_T=final_T, n_contrib=n_contrib, pairs_done=pairs_done)
 
 
 def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:

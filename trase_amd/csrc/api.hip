@@ -32,12 +32,14 @@ int check_hip(hipError_t e, const char* what) {
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static int g_prof_mode = 0;   // 1: every kernel, 2: only the compositing kernels (render_*)
 static std::vector<ProfRec*> g_prof_recs;
 
 bool prof_on() { return g_prof_on; }
 
 ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), rec(nullptr) {
   if (!g_prof_on) return;
+  if (g_prof_mode == 2 && strncmp(n, "render_", 7) != 0) return;
   ProfRec* r = new ProfRec();
   r->name = n;
   if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) { delete r; return; }
@@ -311,6 +313,7 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
 int trase_prof_enable(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
+  g_prof_mode = enable;
   if (enable) {
     for (ProfRec* r : g_prof_recs) { hipEventDestroy(r->e0); hipEventDestroy(r->e1); delete r; }
     g_prof_recs.clear();

@@ -306,8 +306,9 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg
 # --------------------------------------------------------------------------------------
-def profile_enable(flag: bool):
-    _lib.check(_lib.load().trase_prof_enable(1 if flag else 0), "trase_prof_enable")
+def profile_enable(mode: int):
+    """0 off, 1 every kernel, 2 only the compositing kernels (render_fwd / render_bwd)."""
+    _lib.check(_lib.load().trase_prof_enable(int(mode)), "trase_prof_enable")
 
 
 def profile_report() -> dict:
