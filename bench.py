@@ -156,13 +156,16 @@ def main():
     # ---- sizing pass (synchronising policy): measure the pair count of every view
     log(f"scene ready: N={N} {W}x{H} F={F}")
     R.set_sync(True)
-    r_list = []
+    r_list, reff_list = [], []
     for i in range(n_views):
         step(i)
-        r_list.append(R.last_status()[0])
+        st_ = R.last_status()
+        r_list.append(st_[0])        # lineage definition: sum of 16x16 tiles touched
+        reff_list.append(st_[2])     # (8x8 sub-tile, Gaussian) pairs actually binned after exact culling
     r_max, r_mean = max(r_list), sum(r_list) / len(r_list)
-    R.set_sync(False, capacity=int(r_max * 1.25) + 1024)
-    log(f"pairs per view: mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f})")
+    reff_mean = sum(reff_list) / len(reff_list)
+    R.set_sync(False, capacity=int(max(reff_list) * 1.25) + 1024)
+    log(f"pairs per view: lineage R mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f}); binned sub-tile pairs mean {reff_mean:.0f}")
 
     for i in range(args.warmup):
         step(i)
@@ -220,6 +223,7 @@ def main():
             "config": {"workload": f"S4 headline: {N} Gaussians, {W}x{H}, F={F}, SH deg 3, one view per step per GPU"
                                    + (", view-DP + RCCL all-reduce of Gaussian grads" if world > 1 else ""),
                        "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
+                       "subtile_pairs_mean": round(reff_mean),
                        "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -62,3 +62,7 @@ void hs_backward(const HsView* hv, int n, const float* p, const float* scale, co
   }
 }
 }
+
+extern "C" int hs_subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+  return trase::subtile_live(gx, gy, A, B, C, opacity, bx, by, W, H) ? 1 : 0;
+}

@@ -210,10 +210,10 @@ def test_nosync_capacity_policy_and_overflow_flag():
     try:
         R.set_sync(True)
         g_sync, _ = _gpu_call(act, st, need_grad=False)
-        n_pairs = R.last_status()[0]
+        n_lineage, _, n_pairs = R.last_status()      # lineage count R, overflow, pairs after sub-tile culling
         R.set_sync(False, capacity=int(n_pairs * 1.5) + 16)
         g_async, _ = _gpu_call(act, st, need_grad=False)
-        assert R.last_status()[:2] == (n_pairs, 0)
+        assert R.last_status() == (n_lineage, 0, n_pairs)
         for a, b in zip(g_sync, g_async):
             assert torch.equal(a, b)
         R.set_sync(False, capacity=max(n_pairs // 2, 1))

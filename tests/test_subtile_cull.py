@@ -1,0 +1,47 @@
+"""Exact sub-tile culling (gs_math.h subtile_live) must be conservative: it may keep a block no
+pixel of which passes the blend gate, but it must never drop a block in which some pixel does."""
+import ctypes as C
+
+import numpy as np
+
+
+def test_subtile_cull_is_conservative_and_tight(hostsim):
+    hostsim.hs_subtile_live.restype = C.c_int
+    hostsim.hs_subtile_live.argtypes = [C.c_float] * 6 + [C.c_int] * 4
+    rng = np.random.default_rng(0)
+    W, H = 200, 120
+    kept = dropped = wrongly_dropped = kept_dead = 0
+    for _ in range(12000):
+        gx, gy = rng.uniform(-30, W + 30), rng.uniform(-30, H + 30)
+        # random SPD covariance -> conic
+        s1, s2, th = rng.uniform(0.6, 25.0), rng.uniform(0.6, 25.0), rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cov = R @ np.diag([s1 * s1, s2 * s2]) @ R.T
+        con = np.linalg.inv(cov)
+        A, B, Cc = np.float32(con[0, 0]), np.float32(con[0, 1]), np.float32(con[1, 1])
+        op = np.float32(rng.choice([rng.uniform(0.001, 0.02), rng.uniform(0.02, 1.0)]))
+        # a block in the neighbourhood of the Gaussian (that is where the decision is non-trivial)
+        reach = 3.5 * max(s1, s2)
+        bx = 8 * int((gx + rng.uniform(-reach, reach)) // 8)
+        by = 8 * int((gy + rng.uniform(-reach, reach)) // 8)
+        if bx < 0 or by < 0 or bx >= W or by >= H:
+            continue
+        xs = np.arange(bx, min(bx + 8, W), dtype=np.float64)
+        ys = np.arange(by, min(by + 8, H), dtype=np.float64)
+        dx = np.float64(np.float32(gx)) - xs[None, :]
+        dy = np.float64(np.float32(gy)) - ys[:, None]
+        power = -0.5 * (float(A) * dx * dx + float(Cc) * dy * dy) - float(B) * dx * dy
+        alpha = np.minimum(0.99, float(op) * np.exp(np.minimum(power, 0)))
+        passes = bool(((power <= 0) & (alpha >= 1.0 / 255.0 * (1 - 1e-6))).any())
+        live = bool(hostsim.hs_subtile_live(np.float32(gx), np.float32(gy), A, B, Cc, op, int(bx), int(by), W, H))
+        if live:
+            kept += 1
+            kept_dead += (not passes)
+        else:
+            dropped += 1
+            wrongly_dropped += passes
+    assert wrongly_dropped == 0
+    assert dropped > 500 and kept > 500
+    # the continuous-box bound is tight: few kept blocks are dead (the slack is the gap between
+    # the pixel lattice and the continuous box)
+    assert kept_dead < 0.25 * kept, (kept_dead, kept)

@@ -75,11 +75,12 @@ GeomBuf carve_geom(void* ptr, int P) {
   g.clamped = (uint32_t*)c;
   return g;
 }
-size_t bin_bytes(int64_t cap, int T) { return align_up(sizeof(uint32_t) * (size_t)cap) + align_up(sizeof(uint2) * (size_t)T); }
+size_t bin_bytes(int64_t cap, int T) { return align_up(sizeof(uint32_t) * (size_t)cap) * 2 + align_up(sizeof(uint2) * (size_t)T); }
 BinBuf carve_bin(void* ptr, int64_t cap, int T) {
   char* c = (char*)ptr;
   BinBuf b;
   b.point_list = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (size_t)cap);
+  b.pair_slot = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (size_t)cap);
   b.ranges = (uint2*)c;
   (void)T;
   return b;
@@ -114,7 +115,7 @@ PreBuf carve_pre(void* ptr, int P) {
 }
 size_t tmp_bytes(int64_t cap) {
   const size_t n = (size_t)cap;
-  return align_up(sizeof(uint32_t) * n) * 3 + sort_bytes_common(n);
+  return align_up(sizeof(uint32_t) * n) * 4 + sort_bytes_common(n);
 }
 PairBuf carve_tmp(void* ptr, int64_t cap) {
   const size_t n = (size_t)cap;
@@ -122,13 +123,16 @@ PairBuf carve_tmp(void* ptr, int64_t cap) {
   PairBuf t;
   for (int i = 0; i < 2; ++i) { t.sort.keys[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n); }
   t.spare_vals = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n);
+  t.pair_gauss = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n);
   t.sort.vals[0] = t.sort.vals[1] = nullptr;
   t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(n);
   return t;
 }
-size_t bwd_tmp_bytes(int P) { return align_up(sizeof(float) * BWD_ACC * (size_t)P); }
+size_t bwd_tmp_bytes(int P, int F, int64_t cap) {
+  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up(sizeof(float) * bwd_row_floats(F) * (size_t)cap);
+}
 
 static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
   if (!s || !in) { set_error("null settings/inputs"); return TRASE_ERR_INVALID; }
@@ -158,7 +162,7 @@ static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
 enum { WS_GEOM = 1, WS_PRE = 2, WS_BIN = 4, WS_IMG = 8, WS_TMP = 16 };
 static int check_ws(const TraseRastInputs* in, const TraseRastSettings* s, const TraseRastWorkspace* ws, int need) {
   if (!ws) { set_error("null workspace"); return TRASE_ERR_WORKSPACE; }
-  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  const int gx = (s->image_width + SUB - 1) / SUB, gy = (s->image_height + SUB - 1) / SUB;
   if ((need & WS_GEOM) && (!ws->geom || ws->geom_bytes < geom_bytes(in->P))) { set_error("geom workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
   if ((need & WS_PRE) && (!ws->pre || ws->pre_bytes < pre_bytes(in->P))) { set_error("pre workspace missing/too small"); return TRASE_ERR_WORKSPACE; }
   if (need & (WS_BIN | WS_TMP)) {
@@ -182,13 +186,13 @@ const char* trase_version(void) { return "trase_amd 0.1 (gfx950)"; }
 int trase_rast_sizes(int32_t P, int32_t W, int32_t H, int32_t F, int64_t capacity, TraseRastSizes* out) {
   (void)F;
   if (!out || P < 0 || W <= 0 || H <= 0 || capacity < 1) { set_error("trase_rast_sizes: bad arguments"); return TRASE_ERR_INVALID; }
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int gx = (W + SUB - 1) / SUB, gy = (H + SUB - 1) / SUB;   // lists are per 8x8 sub-tile
   out->geom_bytes = geom_bytes(P);
   out->bin_bytes = bin_bytes(capacity, gx * gy);
   out->img_bytes = img_bytes(W, H);
   out->pre_bytes = pre_bytes(P);
   out->tmp_bytes = tmp_bytes(capacity);
-  out->bwd_tmp_bytes = bwd_tmp_bytes(P);
+  out->bwd_tmp_bytes = bwd_tmp_bytes(P, F, capacity);
   return TRASE_OK;
 }
 
@@ -240,7 +244,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(s->device));
   LaunchCtx c{stream, s->debug, s->variant};
-  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  const int gx = (s->image_width + SUB - 1) / SUB, gy = (s->image_height + SUB - 1) / SUB;
   const int T = gx * gy;
   GeomBuf g = carve_geom(ws->geom, in->P);
   BinBuf b = carve_bin(ws->bin, ws->capacity, T);
@@ -251,18 +255,21 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
   if (in->P > 0) {
     int bits = 1;
     while ((1 << bits) < T) ++bits;
-    // arrange the value ping-pong so that the last pass lands in the saved point list
+    // the sort carries each pair's emit-order slot (generated on the fly in the first pass); arrange
+    // the value ping-pong so that the last pass lands in the saved pair_slot array
     const int passes = radix_passes(0, bits);
     const int final_idx = passes & 1;
-    t.sort.vals[final_idx] = b.point_list;
+    t.sort.vals[final_idx] = b.pair_slot;
     t.sort.vals[final_idx ^ 1] = t.spare_vals;
-    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.sort.vals[0], cap);
+    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap);
     if (rc) return rc;
     int idx = 0;
-    rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R, cap, 0, bits, false, &idx);
+    rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-    rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R, cap, b.ranges, T);
+    rc = launch_gather_ids(c, b.pair_slot, t.pair_gauss, g.hdr + HDR_R_EFF, cap, b.point_list);
+    if (rc) return rc;
+    rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T);
     if (rc) return rc;
   } else {
     TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, stream));
@@ -282,31 +289,45 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   int rc = validate(s, in);
   if (rc) return rc;
   if (!gr || !out || (in->P > 0 && !out->radii)) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
-  rc = check_ws(in, s, ws, WS_GEOM | WS_BIN | WS_IMG);
+  rc = check_ws(in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG);
   if (rc) return rc;
-  if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in->P)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
+  if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in->P, in->F, ws->capacity)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(s->device));
   LaunchCtx c{stream, s->debug, s->variant};
-  const int gx = (s->image_width + TILE - 1) / TILE, gy = (s->image_height + TILE - 1) / TILE;
+  const int gx = (s->image_width + SUB - 1) / SUB, gy = (s->image_height + SUB - 1) / SUB;
   GeomBuf g = carve_geom(ws->geom, in->P);
   BinBuf b = carve_bin(ws->bin, ws->capacity, gx * gy);
   ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
+  PreBuf pre = carve_pre(ws->pre, in->P);
   float* acc = (float*)ws->tmp;
+  float* rows = (float*)((char*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in->P));
   if (in->P == 0) return TRASE_OK;
-  TRASE_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * BWD_ACC * (size_t)in->P, stream));
-  if (gr->dL_dsh_objs && in->F > 0)
-    TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
   TraseRastGrads g2 = *gr;
   if (!(s->variant & 0x100)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
   TraseRastInputs in2 = *in;
-  if (!g2.dL_dfeats || !g2.dL_dsh_objs) {
-    // feature map unused by the loss (GAUSSIAN state) or features frozen: the feature channels
-    // contribute nothing we need unless their cotangent also drives alpha
-    if (!g2.dL_dfeats) { in2.F = 0; g2.dL_dsh_objs = nullptr; }
+  bool zero_feats = false;
+  if (!g2.dL_dfeats) {
+    // feature map unused by the loss (GAUSSIAN state): its channels contribute nothing
+    in2.F = 0;
+    zero_feats = g2.dL_dsh_objs != nullptr && in->F > 0;
+    g2.dL_dsh_objs = nullptr;
   }
-  rc = launch_render_bwd(c, *s, in2, g, b, im, g2, acc);
-  if (rc) return rc;
+  if (zero_feats) TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
+  if (s->variant & 1) {
+    // first-generation "lane = pixel" backward with atomics (kept for A/B ablation)
+    TRASE_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * BWD_ACC * (size_t)in->P, stream));
+    if (g2.dL_dsh_objs) TRASE_CHECK(hipMemsetAsync(g2.dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
+    rc = launch_render_bwd(c, *s, in2, g, b, im, g2, acc);
+    if (rc) return rc;
+  } else {
+    // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
+    // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
+    rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows);
+    if (rc) return rc;
+    rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, acc, g2.dL_dsh_objs);
+    if (rc) return rc;
+  }
   return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);
 }
 

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const uint32_t R = carry;
-    hdr[HDR_R] = R;
+    const uint32_t R = carry;     // pairs after exact sub-tile culling (HDR_R holds the lineage count)
     hdr[HDR_R_EFF] = R;
     hdr[HDR_OVERFLOW] = (R > cap) ? 1u : 0u;
   }
@@ -293,39 +292,128 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 // ---- emit (tile, id) pairs in depth-rank order --------------------------------------------------
 __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ sorted_ids, int P,
                                                          const uint32_t* __restrict__ offsets,
-                                                         const float2* __restrict__ xy, const int32_t* __restrict__ radii,
-                                                         const uint32_t* __restrict__ tiles, int gx, int gy,
-                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                         const float2* __restrict__ xy, const float4* __restrict__ conic_o,
+                                                         const int32_t* __restrict__ radii,
+                                                         const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
                                                          uint32_t cap, uint32_t* __restrict__ hdr) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0 && hdr[HDR_R] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
+  if (r == 0) {
+    if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
+    hdr[HDR_WORDS - 2] = cap;
+  }
   if (r >= P) return;
   const uint32_t id = sorted_ids[r];
   const uint32_t nt = tiles[id];
   if (nt == 0) return;
   uint32_t off = offsets[r] - nt;
   const float2 p = xy[id];
+  const float4 co = conic_o[id];
   int x0, y0, x1, y1;
   tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      if (off < cap) {
-        keys[off] = (uint32_t)(y * gx + x);
-        vals[off] = id;
+  const int gx8 = (W + SUB - 1) / SUB;
+  for (int ty = y0; ty < y1; ++ty)
+    for (int tx = x0; tx < x1; ++tx) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
+        if (bx < W && by < H && subtile_live(p.x, p.y, co.x, co.y, co.z, co.w, bx, by, W, H)) {
+          if (off < cap) {
+            keys[off] = (uint32_t)((by / SUB) * gx8 + (bx / SUB));
+            pair_gauss[off] = id;
+          }
+          ++off;
+        }
       }
-      ++off;
     }
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
-                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* vals, uint32_t cap) {
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap) {
   const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
   {
     ProfScope ps("emit_pairs", c.stream);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
-                       radii, g.tiles, gx, gy, keys, vals, cap, g.hdr);
+                       g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr);
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- list entry -> Gaussian id (the sort carried the emit-order slot) ---------------------------
+__global__ __launch_bounds__(256) void gather_ids_kernel(const uint32_t* __restrict__ pair_slot,
+                                                         const uint32_t* __restrict__ pair_gauss,
+                                                         const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                         uint32_t* __restrict__ point_list) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    point_list[i] = pair_gauss[pair_slot[i]];
+}
+
+int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
+                      uint32_t cap, uint32_t* point_list) {
+  int blocks = (int)((cap + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  {
+    ProfScope ps("gather_ids", c.stream);
+    hipLaunchKernelGGL(gather_ids_kernel, dim3(blocks), dim3(256), 0, c.stream, pair_slot, pair_gauss, n_ptr, cap, point_list);
+  }
+  TRASE_POST_LAUNCH("gather_ids", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- backward phase 2: per-Gaussian sum of its (contiguous) per-pair gradient rows ----------------
+// One wave per depth rank; lane = column of the row.  Writes every Gaussian (zeros where it has no
+// pairs), so neither buffer needs a memset and the sums are bit-reproducible.
+template <int ROW>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ tiles, int P,
+                                                          const uint32_t* __restrict__ hdr,
+                                                          const float* __restrict__ rows, float* __restrict__ acc,
+                                                          float* __restrict__ d_feats) {
+  constexpr int F = ROW - 16;
+  const int r = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= P) return;
+  const uint32_t id = sorted_ids[r];
+  const uint32_t nt = tiles[id];
+  uint32_t k1 = offsets[r];
+  uint32_t k0 = k1 - nt;
+  const uint32_t cap = hdr[HDR_WORDS - 2];          // capacity the lists were built with
+  if (k1 > cap) k1 = cap;                           // pairs dropped by an overflow have no row
+  if (k0 > k1) k0 = k1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (lane < ROW) {
+    const float* p = rows + (size_t)k0 * ROW + lane;
+    uint32_t k = k0;
+    for (; k + 4 <= k1; k += 4, p += 4 * ROW) {
+      s0 += p[0]; s1 += p[ROW]; s2 += p[2 * ROW]; s3 += p[3 * ROW];
+    }
+    for (; k < k1; ++k, p += ROW) s0 += p[0];
+    const float tot = (s0 + s1) + (s2 + s3);
+    if (lane < F) {
+      if (d_feats) d_feats[(size_t)id * F + lane] = tot;
+    } else if (lane < F + 10) {
+      acc[(size_t)id * BWD_ACC + (lane - F)] = tot;
+    }
+  }
+}
+
+int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows, float* acc,
+                       float* d_feats) {
+  const int blocks = (P + 3) / 4;
+  {
+    ProfScope ps("reduce_rows", c.stream);
+    switch (F) {
+      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
+      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
+      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
+      default: set_error("reduce_rows: feature width %d not compiled in", F); return TRASE_ERR_UNSUPPORTED;
+    }
+  }
+  TRASE_POST_LAUNCH("reduce_rows", c.stream, c.debug);
   return TRASE_OK;
 }
 

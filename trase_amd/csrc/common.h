@@ -33,6 +33,33 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Inclusive scans over the 64 lanes (lane 0 first).  `ident` fills lanes that have no source.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_fill(float v, float ident) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+  v *= dpp_fill<0x111>(v, 1.0f);
+  v *= dpp_fill<0x112>(v, 1.0f);
+  v *= dpp_fill<0x114>(v, 1.0f);
+  v *= dpp_fill<0x118>(v, 1.0f);
+  v *= dpp_fill<0x142, 0xa>(v, 1.0f);
+  v *= dpp_fill<0x143, 0xc>(v, 1.0f);
+  return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v) {
+  v += dpp_fill<0x111>(v, 0.0f);
+  v += dpp_fill<0x112>(v, 0.0f);
+  v += dpp_fill<0x114>(v, 0.0f);
+  v += dpp_fill<0x118>(v, 0.0f);
+  v += dpp_fill<0x142, 0xa>(v, 0.0f);
+  v += dpp_fill<0x143, 0xc>(v, 0.0f);
+  return v;
+}
+// value of lane-1 (lane 0 receives `ident`): DPP wave_shr:1
+__device__ __forceinline__ float wave_shr1(float v, float ident) { return dpp_fill<0x138>(v, ident); }
+
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -96,8 +123,9 @@ struct GeomBuf {           // saved between forward and backward
   uint32_t* clamped;       // (P) colour clamp bits
 };
 struct BinBuf {            // saved between forward and backward
-  uint32_t* point_list;    // (capacity) Gaussian ids, tile-major, depth-ordered
-  uint2* ranges;           // (T) [start,end) per tile
+  uint32_t* point_list;    // (capacity) Gaussian ids, sub-tile-major, depth-ordered
+  uint32_t* pair_slot;     // (capacity) emit-order slot of every list entry (Gaussian-major numbering)
+  uint2* ranges;           // (T) [start,end) per sub-tile
 };
 struct ImgBuf {            // saved between forward and backward
   float* final_T;          // (H*W)
@@ -116,8 +144,9 @@ struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
   uint32_t* block_sums;    // scan partials
 };
 struct PairBuf {           // stage-2 scratch (capacity-sized)
-  SortBufs sort;           // vals[] = {spare, point_list} arranged by the caller
+  SortBufs sort;           // vals[] = {spare, bin.pair_slot} arranged by the caller
   uint32_t* spare_vals;
+  uint32_t* pair_gauss;    // (capacity) Gaussian id of every pair in emit order
 };
 struct BwdTmp {            // backward scratch: per-Gaussian accumulators filled by atomics
   float* acc;              // (P, BWD_ACC) : d_ndc(2) d_conic(3) d_opacity(1) d_rgb(3) d_depth(1) pad
@@ -130,7 +159,8 @@ size_t bin_bytes(int64_t cap, int T);
 size_t img_bytes(int W, int H);
 size_t pre_bytes(int P);
 size_t tmp_bytes(int64_t cap);
-size_t bwd_tmp_bytes(int P);
+size_t bwd_tmp_bytes(int P, int F, int64_t cap);
+static inline int bwd_row_floats(int F) { return F + 16; }   // per-pair gradient row: F features + 10 scalars, 16-B aligned
 GeomBuf carve_geom(void* p, int P);
 BinBuf carve_bin(void* p, int64_t cap, int T);
 ImgBuf carve_img(void* p, int W, int H);
@@ -155,11 +185,17 @@ int radix_passes(int bit_lo, int bit_hi);
 
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap);
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
-                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* vals, uint32_t cap);
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap);
+int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
+                      uint32_t cap, uint32_t* point_list);
+int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows, float* acc,
+                       float* d_feats);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im);
+int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows);
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

@@ -194,6 +194,44 @@ TRASE_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0,
   y1 = imin(gy, imax(0, (int)((py + r + (float)(TILE - 1)) / (float)TILE)));
 }
 
+// ---- exact sub-tile culling -----------------------------------------------------------------
+// The lists are binned per 8x8 pixel block ("sub-tile").  Which Gaussians a pixel may see is
+// still decided by the 16x16 tile rect above (visible semantics); inside that rect a sub-tile
+// drops a Gaussian only when NO pixel of the block can pass the blend gate
+// alpha = opacity * exp(power) >= 1/255, i.e. when the minimum of the conic's quadratic form
+// q = A dx^2 + 2B dx dy + C dy^2 over the block exceeds 2 ln(255 opacity) (with slack, so that a
+// float32 rounding difference can never drop a pair the compositing kernel would have blended).
+constexpr int SUB = 8;   // sub-tile edge
+
+TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+  const float tau_raw = 2.0f * logf(255.0f * opacity);
+  if (!(tau_raw >= 0.0f)) return false;   // opacity < 1/255 (or NaN): can never pass the gate
+  const float tau = tau_raw * 1.001f + 1e-3f;
+  // pixel centres of the block, clipped to the image
+  const float x0 = (float)bx, x1 = (float)imin(bx + SUB - 1, W - 1);
+  const float y0 = (float)by, y1 = (float)imin(by + SUB - 1, H - 1);
+  if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) return true;   // not positive definite: keep
+  // closest point of the box to the centre
+  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
+  if (cx == gx && cy == gy) return true;        // centre inside the block
+  float best = 3.0e38f;
+  // candidate 1: vertical edge facing the centre (dx fixed), optimum dy clamped to the edge
+  if (cx != gx) {
+    const float dx = cx - gx;
+    float dy = -B * dx / C;                      // unconstrained minimiser along the edge
+    dy = fminf(fmaxf(dy, y0 - gy), y1 - gy);
+    best = fminf(best, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+  }
+  // candidate 2: horizontal edge facing the centre
+  if (cy != gy) {
+    const float dy = cy - gy;
+    float dx = -B * dy / A;
+    dx = fminf(fmaxf(dx, x0 - gx), x1 - gx);
+    best = fminf(best, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+  }
+  return best <= tau;
+}
+
 // Forward of one Gaussian.  `sh` points at 48 floats: this Gaussian's (16,3) coefficients,
 // zero-padded beyond the active degree, or is null when `color` (precomputed rgb) is given.  `cov_in` null => from scale/rot.
 // Returns false (radius 0) when culled.

@@ -35,9 +35,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
                                                              uint32_t* __restrict__ clamped,
                                                              uint32_t* __restrict__ depth_keys,
                                                              uint32_t* __restrict__ hdr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;   // device-resident copy of P for the depth sort
-  if (i >= a.P) return;
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;   // device-resident copy of P for the depth sort
+  // no early return: the wave-level reduction below needs lane 63 of every wave alive
+  const bool active = gi < a.P;
+  const int i = active ? gi : a.P - 1;
   View v;
   fill_view(a, v);
   const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
@@ -67,13 +69,32 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
     color = col;
   }
   Splat o;
-  const bool vis = splat_forward(v, p, sc, q, cov_in, sh, color, o);
-  radii[i] = vis ? o.radius : 0;
-  tiles[i] = vis ? (uint32_t)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0u;
-  depth_keys[i] = vis ? __float_as_uint(o.depth) : 0xffffffffu;
+  const bool vis = splat_forward(v, p, sc, q, cov_in, sh, color, o) && active;
+  if (active) radii[i] = vis ? o.radius : 0;
+  // lineage pair count R (tiles of the 16x16 rect) -> one atomic per wave
+  const float rect_area = vis ? (float)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0.f;
+  const float wave_area = wave_sum_lane63(rect_area);
+  if ((threadIdx.x & 63) == 63 && wave_area > 0.f) atomicAdd(&hdr[HDR_R], (uint32_t)wave_area);
+  // live 8x8 sub-tiles inside the rect (exact culling, see gs_math.h)
+  uint32_t live = 0;
+  const float opac = a.opac[i];
+  if (vis) {
+    for (int ty = o.y0; ty < o.y1; ++ty)
+      for (int tx = o.x0; tx < o.x1; ++tx) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
+          if (bx < a.W && by < a.H && subtile_live(o.px, o.py, o.ca, o.cb, o.cc, opac, bx, by, a.W, a.H)) ++live;
+        }
+      }
+  }
+  if (active) {
+    tiles[i] = live;
+    depth_keys[i] = (vis && live) ? __float_as_uint(o.depth) : 0xffffffffu;
+  }
   if (vis) {
     xy[i] = make_float2(o.px, o.py);
-    conic_o[i] = make_float4(o.ca, o.cb, o.cc, a.opac[i]);
+    conic_o[i] = make_float4(o.ca, o.cb, o.cc, opac);
     rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }

@@ -1,41 +1,52 @@
 // render.hip -- alpha compositing of the per-tile depth-ordered lists (forward) and its backward.
-// Variant 0 ("valu"): one workgroup of 4 waves per 16x16 tile, each wave owns an 8x8 pixel
-// quadrant; batches of 256 list entries are staged through LDS; the per-Gaussian feature row
-// is fetched with a wave-uniform address (scalar-cache path), and only when some lane of the
-// wave actually blends that Gaussian.
+// Variant 0 ("valu"): one wave per 8x8 sub-tile (4 independent waves per workgroup, no workgroup
+// barriers); batches of 64 list entries are staged through wave-private LDS; the per-Gaussian
+// feature row is fetched with a wave-uniform address and only when some lane of the wave
+// actually blends that Gaussian.
 // Semantics: SURVEY.md Appendix A "Render fwd" / "Render bwd"; outputs as consumed at
 // gaussian_renderer/__init__.py:137-155 (image incl. background, feats without, blended depth).
 #include "common.h"
 
 namespace trase {
 
-constexpr int RB = 256;   // list entries staged per batch == threads per workgroup
+constexpr int WPB = 4;     // independent waves (sub-tiles) per workgroup
+constexpr int RB = WPB * WAVE;
 
 struct RenderArgs {
   const uint2* ranges; const uint32_t* point_list;
   const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
-  int W, H, gx, gy;
+  int W, H, gx8, ntiles;
 };
 
-__device__ __forceinline__ void pixel_of_thread(int tile, int gx, int& px, int& py, int& wave, int& lane) {
+// LDS produced and consumed by one wave only: order the accesses without a workgroup barrier
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// one wave == one 8x8 sub-tile; lane -> pixel
+__device__ __forceinline__ int subtile_of_wave(const RenderArgs& a, int& px, int& py, int& wave, int& lane) {
   wave = threadIdx.x >> 6;
   lane = threadIdx.x & 63;
-  const int tx = tile % gx, ty = tile / gx;
-  px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-  py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+  const int tile = blockIdx.x * WPB + wave;
+  const int tx = tile % a.gx8, ty = tile / a.gx8;
+  px = tx * SUB + (lane & 7);
+  py = ty * SUB + (lane >> 3);
+  return tile;
 }
 
 template <int F>
 __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __restrict__ out_img,
                                                         float* __restrict__ out_feat, float* __restrict__ out_depth,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float2 s_xy[RB];
-  __shared__ float4 s_co[RB];
-  __shared__ float4 s_cd[RB];
-  __shared__ uint32_t s_id[RB];
-  const int tile = blockIdx.x;
+  __shared__ float2 s_xy[WPB][WAVE];
+  __shared__ float4 s_co[WPB][WAVE];
+  __shared__ float4 s_cd[WPB][WAVE];
+  __shared__ uint32_t s_id[WPB][WAVE];
   int px, py, wave, lane;
-  pixel_of_thread(tile, a.gx, px, py, wave, lane);
+  const int tile = subtile_of_wave(a, px, py, wave, lane);
+  if (tile >= a.ntiles) return;
   const bool inside = px < a.W && py < a.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = a.ranges[tile];
@@ -46,22 +57,23 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
 #pragma unroll
   for (int c = 0; c < F; ++c) fa[c] = 0.f;
   bool done = !inside;
-  for (uint32_t base = range.x; base < range.y; base += RB) {
-    if (__syncthreads_and(done)) break;
-    const uint32_t n = min((uint32_t)RB, range.y - base);
-    if (threadIdx.x < n) {
-      const uint32_t id = a.point_list[base + threadIdx.x];
-      s_id[threadIdx.x] = id;
-      s_xy[threadIdx.x] = a.xy[id];
-      s_co[threadIdx.x] = a.conic_o[id];
-      s_cd[threadIdx.x] = a.rgbd[id];
+  for (uint32_t base = range.x; base < range.y; base += WAVE) {
+    if (__all(done)) break;
+    const uint32_t n = min((uint32_t)WAVE, range.y - base);
+    wave_lds_sync();
+    if ((uint32_t)lane < n) {
+      const uint32_t id = a.point_list[base + lane];
+      s_id[wave][lane] = id;
+      s_xy[wave][lane] = a.xy[id];
+      s_co[wave][lane] = a.conic_o[id];
+      s_cd[wave][lane] = a.rgbd[id];
     }
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t j = 0; j < n; ++j) {
       if (__all(done)) break;
       ++contributor;
-      const float2 g = s_xy[j];
-      const float4 co = s_co[j];
+      const float2 g = s_xy[wave][j];
+      const float4 co = s_co[wave][j];
       const float dx = g.x - pxf, dy = g.y - pyf;
       const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
       const float alpha = fminf(ALPHA_MAX, co.w * __expf(power));
@@ -70,10 +82,10 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
       if (ok && test_T < T_STOP) { done = true; ok = false; }
       if (__any(ok)) {
         const float w = ok ? alpha * T : 0.0f;
-        const float4 col = s_cd[j];
+        const float4 col = s_cd[wave][j];
         c0 += w * col.x; c1 += w * col.y; c2 += w * col.z; cd += w * col.w;
         if (F > 0) {
-          const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[j]);
+          const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[wave][j]);
           const float* __restrict__ f = a.feats + (size_t)id * F;
 #pragma unroll
           for (int c = 0; c < F; ++c) fa[c] += w * f[c];
@@ -96,13 +108,19 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
   }
 }
 
+static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                             const BinBuf& b) {
+  a.ranges = b.ranges; a.point_list = b.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
+  a.feats = in.sh_objs; a.bg = s.bg; a.W = s.image_width; a.H = s.image_height;
+  a.gx8 = (a.W + SUB - 1) / SUB;
+  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+}
+
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im) {
   RenderArgs a;
-  a.ranges = b.ranges; a.point_list = b.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
-  a.feats = in.sh_objs; a.bg = s.bg; a.W = s.image_width; a.H = s.image_height;
-  a.gx = (a.W + TILE - 1) / TILE; a.gy = (a.H + TILE - 1) / TILE;
-  const int T = a.gx * a.gy;
+  fill_render_args(a, s, in, g, b);
+  const int T = (a.ntiles + WPB - 1) / WPB;
   {
     ProfScope ps("render_fwd", c.stream);
     switch (in.F) {
@@ -132,17 +150,16 @@ struct RenderBwdArgs {
 template <int F>
 __global__ __launch_bounds__(RB) void render_bwd_kernel(RenderBwdArgs b) {
   const RenderArgs& a = b.r;
-  __shared__ float2 s_xy[RB];
-  __shared__ float4 s_co[RB];
-  __shared__ float4 s_cd[RB];
-  __shared__ uint32_t s_id[RB];
-  const int tile = blockIdx.x;
+  __shared__ float2 s_xy[WPB][WAVE];
+  __shared__ float4 s_co[WPB][WAVE];
+  __shared__ float4 s_cd[WPB][WAVE];
+  __shared__ uint32_t s_id[WPB][WAVE];
   int px, py, wave, lane;
-  pixel_of_thread(tile, a.gx, px, py, wave, lane);
+  const int tile = subtile_of_wave(a, px, py, wave, lane);
+  if (tile >= a.ntiles) return;
   const bool inside = px < a.W && py < a.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = a.ranges[tile];
-  const uint32_t todo = range.y - range.x;
   const size_t hw = (size_t)a.H * a.W;
   const size_t pix = (size_t)py * a.W + px;
   // pixel cotangents
@@ -165,33 +182,36 @@ __global__ __launch_bounds__(RB) void render_bwd_kernel(RenderBwdArgs b) {
   float T = T_final;
   float A = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2;   // "colour behind", projected on the cotangent
   const float ddx = 0.5f * (float)a.W, ddy = 0.5f * (float)a.H;
-  uint32_t contributor = todo;
-  // highest list position any pixel of this workgroup blended: entries behind it are skipped
-  for (uint32_t prog = 0; prog < todo; prog += RB) {
-    const uint32_t n = min((uint32_t)RB, todo - prog);
-    __syncthreads();
-    if (threadIdx.x < n) {
-      const uint32_t id = a.point_list[range.y - 1 - prog - threadIdx.x];
-      s_id[threadIdx.x] = id;
-      s_xy[threadIdx.x] = a.xy[id];
-      s_co[threadIdx.x] = a.conic_o[id];
-      s_cd[threadIdx.x] = a.rgbd[id];
+  // entries behind the last one any pixel of this sub-tile blended are never touched
+  uint32_t wave_last = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
+  uint32_t contributor = wave_last;
+  for (uint32_t prog = 0; prog < wave_last; prog += WAVE) {
+    const uint32_t n = min((uint32_t)WAVE, wave_last - prog);
+    wave_lds_sync();
+    if ((uint32_t)lane < n) {
+      const uint32_t id = a.point_list[range.x + wave_last - 1 - prog - lane];
+      s_id[wave][lane] = id;
+      s_xy[wave][lane] = a.xy[id];
+      s_co[wave][lane] = a.conic_o[id];
+      s_cd[wave][lane] = a.rgbd[id];
     }
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t j = 0; j < n; ++j) {
       --contributor;   // 0-based list position of this entry
       const bool live = contributor < last;
       if (!__any(live)) continue;
-      const float2 g = s_xy[j];
-      const float4 co = s_co[j];
+      const float2 g = s_xy[wave][j];
+      const float4 co = s_co[wave][j];
       const float dx = g.x - pxf, dy = g.y - pyf;
       const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
       const float G = __expf(power);
       const float alpha = fminf(ALPHA_MAX, co.w * G);
       const bool ok = live && power <= 0.0f && alpha >= ALPHA_MIN;
       if (!__any(ok)) continue;
-      const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[j]);
-      const float4 col = s_cd[j];
+      const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[wave][j]);
+      const float4 col = s_cd[wave][j];
       float s = col.x * g0 + col.y * g1 + col.z * g2 + col.w * gd;
       const float* __restrict__ f = a.feats + (size_t)id * F;
       float fr[F > 0 ? F : 1];
@@ -244,12 +264,10 @@ int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
                       const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* acc) {
   RenderBwdArgs b;
   RenderArgs& a = b.r;
-  a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
-  a.feats = in.sh_objs; a.bg = s.bg; a.W = s.image_width; a.H = s.image_height;
-  a.gx = (a.W + TILE - 1) / TILE; a.gy = (a.H + TILE - 1) / TILE;
+  fill_render_args(a, s, in, g, bb);
   b.d_img = gr.dL_dimage; b.d_feat = gr.dL_dfeats; b.d_depth = gr.dL_ddepth;
   b.final_T = im.final_T; b.n_contrib = im.n_contrib; b.acc = acc; b.d_feats_out = gr.dL_dsh_objs;
-  const int T = a.gx * a.gy;
+  const int T = (a.ntiles + WPB - 1) / WPB;
   {
     ProfScope ps("render_bwd", c.stream);
     switch (in.F) {

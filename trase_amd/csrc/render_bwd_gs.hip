@@ -1,0 +1,220 @@
+// render_bwd_gs.hip -- backward of the compositing stage, "lane = Gaussian" formulation (default).
+//
+// One wave per 8x8 sub-tile.  The sub-tile's depth-ordered list is walked back to front in chunks
+// of 64 entries; lane l owns ONE Gaussian of the chunk (lane 0 = farthest) and keeps its
+// parameters, its 32-float feature row and all of its gradient accumulators in registers.  The
+// wave then visits the 64 pixels of the sub-tile one after the other (pixel data is wave-uniform:
+// cotangents come from wave-private LDS as broadcast reads).  What is sequential along the list
+// for a fixed pixel becomes a scan across lanes:
+//     T_l  = T_end / prod_{k<=l} (1 - a_k)                      (DPP multiplicative scan)
+//     U_l  = U_end + sum_{k<l} w_k s_k ,  w = a T               (DPP additive scan, exclusive)
+//     dL/da_l = T_l s_l - U_l / (1 - a_l),   s_l = <channels of Gaussian l, pixel cotangent>
+// (U_end starts as T_final * <bg, d_rgb>), so no per-value cross-lane reduction is ever needed:
+// every per-Gaussian sum over pixels is a plain in-register accumulation.  Each chunk then writes
+// ONE row per (sub-tile, Gaussian) pair into the pair's emit-order slot; rows of one Gaussian are
+// contiguous there and are summed by reduce_rows_kernel (binning.hip).  No atomics anywhere.
+// Semantics: SURVEY.md Appendix A "Render bwd" (lineage: straight-through 0.99 clamp, true
+// derivative wrt the conic's off-diagonal entry).
+#include "common.h"
+
+namespace trase {
+
+constexpr int GWPB = 4;   // waves (sub-tiles) per workgroup
+
+struct BwdGsArgs {
+  const uint2* ranges; const uint32_t* point_list;
+  const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
+  const float* d_img; const float* d_feat; const float* d_depth;
+  const float* final_T; const uint32_t* n_contrib;
+  const uint32_t* pair_slot;   // emit-order slot of every list entry
+  float* rows;         // (capacity, F+16) one gradient row per pair, indexed by slot
+  int W, H, gx8, ntiles;
+  int ablate;          // debug: bit0 skip the atomic flush, bit1 skip the feature channels' work
+};
+
+__device__ __forceinline__ void wave_lds_sync2() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int F>
+__global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) {
+  constexpr int CH = 4 + F;                      // r g b depth | features
+  __shared__ __attribute__((aligned(16))) float s_cot[GWPB][WAVE][CH];   // pixel-major cotangents
+  __shared__ __attribute__((aligned(16))) float4 s_pix[GWPB][WAVE];      // T_end, U_end, last (bits), -
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * GWPB + wave;
+  if (tile >= a.ntiles) return;
+  const int tx = tile % a.gx8, ty = tile / a.gx8;
+  const uint2 range = a.ranges[tile];
+  // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
+  uint32_t last;
+  {
+    const int px = tx * SUB + (lane & 7), py = ty * SUB + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const size_t hw = (size_t)a.H * a.W;
+    const size_t pix = (size_t)py * a.W + px;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, Tf = 0.f;
+    last = 0;
+    if (inside) {
+      Tf = a.final_T[pix];
+      last = a.n_contrib[pix];
+      if (a.d_img) { g0 = a.d_img[pix]; g1 = a.d_img[hw + pix]; g2 = a.d_img[2 * hw + pix]; }
+      if (a.d_depth) gd = a.d_depth[pix];
+    }
+    float* row = s_cot[wave][lane];
+    *reinterpret_cast<float4*>(row) = make_float4(g0, g1, g2, gd);
+    if (F > 0) {
+#pragma unroll
+      for (int c4 = 0; c4 < F / 4; ++c4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside && a.d_feat) {
+          v.x = a.d_feat[(size_t)(4 * c4 + 0) * hw + pix];
+          v.y = a.d_feat[(size_t)(4 * c4 + 1) * hw + pix];
+          v.z = a.d_feat[(size_t)(4 * c4 + 2) * hw + pix];
+          v.w = a.d_feat[(size_t)(4 * c4 + 3) * hw + pix];
+        }
+        *reinterpret_cast<float4*>(row + 4 + 4 * c4) = v;
+      }
+    }
+    const float bdot = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2;
+    s_pix[wave][lane] = make_float4(Tf, Tf * bdot, __uint_as_float(last), 0.f);
+  }
+  uint32_t wave_last = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
+  wave_lds_sync2();
+  const float ddx = 0.5f * (float)a.W, ddy = 0.5f * (float)a.H;
+  const float bx = (float)(tx * SUB), by = (float)(ty * SUB);
+  // ---- chunks of 64 list entries, back to front ----------------------------------------------------
+  // (every list entry gets its row written exactly once; entries behind the last blended one get zeros)
+  const uint32_t len = range.y - range.x;
+  for (uint32_t c1 = len; c1 > 0; c1 = (c1 > WAVE) ? c1 - WAVE : 0) {
+    const uint32_t c0 = (c1 > WAVE) ? c1 - WAVE : 0;
+    const uint32_t n = c1 - c0;
+    const bool lane_valid = (uint32_t)lane < n;
+    const uint32_t pos = lane_valid ? (c1 - 1 - lane) : 0;     // lane 0 = farthest entry of the chunk
+    const uint32_t id = a.point_list[range.x + pos];
+    const uint32_t slot = a.pair_slot[range.x + pos];
+    constexpr int ROW = F + 16;
+    if (c0 >= wave_last) {                         // wave-uniform: nothing of this chunk was ever blended
+      if (lane_valid) {
+        float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
+#pragma unroll
+        for (int q = 0; q < ROW / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
+    const float2 gxy = a.xy[id];
+    const float4 co = a.conic_o[id];
+    const float4 col = a.rgbd[id];
+    float f[F > 0 ? F : 1];
+    if (F > 0) {
+      const float4* fr = reinterpret_cast<const float4*>(a.feats + (size_t)id * F);
+#pragma unroll
+      for (int c4 = 0; c4 < F / 4; ++c4) {
+        const float4 v = fr[c4];
+        f[4 * c4] = v.x; f[4 * c4 + 1] = v.y; f[4 * c4 + 2] = v.z; f[4 * c4 + 3] = v.w;
+      }
+    }
+    float a_nx = 0.f, a_ny = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f;
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+    float af[F > 0 ? F : 1];
+#pragma unroll
+    for (int c = 0; c < F; ++c) af[c] = 0.f;
+    const float rx = gxy.x - bx, ry = gxy.y - by;     // centre relative to the sub-tile origin
+    for (int p = 0; p < WAVE; ++p) {
+      const float4 pst = s_pix[wave][p];               // uniform read
+      const uint32_t plast = __builtin_amdgcn_readfirstlane(__float_as_uint(pst.z));
+      if (plast <= c0) continue;                       // nothing of this chunk was blended into pixel p
+      const float T_end = pst.x, U_end = pst.y;
+      const float dx = rx - (float)(p & 7), dy = ry - (float)(p >> 3);
+      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      const float G = __expf(power);
+      const float alpha = fminf(ALPHA_MAX, co.w * G);
+      const bool ok = lane_valid && pos < plast && power <= 0.0f && alpha >= ALPHA_MIN;
+      const float al = ok ? alpha : 0.0f;
+      const float om = 1.0f - al;
+      const float PP = wave_scan_mul(om);
+      const float T = T_end * __builtin_amdgcn_rcpf(PP);           // transmittance in front of this Gaussian
+      const float w = al * T;
+      // s = <channels, cotangent of pixel p>
+      const float* cot = s_cot[wave][p];
+      const float4 cg = *reinterpret_cast<const float4*>(cot);
+      float s = col.x * cg.x + col.y * cg.y + col.z * cg.z + col.w * cg.w;
+      float gf[F > 0 ? F : 1];
+      if (F > 0) {
+#pragma unroll
+        for (int c4 = 0; c4 < F / 4; ++c4) {
+          const float4 v = *reinterpret_cast<const float4*>(cot + 4 + 4 * c4);
+          gf[4 * c4] = v.x; gf[4 * c4 + 1] = v.y; gf[4 * c4 + 2] = v.z; gf[4 * c4 + 3] = v.w;
+          s += f[4 * c4] * v.x + f[4 * c4 + 1] * v.y + f[4 * c4 + 2] * v.z + f[4 * c4 + 3] * v.w;
+        }
+      }
+      const float ws = w * s;
+      const float incl = wave_scan_add(ws);
+      const float U = U_end + (incl - ws);
+      const float dL_dalpha = ok ? (T * s - U * __builtin_amdgcn_rcpf(om)) : 0.0f;
+      // carries for the next (nearer) chunk: lane 63 sees the whole chunk
+      if (lane == WAVE - 1) {
+        s_pix[wave][p].x = T;                          // om == 1 on invalid lanes, so this is T in front of the chunk
+        s_pix[wave][p].y = U_end + incl;
+      }
+      const float dL_dG = co.w * dL_dalpha;
+      const float gdx = G * dx, gdy = G * dy;
+      a_nx += dL_dG * (-gdx * co.x - gdy * co.y);
+      a_ny += dL_dG * (-gdy * co.z - gdx * co.y);
+      a_ca += -0.5f * gdx * dx * dL_dG;
+      a_cb += -gdx * dy * dL_dG;
+      a_cc += -0.5f * gdy * dy * dL_dG;
+      a_op += G * dL_dalpha;
+      a_r += w * cg.x; a_g += w * cg.y; a_b += w * cg.z; a_d += w * cg.w;
+      if (F > 0) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) af[c] += w * gf[c];
+      }
+    }
+    // ---- write this chunk's per-Gaussian sums: one row per pair --------------------------------
+    if (lane_valid && !(a.ablate & 1)) {
+      float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
+      if (F > 0) {
+#pragma unroll
+        for (int q = 0; q < F / 4; ++q) row[q] = make_float4(af[4 * q], af[4 * q + 1], af[4 * q + 2], af[4 * q + 3]);
+      }
+      row[F / 4 + 0] = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
+      row[F / 4 + 1] = make_float4(a_cc, a_op, a_r, a_g);
+      row[F / 4 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
+      row[F / 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    wave_lds_sync2();   // carries written by lane 63 are read by the next chunk
+  }
+}
+
+int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows) {
+  BwdGsArgs a;
+  a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
+  a.feats = in.sh_objs; a.bg = s.bg;
+  a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.rows = rows;
+  a.W = s.image_width; a.H = s.image_height;
+  a.gx8 = (a.W + SUB - 1) / SUB;
+  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  a.ablate = (c.variant >> 4) & 0xf;
+  const int blocks = (a.ntiles + GWPB - 1) / GWPB;
+  {
+    ProfScope ps("render_bwd", c.stream);
+    switch (in.F) {
+      case 0: hipLaunchKernelGGL(render_bwd_gs_kernel<0>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
+      case 16: hipLaunchKernelGGL(render_bwd_gs_kernel<16>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
+      case 32: hipLaunchKernelGGL(render_bwd_gs_kernel<32>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
+      default: set_error("render_bwd: feature width %d not compiled in (0,16,32)", in.F); return TRASE_ERR_UNSUPPORTED;
+    }
+  }
+  TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+}  // namespace trase

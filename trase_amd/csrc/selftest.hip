@@ -23,6 +23,17 @@ __global__ void selftest_wave_kernel(float* outf, unsigned long long* outu) {
   if (lane == 0) outf[2] = pc;
   float li = wave_sum_all((float)lane_id());
   if (lane == 0) outf[3] = li;
+  // scans: inclusive add of 1..64 -> lane l holds (l+1)(l+2)/2; inclusive mul of 2 on even lanes (1 on odd)
+  const float sa = wave_scan_add(v);
+  float bad = (sa == 0.5f * (float)((lane + 1) * (lane + 2))) ? 0.f : 1.f;
+  const float sm = wave_scan_mul((lane & 1u) ? 1.0f : 1.03125f);
+  float want = 1.0f;
+  for (unsigned k = 0; k <= lane; k += 2) want *= 1.03125f;
+  bad += (fabsf(sm - want) <= 1e-5f * want) ? 0.f : 1.f;
+  const float sh = wave_shr1(v, -7.0f);
+  bad += (sh == (lane == 0 ? -7.0f : (float)lane)) ? 0.f : 1.f;
+  bad = wave_sum_all(bad);
+  if (lane == 0) outf[4] = bad;
 }
 
 // MFMA f32 32x32x2 layout probe: A[i][k] = i + 100k, B[k][j] = (j+1) * (k ? 0.5 : 1)
@@ -82,6 +93,7 @@ extern "C" int trase_selftest(int32_t device, trase_stream_t stream_, char* msg,
   expect("ballot odd lanes", (double)(hu[0] == 0xAAAAAAAAAAAAAAAAull), 1.0);
   expect("lanemask_lt popcount sum", hf[2], 2016.0);
   expect("lane_id sum", hf[3], 2016.0);
+  expect("wave scans (add, mul, shr1) bad lanes", hf[4], 0.0);
   int mfma_bad = 0;
   for (int i = 0; i < 32; ++i)
     for (int j = 0; j < 32; ++j) {

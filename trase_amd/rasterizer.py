@@ -168,7 +168,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if _Policy.sync:
             st = (C.c_int64 * 3)()
             _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
-            capacity = max(int(st[0]), 1)
+            capacity = max(int(st[2]), 1)      # pairs after exact sub-tile culling
         else:
             capacity = max(int(_Policy.capacity), 1)
         _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
@@ -187,14 +187,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         ctx.save_for_backward(means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
-                              cov3Ds_precomp, radii, geom, binb, img)
+                              cov3Ds_precomp, radii, geom, binb, img, pre)
         return image, radii, feats, depth
 
     @staticmethod
     def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
         lib = _lib.load()
         (means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-         radii, geom, binb, img) = ctx.saved_tensors
+         radii, geom, binb, img, pre) = ctx.saved_tensors
         P, M, F, H, W = ctx.dims
         device = means3D.device
         keep: list = []
@@ -215,6 +215,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
         ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
+        ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
         ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
         ws.capacity = ctx.capacity
 
