@@ -118,11 +118,8 @@ def main():
     names = ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity", "gaussian_features")
     params = [getattr(scene, k).requires_grad_(True) for k in names]
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
-    flat = torch.zeros(sum(p.numel() for p in params), device=device)
-    off = 0
-    for p in params:
-        p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
+    from trase_amd.dp import FlatGradBucket
+    bucket = FlatGradBucket(params)
 
     n_views = 16
     cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
@@ -132,7 +129,7 @@ def main():
     g_feat = torch.randn(F, H, W, generator=g).to(device) / P
 
     def step(i):
-        flat.zero_()
+        bucket.zero()
         st = settings[i % n_views]
         xyz, f_dc, f_rest, scaling, rotation, opacity, gfeat = params
         means2D = torch.zeros_like(xyz, requires_grad=True)            # gaussian_renderer/__init__.py:48
@@ -145,8 +142,7 @@ def main():
             means3D=xyz, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=None, opacities=opac,
             scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward([img, feats], [g_img, g_feat])
-        if world > 1:
-            dist.all_reduce(flat)
+        bucket.allreduce()
         return radii
 
     def log(msg):

@@ -1,0 +1,46 @@
+"""N>1 path on CPU: two gloo ranks produce different per-view gradients; the flat bucket's single
+all-reduce must equal the sum of the single-view gradients (parity definition of SURVEY.md 8e)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket, allreduce_densify_stats
+    torch.manual_seed(0)                      # identical replicas
+    params = [torch.randn(50, 3, requires_grad=True), torch.randn(50, 1, 32, requires_grad=True), torch.randn(50, 4, requires_grad=True)]
+    bucket = FlatGradBucket(params)
+    bucket.zero()
+    view_scale = float(rank + 1)              # "a different view per rank"
+    loss = sum((p * p).sum() * view_scale for p in params)
+    loss.backward()
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in params), ".grad must stay a view of the bucket"
+    bucket.allreduce()
+    want = [2 * p.detach() * sum(range(1, world + 1)) for p in params]
+    ok = all(torch.allclose(p.grad, w) for p, w in zip(params, want))
+    acc, den, rad = torch.full((5, 1), float(rank)), torch.ones(5, 1), torch.arange(5.0) * (rank + 1)
+    allreduce_densify_stats(acc, den, rad)
+    ok = ok and torch.equal(acc, torch.full((5, 1), float(sum(range(world))))) and torch.equal(den, torch.full((5, 1), float(world)))
+    ok = ok and torch.equal(rad, torch.arange(5.0) * world)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_equals_sum_of_view_grads():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
