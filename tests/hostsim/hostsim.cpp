@@ -27,8 +27,10 @@ void hs_forward(const HsView* hv, int n, const float* p, const float* scale, con
     Splat o;
     float shl[48];
     if (sh) for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * ncoef(v.deg)) ? sh[48 * i + k] : 0.f;
-    bool vis = splat_forward(v, p + 3 * i, scale ? scale + 3 * i : nullptr, quat ? quat + 4 * i : nullptr,
-                             cov ? cov + 6 * i : nullptr, sh ? shl : nullptr, color ? color + 3 * i : nullptr, o);
+    const float* sc = scale ? scale + 3 * i : nullptr; const float* qq = quat ? quat + 4 * i : nullptr;
+    const float* cv = cov ? cov + 6 * i : nullptr; const float* cl = color ? color + 3 * i : nullptr;
+    bool vis = cov ? (sh ? splat_forward<true, true>(v, p + 3 * i, sc, qq, cv, shl, cl, o) : splat_forward<true, false>(v, p + 3 * i, sc, qq, cv, shl, cl, o))
+                   : (sh ? splat_forward<false, true>(v, p + 3 * i, sc, qq, cv, shl, cl, o) : splat_forward<false, false>(v, p + 3 * i, sc, qq, cv, shl, cl, o));
     float* r = out + 15 * i;
     for (int k = 0; k < 15; ++k) r[k] = 0.f;
     if (!vis) continue;
@@ -51,8 +53,12 @@ void hs_backward(const HsView* hv, int n, const float* p, const float* scale, co
     float shl[48], dsh[48];
     for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
     if (sh) for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * ncoef(v.deg)) ? sh[48 * i + k] : 0.f;
-    splat_backward(v, p + 3 * i, scale ? scale + 3 * i : nullptr, quat ? quat + 4 * i : nullptr,
-                   cov ? cov + 6 * i : nullptr, sh ? shl : nullptr, (unsigned)clamped[i], gi, go, sh ? dsh : nullptr);
+    const float* sc = scale ? scale + 3 * i : nullptr; const float* qq = quat ? quat + 4 * i : nullptr;
+    const float* cv = cov ? cov + 6 * i : nullptr;
+    if (cov) { if (sh) splat_backward<true, true>(v, p + 3 * i, sc, qq, cv, shl, (unsigned)clamped[i], gi, go, dsh);
+               else splat_backward<true, false>(v, p + 3 * i, sc, qq, cv, shl, (unsigned)clamped[i], gi, go, dsh); }
+    else { if (sh) splat_backward<false, true>(v, p + 3 * i, sc, qq, cv, shl, (unsigned)clamped[i], gi, go, dsh);
+           else splat_backward<false, false>(v, p + 3 * i, sc, qq, cv, shl, (unsigned)clamped[i], gi, go, dsh); }
     float* r = gout + 16 * i;
     for (int k = 0; k < 3; ++k) r[k] = go.d_p[k];
     for (int k = 0; k < 3; ++k) r[3 + k] = go.d_scale[k];

@@ -235,11 +235,13 @@ TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float 
 // Forward of one Gaussian.  `sh` points at 48 floats: this Gaussian's (16,3) coefficients,
 // zero-padded beyond the active degree, or is null when `color` (precomputed rgb) is given.  `cov_in` null => from scale/rot.
 // Returns false (radius 0) when culled.
+// USE_COV / USE_SH are compile-time so that the small per-Gaussian arrays stay in registers.
+template <bool USE_COV, bool USE_SH>
 TRASE_HD bool splat_forward(const View& v, const float p[3], const float* scale, const float* quat,
                             const float* cov_in, const float* sh, const float* color, Splat& o) {
   o.radius = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0; o.clamped = 0;
   float cov[6];
-  if (cov_in) { for (int i = 0; i < 6; ++i) cov[i] = cov_in[i]; }
+  if (USE_COV) { for (int i = 0; i < 6; ++i) cov[i] = cov_in[i]; }
   else cov3d_from_scale_rot(scale, v.mod, quat, cov);
   Ewa e;
   ewa_forward(v, p, cov, e);
@@ -264,7 +266,7 @@ TRASE_HD bool splat_forward(const View& v, const float p[3], const float* scale,
   tile_rect(o.px, o.py, radius, v.gx, v.gy, o.x0, o.y0, o.x1, o.y1);
   if ((o.x1 - o.x0) * (o.y1 - o.y0) == 0) { o.x0 = o.y0 = o.x1 = o.y1 = 0; return false; }
   o.depth = e.t[2];
-  if (color) {
+  if (!USE_SH) {
     o.rgb[0] = color[0]; o.rgb[1] = color[1]; o.rgb[2] = color[2];
   } else {
     float d[3], il, b[16];
@@ -298,11 +300,12 @@ struct SplatGradOut {
 
 // Backward of splat_forward for a *visible* Gaussian.  d_sh receives 48 floats ((16,3), zero
 // beyond the active degree); `sh` as in splat_forward; `clamped` from forward.
+template <bool USE_COV, bool USE_SH>
 TRASE_HD void splat_backward(const View& v, const float p[3], const float* scale, const float* quat,
                              const float* cov_in, const float* sh, unsigned clamped,
-                             const SplatGradIn& gi, SplatGradOut& go, float* d_sh /* may be null */) {
+                             const SplatGradIn& gi, SplatGradOut& go, float* d_sh /* 48 floats when USE_SH */) {
   float cov[6];
-  if (cov_in) { for (int i = 0; i < 6; ++i) cov[i] = cov_in[i]; }
+  if (USE_COV) { for (int i = 0; i < 6; ++i) cov[i] = cov_in[i]; }
   else cov3d_from_scale_rot(scale, v.mod, quat, cov);
   Ewa e;
   ewa_forward(v, p, cov, e);
@@ -353,7 +356,7 @@ TRASE_HD void splat_backward(const View& v, const float p[3], const float* scale
   for (int k = 0; k < 3; ++k)
     go.d_p[k] += (PM[4 * k + 0] * pw - PM[4 * k + 3] * m1) * gi.d_ndcx + (PM[4 * k + 1] * pw - PM[4 * k + 3] * m2) * gi.d_ndcy;
   // colour -> SH coefficients and view direction
-  if (sh) {
+  if (USE_SH) {
     float dr[3];
     for (int ch = 0; ch < 3; ++ch) dr[ch] = ((clamped >> ch) & 1u) ? 0.f : gi.d_rgb[ch];
     float d[3], il, bb[16], gx[16], gy[16], gz[16];
@@ -364,7 +367,7 @@ TRASE_HD void splat_backward(const View& v, const float p[3], const float* scale
     TRASE_UNROLL
     for (int k = 0; k < 16; ++k) {
       const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
-      if (d_sh) { d_sh[3 * k] = bb[k] * dr[0]; d_sh[3 * k + 1] = bb[k] * dr[1]; d_sh[3 * k + 2] = bb[k] * dr[2]; }
+      d_sh[3 * k] = bb[k] * dr[0]; d_sh[3 * k + 1] = bb[k] * dr[1]; d_sh[3 * k + 2] = bb[k] * dr[2];
       const float w = s0 * dr[0] + s1 * dr[1] + s2 * dr[2];
       dd[0] += gx[k] * w; dd[1] += gy[k] * w; dd[2] += gz[k] * w;
     }
@@ -375,7 +378,7 @@ TRASE_HD void splat_backward(const View& v, const float p[3], const float* scale
   for (int i = 0; i < 6; ++i) go.d_cov[i] = dS[i];
   for (int k = 0; k < 3; ++k) go.d_scale[k] = 0.f;
   for (int k = 0; k < 4; ++k) go.d_quat[k] = 0.f;
-  if (!cov_in) {
+  if (!USE_COV) {
     float R[9];
     quat_to_rot(quat, R);
     const float sm[3] = {v.mod * scale[0], v.mod * scale[1], v.mod * scale[2]};

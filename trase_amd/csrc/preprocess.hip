@@ -29,6 +29,7 @@ __device__ __forceinline__ void fill_view(const PreArgs& a, View& v) {
   v.deg = a.deg;
 }
 
+template <bool USE_COV, bool USE_SH>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t* __restrict__ radii,
                                                              float2* __restrict__ xy, float4* __restrict__ conic_o,
                                                              float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
@@ -43,33 +44,40 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   View v;
   fill_view(a, v);
   const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
-  float sc[3], q[4], cv[6];
-  const float* cov_in = nullptr;
-  if (a.cov3d) {
+  float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (USE_COV) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) cv[k] = a.cov3d[6 * i + k];
-    cov_in = cv;
   } else {
     sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
     const float4 qq = reinterpret_cast<const float4*>(a.rots)[i];
     q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
   }
   float shl[48];
-  const float* sh = nullptr;
-  float col[3];
-  const float* color = nullptr;
-  if (a.shs) {
-    const int n = ncoef(a.deg);
+  float col[3] = {0.f, 0.f, 0.f};
+  if (USE_SH) {
+    const int n3 = 3 * ncoef(a.deg);
     const float* src = a.shs + (size_t)i * a.M * 3;
+    if (a.M == 16) {            // full rows: 12 aligned 16-byte loads
+      const float4* s4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
-    for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * n) ? src[k] : 0.f;
-    sh = shl;
+      for (int k = 0; k < 12; ++k) {
+        const float4 t = s4[k];
+        shl[4 * k] = t.x; shl[4 * k + 1] = t.y; shl[4 * k + 2] = t.z; shl[4 * k + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 48; ++k) shl[k] = (k < n3) ? shl[k] : 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 48; ++k) shl[k] = (k < n3) ? src[k] : 0.f;
+    }
   } else {
+#pragma unroll
+    for (int k = 0; k < 48; ++k) shl[k] = 0.f;
     col[0] = a.colors[3 * i]; col[1] = a.colors[3 * i + 1]; col[2] = a.colors[3 * i + 2];
-    color = col;
   }
   Splat o;
-  const bool vis = splat_forward(v, p, sc, q, cov_in, sh, color, o) && active;
+  const bool vis = splat_forward<USE_COV, USE_SH>(v, p, sc, q, cv, shl, col, o) && active;
   if (active) radii[i] = vis ? o.radius : 0;
   // lineage pair count R (tiles of the 16x16 rect) -> one atomic per wave
   const float rect_area = vis ? (float)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0.f;
@@ -100,18 +108,26 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   }
 }
 
-int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
-                          const GeomBuf& g, uint32_t* depth_keys) {
-  PreArgs a;
+static void fill_pre_args(PreArgs& a, const TraseRastSettings& s, const TraseRastInputs& in) {
   a.means3D = in.means3D; a.shs = in.shs; a.colors = in.colors_precomp; a.opac = in.opacities;
   a.scales = in.scales; a.rots = in.rotations; a.cov3d = in.cov3D_precomp;
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = in.P; a.M = in.M; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+}
+
+int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
+                          const GeomBuf& g, uint32_t* depth_keys) {
+  PreArgs a;
+  fill_pre_args(a, s, in);
+  const dim3 grid((in.P + 255) / 256), block(256);
+  const bool cov = in.cov3D_precomp != nullptr, sh = in.shs != nullptr;
   {
     ProfScope ps("preprocess_fwd", c.stream);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((in.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.xy,
-                       g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr);
+#define TRASE_PRE_FWD(C, S) hipLaunchKernelGGL((preprocess_fwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr)
+    if (cov) { if (sh) TRASE_PRE_FWD(true, true); else TRASE_PRE_FWD(true, false); }
+    else { if (sh) TRASE_PRE_FWD(false, true); else TRASE_PRE_FWD(false, false); }
+#undef TRASE_PRE_FWD
   }
   TRASE_POST_LAUNCH("preprocess_fwd", c.stream, c.debug);
   return TRASE_OK;
@@ -123,6 +139,7 @@ struct PreBwdOut {
   float* d_rots; float* d_cov3d;
 };
 
+template <bool USE_COV, bool USE_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreArgs a, const int32_t* __restrict__ radii,
                                                              const uint32_t* __restrict__ clamped,
                                                              const float* __restrict__ acc, PreBwdOut o) {
@@ -144,73 +161,90 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreArgs a, const in
 #pragma unroll
   for (int k = 0; k < 6; ++k) go.d_cov[k] = 0.f;
   if (vis) {
-    const float* r = acc + (size_t)i * BWD_ACC;
-    gi.d_ndcx = r[ACC_NDCX]; gi.d_ndcy = r[ACC_NDCY];
-    gi.d_ca = r[ACC_CA]; gi.d_cb = r[ACC_CB]; gi.d_cc = r[ACC_CC];
-    d_op = r[ACC_OP];
-    gi.d_rgb[0] = r[ACC_R]; gi.d_rgb[1] = r[ACC_G]; gi.d_rgb[2] = r[ACC_B];
-    gi.d_depth = r[ACC_D];
+    const float4* r4 = reinterpret_cast<const float4*>(acc + (size_t)i * BWD_ACC);
+    const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+    gi.d_ndcx = r0.x; gi.d_ndcy = r0.y; gi.d_ca = r0.z; gi.d_cb = r0.w;
+    gi.d_cc = r1.x; d_op = r1.y; gi.d_rgb[0] = r1.z; gi.d_rgb[1] = r1.w;
+    gi.d_rgb[2] = r2.x; gi.d_depth = r2.y;
     View v;
     fill_view(a, v);
     const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
-    float sc[3], q[4], cv[6];
-    const float* cov_in = nullptr;
-    if (a.cov3d) {
+    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (USE_COV) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) cv[k] = a.cov3d[6 * i + k];
-      cov_in = cv;
     } else {
       sc[0] = a.scales[3 * i]; sc[1] = a.scales[3 * i + 1]; sc[2] = a.scales[3 * i + 2];
       const float4 qq = reinterpret_cast<const float4*>(a.rots)[i];
       q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
     }
     float shl[48];
-    const float* sh = nullptr;
-    if (a.shs) {
-      const int n = ncoef(a.deg);
+    if (USE_SH) {
+      const int n3 = 3 * ncoef(a.deg);
       const float* src = a.shs + (size_t)i * a.M * 3;
+      if (a.M == 16) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
-      for (int k = 0; k < 48; ++k) shl[k] = (k < 3 * n) ? src[k] : 0.f;
-      sh = shl;
+        for (int k = 0; k < 12; ++k) {
+          const float4 t = s4[k];
+          shl[4 * k] = t.x; shl[4 * k + 1] = t.y; shl[4 * k + 2] = t.z; shl[4 * k + 3] = t.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 48; ++k) shl[k] = (k < n3) ? shl[k] : 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 48; ++k) shl[k] = (k < n3) ? src[k] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 48; ++k) shl[k] = 0.f;
     }
-    splat_backward(v, p, sc, q, cov_in, sh, a.shs ? clamped[i] : 0u, gi, go, a.shs ? dsh : nullptr);
+    splat_backward<USE_COV, USE_SH>(v, p, sc, q, cv, shl, USE_SH ? clamped[i] : 0u, gi, go, dsh);
   }
   if (o.d_means3D) { o.d_means3D[3 * i] = go.d_p[0]; o.d_means3D[3 * i + 1] = go.d_p[1]; o.d_means3D[3 * i + 2] = go.d_p[2]; }
   if (o.d_means2D) { o.d_means2D[3 * i] = gi.d_ndcx; o.d_means2D[3 * i + 1] = gi.d_ndcy; o.d_means2D[3 * i + 2] = 0.f; }
   if (o.d_opac) o.d_opac[i] = d_op;
-  if (o.d_scales) { o.d_scales[3 * i] = go.d_scale[0]; o.d_scales[3 * i + 1] = go.d_scale[1]; o.d_scales[3 * i + 2] = go.d_scale[2]; }
-  if (o.d_rots) reinterpret_cast<float4*>(o.d_rots)[i] = make_float4(go.d_quat[0], go.d_quat[1], go.d_quat[2], go.d_quat[3]);
-  if (o.d_cov3d) {
+  if (!USE_COV) {
+    if (o.d_scales) { o.d_scales[3 * i] = go.d_scale[0]; o.d_scales[3 * i + 1] = go.d_scale[1]; o.d_scales[3 * i + 2] = go.d_scale[2]; }
+    if (o.d_rots) reinterpret_cast<float4*>(o.d_rots)[i] = make_float4(go.d_quat[0], go.d_quat[1], go.d_quat[2], go.d_quat[3]);
+  } else if (o.d_cov3d) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) o.d_cov3d[6 * i + k] = go.d_cov[k];
   }
-  if (o.d_colors) { o.d_colors[3 * i] = gi.d_rgb[0]; o.d_colors[3 * i + 1] = gi.d_rgb[1]; o.d_colors[3 * i + 2] = gi.d_rgb[2]; }
-  if (o.d_shs) {
+  if (!USE_SH) {
+    if (o.d_colors) { o.d_colors[3 * i] = gi.d_rgb[0]; o.d_colors[3 * i + 1] = gi.d_rgb[1]; o.d_colors[3 * i + 2] = gi.d_rgb[2]; }
+  } else if (o.d_shs) {
     float* dst = o.d_shs + (size_t)i * a.M * 3;
-    const int m3 = a.M * 3;
+    if (a.M == 16) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
-    for (int k = 0; k < 48; ++k)
-      if (k < m3) dst[k] = dsh[k];
+      for (int k = 0; k < 12; ++k) d4[k] = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+    } else {
+      const int m3 = a.M * 3;
+#pragma unroll
+      for (int k = 0; k < 48; ++k)
+        if (k < m3) dst[k] = dsh[k];
+    }
   }
 }
 
 int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
                           const GeomBuf& g, const float* acc, const TraseRastGrads& gr) {
   PreArgs a;
-  a.means3D = in.means3D; a.shs = in.shs; a.colors = in.colors_precomp; a.opac = in.opacities;
-  a.scales = in.scales; a.rots = in.rotations; a.cov3d = in.cov3D_precomp;
-  a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
-  a.P = in.P; a.M = in.M; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
-  a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  fill_pre_args(a, s, in);
   PreBwdOut o;
   o.d_means3D = gr.dL_dmeans3D; o.d_means2D = gr.dL_dmeans2D; o.d_shs = in.shs ? gr.dL_dshs : nullptr;
   o.d_colors = in.colors_precomp ? gr.dL_dcolors : nullptr; o.d_opac = gr.dL_dopacities;
   o.d_scales = in.cov3D_precomp ? nullptr : gr.dL_dscales; o.d_rots = in.cov3D_precomp ? nullptr : gr.dL_drotations;
   o.d_cov3d = in.cov3D_precomp ? gr.dL_dcov3D : nullptr;
+  const dim3 grid((in.P + 255) / 256), block(256);
+  const bool cov = in.cov3D_precomp != nullptr, sh = in.shs != nullptr;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((in.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped,
-                       acc, o);
+#define TRASE_PRE_BWD(C, S) hipLaunchKernelGGL((preprocess_bwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.clamped, acc, o)
+    if (cov) { if (sh) TRASE_PRE_BWD(true, true); else TRASE_PRE_BWD(true, false); }
+    else { if (sh) TRASE_PRE_BWD(false, true); else TRASE_PRE_BWD(false, false); }
+#undef TRASE_PRE_BWD
   }
   TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
   return TRASE_OK;
