@@ -118,8 +118,9 @@ def main():
     names = ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity", "gaussian_features")
     params = [getattr(scene, k).requires_grad_(True) for k in names]
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
+    # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
-    bucket = FlatGradBucket(params)
+    bucket = FlatGradBucket(params) if world > 1 else None
 
     n_views = 16
     cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
@@ -129,7 +130,11 @@ def main():
     g_feat = torch.randn(F, H, W, generator=g).to(device) / P
 
     def step(i):
-        bucket.zero()
+        if bucket is not None:
+            bucket.zero()
+        else:
+            for p_ in params:
+                p_.grad = None
         st = settings[i % n_views]
         xyz, f_dc, f_rest, scaling, rotation, opacity, gfeat = params
         means2D = torch.zeros_like(xyz, requires_grad=True)            # gaussian_renderer/__init__.py:48
@@ -142,7 +147,8 @@ def main():
             means3D=xyz, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=None, opacities=opac,
             scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward([img, feats], [g_img, g_feat])
-        bucket.allreduce()
+        if bucket is not None:
+            bucket.allreduce()
         return radii
 
     def log(msg):

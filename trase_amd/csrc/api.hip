@@ -131,7 +131,7 @@ PairBuf carve_tmp(void* ptr, int64_t cap) {
   return t;
 }
 size_t bwd_tmp_bytes(int P, int F, int64_t cap) {
-  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up(sizeof(float) * bwd_row_floats(F) * (size_t)cap);
+  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up((size_t)cap) + align_up(sizeof(float) * bwd_row_floats(F) * (size_t)cap);
 }
 
 static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
@@ -301,7 +301,8 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
   PreBuf pre = carve_pre(ws->pre, in->P);
   float* acc = (float*)ws->tmp;
-  float* rows = (float*)((char*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in->P));
+  uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in->P);
+  float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
   if (in->P == 0) return TRASE_OK;
   TraseRastGrads g2 = *gr;
   if (!(s->variant & 0x100)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
@@ -323,9 +324,10 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   } else {
     // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
     // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
-    rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows);
+    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+    rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags);
     if (rc) return rc;
-    rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, acc, g2.dL_dsh_objs);
+    rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
     if (rc) return rc;
   }
   return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ tiles, int P,
                                                           const uint32_t* __restrict__ hdr,
-                                                          const float* __restrict__ rows, float* __restrict__ acc,
+                                                          const float* __restrict__ rows,
+                                                          const uint8_t* __restrict__ flags, float* __restrict__ acc,
                                                           float* __restrict__ d_feats) {
   constexpr int F = ROW - 16;
   const int r = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
@@ -384,14 +385,30 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
   const uint32_t cap = hdr[HDR_WORDS - 2];          // capacity the lists were built with
   if (k1 > cap) k1 = cap;                           // pairs dropped by an overflow have no row
   if (k0 > k1) k0 = k1;
+  // rows exist only for pairs that were blended somewhere (flag == 1): fetch 64 flags at a time,
+  // ballot them into a mask and walk its set bits (wave-uniform), four row loads in flight
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (lane < ROW) {
-    const float* p = rows + (size_t)k0 * ROW + lane;
-    uint32_t k = k0;
-    for (; k + 4 <= k1; k += 4, p += 4 * ROW) {
-      s0 += p[0]; s1 += p[ROW]; s2 += p[2 * ROW]; s3 += p[3 * ROW];
+  const bool col = lane < ROW;
+  for (uint32_t kb = k0; kb < k1; kb += WAVE) {
+    const uint32_t kk = kb + lane;
+    unsigned long long m = __ballot(kk < k1 && flags[kk] != 0);
+    const float* base = rows + (size_t)kb * ROW + lane;
+    while (m) {
+      const int b0 = __builtin_ctzll(m); m &= m - 1;
+      int b1 = -1, b2 = -1, b3 = -1;
+      if (m) { b1 = __builtin_ctzll(m); m &= m - 1; }
+      if (m) { b2 = __builtin_ctzll(m); m &= m - 1; }
+      if (m) { b3 = __builtin_ctzll(m); m &= m - 1; }
+      if (col) {
+        const float v0 = base[(size_t)b0 * ROW];
+        const float v1 = (b1 >= 0) ? base[(size_t)b1 * ROW] : 0.f;
+        const float v2 = (b2 >= 0) ? base[(size_t)b2 * ROW] : 0.f;
+        const float v3 = (b3 >= 0) ? base[(size_t)b3 * ROW] : 0.f;
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      }
     }
-    for (; k < k1; ++k, p += ROW) s0 += p[0];
+  }
+  if (col) {
     const float tot = (s0 + s1) + (s2 + s3);
     if (lane < F) {
       if (d_feats) d_feats[(size_t)id * F + lane] = tot;
@@ -401,15 +418,15 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
   }
 }
 
-int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows, float* acc,
-                       float* d_feats) {
+int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
+                       const uint8_t* row_flags, float* acc, float* d_feats) {
   const int blocks = (P + 3) / 4;
   {
     ProfScope ps("reduce_rows", c.stream);
     switch (F) {
-      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
-      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
-      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, acc, d_feats); break;
+      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
+      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
+      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
       default: set_error("reduce_rows: feature width %d not compiled in", F); return TRASE_ERR_UNSUPPORTED;
     }
   }

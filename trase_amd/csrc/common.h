@@ -57,6 +57,64 @@ __device__ __forceinline__ float wave_scan_add(float v) {
   v += dpp_fill<0x143, 0xc>(v, 0.0f);
   return v;
 }
+// Single-instruction scan steps (the builtin form costs a v_mov_dpp + the arithmetic op per step).
+// A lane whose DPP source is out of range, or whose row is masked off, is simply not written, which
+// is the identity for both scans.  s_nop 1 = the 2 wait states a DPP read needs after a VALU write.
+__device__ __forceinline__ float wave_scan_mul_asm(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float wave_scan_add_asm(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
+// ---- per-(sub-tile, Gaussian) blend exponent --------------------------------------------------
+// alpha_raw = opacity * exp(power) is evaluated as exp2(e) with
+//   e(j,i) = log2(e) * power + log2(opacity),   (j,i) = pixel coordinates inside the 8x8 sub-tile,
+// expanded once per pair into a polynomial in (j,i) around the sub-tile origin.  Forward and
+// backward evaluate the SAME expression tree (explicit fmaf), so their gate decisions agree bit
+// for bit:   power <= 0  <=>  e <= thr (= log2 opacity);   alpha >= 1/255  <=>  e >= LOG2_ALPHA_MIN.
+constexpr float LOG2_ALPHA_MIN = -7.994353436858858f;   // log2(1/255)
+struct PairPoly { float k0, kj, ki, kjj, kii, kij, thr; };
+
+__device__ __forceinline__ PairPoly pair_poly(float2 gxy, float4 co, float bx, float by) {
+  constexpr float L = 1.4426950408889634f;
+  const float rx = gxy.x - bx, ry = gxy.y - by;
+  const float A = co.x, B = co.y, C = co.z;
+  PairPoly k;
+  k.thr = __log2f(co.w);
+  k.k0 = fmaf(L, fmaf(-0.5f, fmaf(A * rx, rx, C * ry * ry), -(B * rx) * ry), k.thr);
+  k.kj = L * fmaf(A, rx, B * ry);
+  k.ki = L * fmaf(C, ry, B * rx);
+  k.kjj = -0.5f * L * A;
+  k.kii = -0.5f * L * C;
+  k.kij = -L * B;
+  return k;
+}
+// row part (pixel row i) and full exponent (pixel column j)
+__device__ __forceinline__ float poly_row_base(const PairPoly& k, float i, float ii) { return fmaf(ii, k.kii, fmaf(i, k.ki, k.k0)); }
+__device__ __forceinline__ float poly_row_slope(const PairPoly& k, float i) { return fmaf(i, k.kij, k.kj); }
+__device__ __forceinline__ float poly_eval(const PairPoly& k, float base, float slope, float j, float jj) {
+  return fmaf(jj, k.kjj, fmaf(j, slope, base));
+}
+
 // value of lane-1 (lane 0 receives `ident`): DPP wave_shr:1
 __device__ __forceinline__ float wave_shr1(float v, float ident) { return dpp_fill<0x138>(v, ident); }
 
@@ -188,14 +246,14 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap);
 int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
                       uint32_t cap, uint32_t* point_list);
-int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows, float* acc,
-                       float* d_feats);
+int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
+                       const uint8_t* row_flags, float* acc, float* d_feats);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im);
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows);
+                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

@@ -28,8 +28,9 @@ struct BwdGsArgs {
   const float* final_T; const uint32_t* n_contrib;
   const uint32_t* pair_slot;   // emit-order slot of every list entry
   float* rows;         // (capacity, F+16) one gradient row per pair, indexed by slot
+  uint8_t* row_flags;  // (capacity) 1 where a row was written (zeroed by the caller beforehand)
   int W, H, gx8, ntiles;
-  int ablate;          // debug: bit0 skip the atomic flush, bit1 skip the feature channels' work
+  int ablate;          // debug/A-B (variant bits 4..7): bit0 skip the row writes, bit1 builtin instead of asm DPP scans
 };
 
 __device__ __forceinline__ void wave_lds_sync2() {
@@ -38,7 +39,7 @@ __device__ __forceinline__ void wave_lds_sync2() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int F>
+template <int F, bool ASM>
 __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) {
   constexpr int CH = 4 + F;                      // r g b depth | features
   __shared__ __attribute__((aligned(16))) float s_cot[GWPB][WAVE][CH];   // pixel-major cotangents
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
   const float ddx = 0.5f * (float)a.W, ddy = 0.5f * (float)a.H;
   const float bx = (float)(tx * SUB), by = (float)(ty * SUB);
   // ---- chunks of 64 list entries, back to front ----------------------------------------------------
-  // (every list entry gets its row written exactly once; entries behind the last blended one get zeros)
-  const uint32_t len = range.y - range.x;
-  for (uint32_t c1 = len; c1 > 0; c1 = (c1 > WAVE) ? c1 - WAVE : 0) {
+  // Entries behind the last one any pixel of this sub-tile blended are never touched: they get no
+  // row (their flag stays 0).  Chunks are aligned to that last blended entry.
+  for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > WAVE) ? c1 - WAVE : 0) {
     const uint32_t c0 = (c1 > WAVE) ? c1 - WAVE : 0;
     const uint32_t n = c1 - c0;
     const bool lane_valid = (uint32_t)lane < n;
@@ -99,14 +100,6 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     const uint32_t id = a.point_list[range.x + pos];
     const uint32_t slot = a.pair_slot[range.x + pos];
     constexpr int ROW = F + 16;
-    if (c0 >= wave_last) {                         // wave-uniform: nothing of this chunk was ever blended
-      if (lane_valid) {
-        float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
-#pragma unroll
-        for (int q = 0; q < ROW / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      continue;
-    }
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
     const float4 col = a.rgbd[id];
@@ -119,63 +112,79 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
         f[4 * c4] = v.x; f[4 * c4 + 1] = v.y; f[4 * c4 + 2] = v.z; f[4 * c4 + 3] = v.w;
       }
     }
-    float a_nx = 0.f, a_ny = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f;
+    const PairPoly k = pair_poly(gxy, co, bx, by);
+    const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;     // invalid lanes never pass pos < plast
+    // pixel-moment sums of q = alpha_raw * dL/dalpha (geometry gradients are linear in them)
+    float S0 = 0.f, Sj = 0.f, Si = 0.f, Sjj = 0.f, Sij = 0.f, Sii = 0.f;
     float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
     float af[F > 0 ? F : 1];
 #pragma unroll
     for (int c = 0; c < F; ++c) af[c] = 0.f;
-    const float rx = gxy.x - bx, ry = gxy.y - by;     // centre relative to the sub-tile origin
-    for (int p = 0; p < WAVE; ++p) {
-      const float4 pst = s_pix[wave][p];               // uniform read
-      const uint32_t plast = __builtin_amdgcn_readfirstlane(__float_as_uint(pst.z));
-      if (plast <= c0) continue;                       // nothing of this chunk was blended into pixel p
-      const float T_end = pst.x, U_end = pst.y;
-      const float dx = rx - (float)(p & 7), dy = ry - (float)(p >> 3);
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(ALPHA_MAX, co.w * G);
-      const bool ok = lane_valid && pos < plast && power <= 0.0f && alpha >= ALPHA_MIN;
-      const float al = ok ? alpha : 0.0f;
-      const float om = 1.0f - al;
-      const float PP = wave_scan_mul(om);
-      const float T = T_end * __builtin_amdgcn_rcpf(PP);           // transmittance in front of this Gaussian
-      const float w = al * T;
-      // s = <channels, cotangent of pixel p>
-      const float* cot = s_cot[wave][p];
-      const float4 cg = *reinterpret_cast<const float4*>(cot);
-      float s = col.x * cg.x + col.y * cg.y + col.z * cg.z + col.w * cg.w;
-      float gf[F > 0 ? F : 1];
-      if (F > 0) {
+    for (int i = 0; i < SUB; ++i) {
+      const float fi = (float)i, fii = (float)(i * i);
+      const float base = poly_row_base(k, fi, fii);
+      const float slope = poly_row_slope(k, fi);
+      float R0 = 0.f, R1 = 0.f, R2 = 0.f;            // row sums of q, q*j, q*j^2
 #pragma unroll
-        for (int c4 = 0; c4 < F / 4; ++c4) {
-          const float4 v = *reinterpret_cast<const float4*>(cot + 4 + 4 * c4);
-          gf[4 * c4] = v.x; gf[4 * c4 + 1] = v.y; gf[4 * c4 + 2] = v.z; gf[4 * c4 + 3] = v.w;
-          s += f[4 * c4] * v.x + f[4 * c4 + 1] * v.y + f[4 * c4 + 2] * v.z + f[4 * c4 + 3] * v.w;
+      for (int j = 0; j < SUB; ++j) {
+        const int p = i * SUB + j;
+        const float4 pst = s_pix[wave][p];               // uniform read
+        const uint32_t plast = __builtin_amdgcn_readfirstlane(__float_as_uint(pst.z));
+        if (plast <= c0) continue;                       // nothing of this chunk was blended into pixel p
+        const float T_end = pst.x, U_end = pst.y;
+        const float e = poly_eval(k, base, slope, (float)j, (float)(j * j));
+        const float araw = __builtin_amdgcn_exp2f(e);    // opacity * exp(power)
+        const bool ok = (e <= k.thr) && (e >= LOG2_ALPHA_MIN) && (pos_cmp < plast);
+        const float al = ok ? fminf(ALPHA_MAX, araw) : 0.0f;
+        const float om = 1.0f - al;
+        const float PP = ASM ? wave_scan_mul_asm(om) : wave_scan_mul(om);
+        const float T = T_end * __builtin_amdgcn_rcpf(PP);   // transmittance in front of this Gaussian
+        const float w = al * T;
+        // s = <channels, cotangent of pixel p>
+        const float* cot = s_cot[wave][p];
+        const float4 cg = *reinterpret_cast<const float4*>(cot);
+        float s = col.x * cg.x + col.y * cg.y + col.z * cg.z + col.w * cg.w;
+        float gf[F > 0 ? F : 1];
+        if (F > 0) {
+#pragma unroll
+          for (int c4 = 0; c4 < F / 4; ++c4) {
+            const float4 v = *reinterpret_cast<const float4*>(cot + 4 + 4 * c4);
+            gf[4 * c4] = v.x; gf[4 * c4 + 1] = v.y; gf[4 * c4 + 2] = v.z; gf[4 * c4 + 3] = v.w;
+            s += f[4 * c4] * v.x + f[4 * c4 + 1] * v.y + f[4 * c4 + 2] * v.z + f[4 * c4 + 3] * v.w;
+          }
+        }
+        const float ws = w * s;
+        const float incl = ASM ? wave_scan_add_asm(ws) : wave_scan_add(ws);
+        const float U = U_end + (incl - ws);
+        const float dL_dalpha = ok ? (T * s - U * __builtin_amdgcn_rcpf(om)) : 0.0f;
+        // carries for the next (nearer) chunk: lane 63 sees the whole chunk
+        if (lane == WAVE - 1) {
+          s_pix[wave][p].x = T;                          // om == 1 on invalid lanes: T in front of the chunk
+          s_pix[wave][p].y = U_end + incl;
+        }
+        const float q = araw * dL_dalpha;                // == opacity * G * dL/dalpha (straight-through clamp)
+        R0 += q;
+        R1 = fmaf(q, (float)j, R1);
+        R2 = fmaf(q, (float)(j * j), R2);
+        a_r = fmaf(w, cg.x, a_r); a_g = fmaf(w, cg.y, a_g); a_b = fmaf(w, cg.z, a_b); a_d = fmaf(w, cg.w, a_d);
+        if (F > 0) {
+#pragma unroll
+          for (int c = 0; c < F; ++c) af[c] = fmaf(w, gf[c], af[c]);
         }
       }
-      const float ws = w * s;
-      const float incl = wave_scan_add(ws);
-      const float U = U_end + (incl - ws);
-      const float dL_dalpha = ok ? (T * s - U * __builtin_amdgcn_rcpf(om)) : 0.0f;
-      // carries for the next (nearer) chunk: lane 63 sees the whole chunk
-      if (lane == WAVE - 1) {
-        s_pix[wave][p].x = T;                          // om == 1 on invalid lanes, so this is T in front of the chunk
-        s_pix[wave][p].y = U_end + incl;
-      }
-      const float dL_dG = co.w * dL_dalpha;
-      const float gdx = G * dx, gdy = G * dy;
-      a_nx += dL_dG * (-gdx * co.x - gdy * co.y);
-      a_ny += dL_dG * (-gdy * co.z - gdx * co.y);
-      a_ca += -0.5f * gdx * dx * dL_dG;
-      a_cb += -gdx * dy * dL_dG;
-      a_cc += -0.5f * gdy * dy * dL_dG;
-      a_op += G * dL_dalpha;
-      a_r += w * cg.x; a_g += w * cg.y; a_b += w * cg.z; a_d += w * cg.w;
-      if (F > 0) {
-#pragma unroll
-        for (int c = 0; c < F; ++c) af[c] += w * gf[c];
-      }
+      S0 += R0; Sj += R1; Sjj += R2;
+      Si = fmaf(fi, R0, Si); Sii = fmaf(fii, R0, Sii); Sij = fmaf(fi, R1, Sij);
     }
+    // moments about the sub-tile origin -> sums over dx = rx - j, dy = ry - i
+    const float rx = gxy.x - bx, ry = gxy.y - by;
+    const float Qx = rx * S0 - Sj, Qy = ry * S0 - Si;
+    const float Qxx = rx * (rx * S0 - 2.0f * Sj) + Sjj;
+    const float Qyy = ry * (ry * S0 - 2.0f * Si) + Sii;
+    const float Qxy = rx * (ry * S0 - Si) - ry * Sj + Sij;
+    const float a_nx = -(co.x * Qx + co.y * Qy);
+    const float a_ny = -(co.z * Qy + co.y * Qx);
+    const float a_ca = -0.5f * Qxx, a_cb = -Qxy, a_cc = -0.5f * Qyy;
+    const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
     // ---- write this chunk's per-Gaussian sums: one row per pair --------------------------------
     if (lane_valid && !(a.ablate & 1)) {
       float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
@@ -187,18 +196,19 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
       row[F / 4 + 1] = make_float4(a_cc, a_op, a_r, a_g);
       row[F / 4 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
       row[F / 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.row_flags[slot] = 1;
     }
     wave_lds_sync2();   // carries written by lane 63 are read by the next chunk
   }
 }
 
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows) {
+                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags) {
   BwdGsArgs a;
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
   a.feats = in.sh_objs; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
-  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.rows = rows;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.rows = rows; a.row_flags = row_flags;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
@@ -207,9 +217,11 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
   {
     ProfScope ps("render_bwd", c.stream);
     switch (in.F) {
-      case 0: hipLaunchKernelGGL(render_bwd_gs_kernel<0>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
-      case 16: hipLaunchKernelGGL(render_bwd_gs_kernel<16>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
-      case 32: hipLaunchKernelGGL(render_bwd_gs_kernel<32>, dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); break;
+#define TRASE_BWD_GS(FF) do { if (a.ablate & 2) hipLaunchKernelGGL((render_bwd_gs_kernel<FF, false>), dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); \
+                             else hipLaunchKernelGGL((render_bwd_gs_kernel<FF, true>), dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); } while (0)
+      case 0: TRASE_BWD_GS(0); break;
+      case 16: TRASE_BWD_GS(16); break;
+      case 32: TRASE_BWD_GS(32); break;
       default: set_error("render_bwd: feature width %d not compiled in (0,16,32)", in.F); return TRASE_ERR_UNSUPPORTED;
     }
   }

@@ -30,6 +30,10 @@ __global__ void selftest_wave_kernel(float* outf, unsigned long long* outu) {
   float want = 1.0f;
   for (unsigned k = 0; k <= lane; k += 2) want *= 1.03125f;
   bad += (fabsf(sm - want) <= 1e-5f * want) ? 0.f : 1.f;
+  const float sa2 = wave_scan_add_asm(v);
+  bad += (sa2 == sa) ? 0.f : 1.f;
+  const float sm2 = wave_scan_mul_asm((lane & 1u) ? 1.0f : 1.03125f);
+  bad += (sm2 == sm) ? 0.f : 1.f;
   const float sh = wave_shr1(v, -7.0f);
   bad += (sh == (lane == 0 ? -7.0f : (float)lane)) ? 0.f : 1.f;
   bad = wave_sum_all(bad);
@@ -93,7 +97,7 @@ extern "C" int trase_selftest(int32_t device, trase_stream_t stream_, char* msg,
   expect("ballot odd lanes", (double)(hu[0] == 0xAAAAAAAAAAAAAAAAull), 1.0);
   expect("lanemask_lt popcount sum", hf[2], 2016.0);
   expect("lane_id sum", hf[3], 2016.0);
-  expect("wave scans (add, mul, shr1) bad lanes", hf[4], 0.0);
+  expect("wave scans (builtin + asm add/mul, shr1) bad lanes", hf[4], 0.0);
   int mfma_bad = 0;
   for (int i = 0; i < 32; ++i)
     for (int j = 0; j < 32; ++j) {
