@@ -40,57 +40,64 @@ template <int F>
 __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __restrict__ out_img,
                                                         float* __restrict__ out_feat, float* __restrict__ out_depth,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float2 s_xy[WPB][WAVE];
-  __shared__ float4 s_co[WPB][WAVE];
+  // per staged list entry: the blend-exponent polynomial (common.h pair_poly), colour+depth, id
+  __shared__ float4 s_k0[WPB][WAVE];   // k0, kj, ki, kjj
+  __shared__ float4 s_k1[WPB][WAVE];   // kii, kij, thr, id (bits)
   __shared__ float4 s_cd[WPB][WAVE];
-  __shared__ uint32_t s_id[WPB][WAVE];
   int px, py, wave, lane;
   const int tile = subtile_of_wave(a, px, py, wave, lane);
   if (tile >= a.ntiles) return;
   const bool inside = px < a.W && py < a.H;
-  const float pxf = (float)px, pyf = (float)py;
+  const float bx = (float)((tile % a.gx8) * SUB), by = (float)((tile / a.gx8) * SUB);
+  const float fj = (float)(lane & 7), fi = (float)(lane >> 3);
+  const float fjj = fj * fj, fii = fi * fi;
   const uint2 range = a.ranges[tile];
   float T = 1.0f;
-  uint32_t contributor = 0, last = 0;
+  uint32_t last = 0;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
   float fa[F > 0 ? F : 1];
 #pragma unroll
   for (int c = 0; c < F; ++c) fa[c] = 0.f;
-  bool done = !inside;
+  // a finished pixel (outside the image, or transmittance exhausted) is encoded as live == 0
+  float live = inside ? 1.0f : 0.0f;
   for (uint32_t base = range.x; base < range.y; base += WAVE) {
-    if (__all(done)) break;
+    if (!__any(live != 0.0f)) break;
     const uint32_t n = min((uint32_t)WAVE, range.y - base);
     wave_lds_sync();
     if ((uint32_t)lane < n) {
       const uint32_t id = a.point_list[base + lane];
-      s_id[wave][lane] = id;
-      s_xy[wave][lane] = a.xy[id];
-      s_co[wave][lane] = a.conic_o[id];
+      const PairPoly k = pair_poly(a.xy[id], a.conic_o[id], bx, by);
+      s_k0[wave][lane] = make_float4(k.k0, k.kj, k.ki, k.kjj);
+      s_k1[wave][lane] = make_float4(k.kii, k.kij, k.thr, __uint_as_float(id));
       s_cd[wave][lane] = a.rgbd[id];
     }
     wave_lds_sync();
     for (uint32_t j = 0; j < n; ++j) {
-      if (__all(done)) break;
-      ++contributor;
-      const float2 g = s_xy[wave][j];
-      const float4 co = s_co[wave][j];
-      const float dx = g.x - pxf, dy = g.y - pyf;
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      const float alpha = fminf(ALPHA_MAX, co.w * __expf(power));
-      bool ok = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+      const float4 q0 = s_k0[wave][j];
+      const float4 q1 = s_k1[wave][j];
+      PairPoly k;
+      k.k0 = q0.x; k.kj = q0.y; k.ki = q0.z; k.kjj = q0.w; k.kii = q1.x; k.kij = q1.y; k.thr = q1.z;
+      const float e = poly_eval(k, poly_row_base(k, fi, fii), poly_row_slope(k, fi), fj, fjj);
+      const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(e));
+      const bool gate = (live != 0.0f) && (e <= k.thr) && (e >= LOG2_ALPHA_MIN);
       const float test_T = T * (1.0f - alpha);
-      if (ok && test_T < T_STOP) { done = true; ok = false; }
+      const bool stop = gate && (test_T < T_STOP);       // this one is NOT blended and the pixel is finished
+      const bool ok = gate && !stop;
+      live = stop ? 0.0f : live;
       if (__any(ok)) {
         const float w = ok ? alpha * T : 0.0f;
         const float4 col = s_cd[wave][j];
-        c0 += w * col.x; c1 += w * col.y; c2 += w * col.z; cd += w * col.w;
+        c0 = fmaf(w, col.x, c0); c1 = fmaf(w, col.y, c1); c2 = fmaf(w, col.z, c2); cd = fmaf(w, col.w, cd);
         if (F > 0) {
-          const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[wave][j]);
-          const float* __restrict__ f = a.feats + (size_t)id * F;
+          // wave-uniform row: read it through the scalar cache (constant address space => s_load)
+          const uint32_t id = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
+          typedef __attribute__((address_space(4))) const float cfloat;
+          cfloat* f = (cfloat*)(a.feats + (size_t)id * F);
 #pragma unroll
-          for (int c = 0; c < F; ++c) fa[c] += w * f[c];
+          for (int c = 0; c < F; ++c) fa[c] = fmaf(w, f[c], fa[c]);
         }
-        if (ok) { T = test_T; last = contributor; }
+        T = ok ? test_T : T;
+        last = ok ? (base - range.x + j + 1) : last;
       }
     }
   }
