@@ -155,6 +155,13 @@ int trase_knn_sizes(int32_t N, size_t* ws_bytes);
 int trase_knn_dist2(const float* points, int32_t N, float* out, void* ws, size_t ws_bytes, int32_t device,
                     trase_stream_t stream);
 
+/* pytorch3d.ops.knn_points replacement (scene/gaussian_model.py:88-92 K=16 self-KNN for feature
+ * smoothing; render.py:222, gui.py:1048, utils/loss_utils.py:141,192 cross-KNN): for every point of
+ * p1 the K (<= 16) nearest points of p2, ascending; idx int64 (N1,K), squared distances (N1,K).
+ * Workspace: trase_knn_sizes(N2). */
+int trase_knn_points(const float* p1, int32_t N1, const float* p2, int32_t N2, int32_t K, int64_t* idx,
+                     float* dists, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

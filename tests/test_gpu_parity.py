@@ -234,3 +234,47 @@ def test_distcuda2_matches_kdtree():
         want = (d[:, 1:] ** 2).mean(axis=1)
         got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-10)
+
+
+def test_knn_points_matches_kdtree_self_and_cross():
+    """pytorch3d.ops.knn_points stand-in: K=16 self-KNN (scene/gaussian_model.py:88-92) and K=1
+    cross-KNN (render.py:222) against scipy's exact KD-tree."""
+    from scipy.spatial import cKDTree
+    from pytorch3d.ops import knn_points
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-1.3, 1.3, size=(30000, 3)).astype(np.float32)
+    tree = cKDTree(pts.astype(np.float64))
+    t = torch.from_numpy(pts).cuda()
+    out = knn_points(t.unsqueeze(0), t.unsqueeze(0), K=16)
+    assert out.idx.shape == (1, 30000, 16) and out.idx.dtype == torch.int64
+    d, i = tree.query(pts.astype(np.float64), k=16)
+    np.testing.assert_allclose(out.dists[0].cpu().numpy(), d ** 2, rtol=2e-4, atol=1e-9)
+    same = (out.idx[0].cpu().numpy() == i)
+    assert same.mean() > 0.999          # ties between equidistant neighbours may be ordered differently
+    assert (out.idx[0, :, 0].cpu().numpy() == np.arange(30000)).all()   # a point finds itself first
+    # cross-KNN with queries partly outside the cloud's bounding box
+    q = rng.uniform(-2.0, 2.0, size=(5000, 3)).astype(np.float32)
+    out1 = knn_points(torch.from_numpy(q).cuda().unsqueeze(0), t.unsqueeze(0), K=1)
+    d1, i1 = tree.query(q.astype(np.float64), k=1)
+    np.testing.assert_allclose(out1.dists[0, :, 0].cpu().numpy(), d1 ** 2, rtol=2e-4, atol=1e-9)
+    assert (out1.idx[0, :, 0].cpu().numpy() == i1).mean() > 0.999
+
+
+def test_feature_smoothing_path_with_knn_shim():
+    """get_smoothed_gaussian_features (scene/gaussian_model.py:79-104) restated: KNN(16) indices from the
+    shim, gather of L2-normalised features of a neighbour subset, mean -> (N,1,32); gradients flow."""
+    from pytorch3d.ops import knn_points
+    g = torch.Generator().manual_seed(0)
+    n = 4000
+    xyz = (torch.rand(n, 3, generator=g) * 2 - 1).cuda()
+    feats = torch.randn(n, 1, 32, generator=g).cuda().requires_grad_(True)
+    idx = knn_points(xyz.unsqueeze(0), xyz.unsqueeze(0), K=16).idx.squeeze()
+    normed = torch.nn.functional.normalize(feats, dim=-1, p=2)
+    sel = torch.randperm(16, generator=g)[:8].cuda()
+    ret = normed[idx[:, sel], 0, :].mean(dim=1).unsqueeze(1)
+    assert ret.shape == (n, 1, 32)
+    d = torch.cdist(xyz.cpu().double(), xyz.cpu().double())
+    ref_idx = d.topk(16, largest=False).indices
+    assert (ref_idx.sort(dim=1).values == idx.cpu().sort(dim=1).values).float().mean() > 0.999
+    ret.sum().backward()
+    assert torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0

@@ -81,6 +81,8 @@ SYMBOLS = [
                                       C.POINTER(RastWorkspace), C.POINTER(RastGrads), C.c_void_p]),
     ("trase_knn_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     ("trase_knn_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_knn_points", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),

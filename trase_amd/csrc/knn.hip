@@ -168,6 +168,73 @@ __global__ __launch_bounds__(256) void knn_query_kernel(const float* __restrict_
   out[self] = cnt ? sum / 3.0f : 0.f;
 }
 
+// top-KT nearest points of the hashed cloud `pts` for every query point; ascending, squared distance
+template <int KT>
+__global__ __launch_bounds__(256) void knn_points_kernel(const float* __restrict__ qpts, int nq,
+                                                         const float* __restrict__ pts, int n, int K,
+                                                         const KnnParams* pp, uint32_t mask,
+                                                         const uint32_t* __restrict__ sorted_ids,
+                                                         const uint2* __restrict__ buckets,
+                                                         int64_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const KnnParams p = *pp;
+  const float x = qpts[3 * i], y = qpts[3 * i + 1], z = qpts[3 * i + 2];
+  int cx, cy, cz;
+  cell_of(p, x, y, z, cx, cy, cz);
+  // distance from the query to its (clamped) cell: queries outside the cloud's box start farther away
+  float bd[KT];
+  uint32_t bi[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) { bd[k] = 3.0e38f; bi[k] = 0u; }
+  const int rmax = max(p.dims[0], max(p.dims[1], p.dims[2]));
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, p.dims[2] - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, p.dims[1] - 1);
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, p.dims[0] - 1);
+    for (int zz = z0; zz <= z1; ++zz)
+      for (int yy = y0; yy <= y1; ++yy) {
+        const bool face = (abs(zz - cz) == r) || (abs(yy - cy) == r);
+        const int step = face ? 1 : max(1, 2 * r);
+        for (int xx = face ? x0 : cx - r; xx <= (face ? x1 : cx + r); xx += step) {
+          if (xx < 0 || xx >= p.dims[0]) continue;
+          const uint2 bk = buckets[cell_hash(xx, yy, zz, mask)];
+          for (uint32_t k = bk.x; k < bk.y; ++k) {
+            const uint32_t j = sorted_ids[k];
+            const float qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
+            int ox, oy, oz;
+            cell_of(p, qx, qy, qz, ox, oy, oz);
+            if (ox != xx || oy != yy || oz != zz) continue;   // hash collision: belongs to another cell
+            const float dx = qx - x, dy = qy - y, dz = qz - z;
+            float d = dx * dx + dy * dy + dz * dz;
+            uint32_t id = j;
+            if (d < bd[KT - 1] || (d == bd[KT - 1] && id < bi[KT - 1])) {
+              // sorted insertion (ties by index so the result does not depend on the bucket order)
+#pragma unroll
+              for (int t = 0; t < KT; ++t) {
+                const bool lt = d < bd[t] || (d == bd[t] && id < bi[t]);
+                const float td = lt ? bd[t] : d; const uint32_t ti = lt ? bi[t] : id;
+                bd[t] = lt ? d : bd[t]; bi[t] = lt ? id : bi[t];
+                d = td; id = ti;
+              }
+            }
+          }
+        }
+      }
+    const float bound = (float)r * p.h;
+    if (bd[KT - 1] <= bound * bound && r > 0) break;
+    if (KT == 1 && bd[0] == 0.0f) break;
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    if (k < K) {
+      const bool have = bd[k] < 3.0e38f;     // fewer than K points in the cloud: pad like pytorch3d (idx 0, dist 0)
+      idx_out[(size_t)i * K + k] = have ? (int64_t)bi[k] : 0;
+      dist_out[(size_t)i * K + k] = have ? bd[k] : 0.0f;
+    }
+  }
+}
+
 static int knn_bits(int N) {
   int bits = 4;
   while ((1u << bits) < (uint32_t)N && bits < 26) ++bits;
@@ -210,6 +277,22 @@ int trase_knn_sizes(int32_t N, size_t* ws_bytes) {
   return TRASE_OK;
 }
 
+static int knn_build(const LaunchCtx& c, const float* points, int32_t N, KnnWs& w, uint32_t mask, int bits, int* idx_out) {
+  hipStream_t stream = c.stream;
+  const int blocks = (N + 255) / 256;
+  {
+    ProfScope ps("knn_bbox", stream);
+    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(1), 0, stream, w.prm, (uint32_t)N);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, stream, points, N, w.prm);
+    hipLaunchKernelGGL(knn_params_kernel, dim3(1), dim3(1), 0, stream, w.prm);
+    hipLaunchKernelGGL(knn_keys_kernel, dim3(blocks), dim3(256), 0, stream, points, N, w.prm, mask, w.sort.keys[0]);
+  }
+  TRASE_POST_LAUNCH("knn_keys", stream, 0);
+  int rc = radix_sort_pairs(c, w.sort, &w.prm->n, (uint32_t)N, 0, bits, true, idx_out);
+  if (rc) return rc;
+  return launch_tile_ranges(c, w.sort.keys[*idx_out], &w.prm->n, (uint32_t)N, w.buckets, 1 << bits);
+}
+
 int trase_knn_dist2(const float* points, int32_t N, float* out, void* ws, size_t ws_bytes, int32_t device,
                     trase_stream_t stream_) {
   if (N < 0 || (N > 0 && (!points || !out))) { set_error("trase_knn_dist2: bad arguments"); return TRASE_ERR_INVALID; }
@@ -221,26 +304,49 @@ int trase_knn_dist2(const float* points, int32_t N, float* out, void* ws, size_t
   KnnWs w = knn_carve(ws, N);
   const int bits = knn_bits(N);
   const uint32_t mask = (1u << bits) - 1u;
-  const int blocks = (N + 255) / 256;
-  {
-    ProfScope ps("knn_bbox", stream);
-    hipLaunchKernelGGL(knn_init_kernel, dim3(1), dim3(1), 0, stream, w.prm, (uint32_t)N);
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, stream, points, N, w.prm);
-    hipLaunchKernelGGL(knn_params_kernel, dim3(1), dim3(1), 0, stream, w.prm);
-    hipLaunchKernelGGL(knn_keys_kernel, dim3(blocks), dim3(256), 0, stream, points, N, w.prm, mask, w.sort.keys[0]);
-  }
-  TRASE_POST_LAUNCH("knn_keys", stream, 0);
   int idx = 0;
-  int rc = radix_sort_pairs(c, w.sort, &w.prm->n, (uint32_t)N, 0, bits, true, &idx);
-  if (rc) return rc;
-  rc = launch_tile_ranges(c, w.sort.keys[idx], &w.prm->n, (uint32_t)N, w.buckets, 1 << bits);
+  int rc = knn_build(c, points, N, w, mask, bits, &idx);
   if (rc) return rc;
   {
     ProfScope ps("knn_query", stream);
-    hipLaunchKernelGGL(knn_query_kernel, dim3(blocks), dim3(256), 0, stream, points, N, w.prm, mask, w.sort.vals[idx],
+    hipLaunchKernelGGL(knn_query_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, points, N, w.prm, mask, w.sort.vals[idx],
                        w.buckets, out);
   }
   TRASE_POST_LAUNCH("knn_query", stream, 0);
+  return TRASE_OK;
+}
+
+// pytorch3d.ops.knn_points replacement (call sites scene/gaussian_model.py:88-92 K=16 self-KNN,
+// render.py:222 / gui.py:1048 / utils/loss_utils.py:141,192 cross-KNN): the K nearest points of
+// p2 for every point of p1, ascending, squared distances; a query that is itself in p2 finds itself.
+int trase_knn_points(const float* p1, int32_t N1, const float* p2, int32_t N2, int32_t K, int64_t* idx_out,
+                     float* dist_out, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (N1 < 0 || N2 < 0 || K < 1 || K > 16) { set_error("trase_knn_points: need 1 <= K <= 16 (got %d)", K); return TRASE_ERR_INVALID; }
+  if (N1 == 0) return TRASE_OK;
+  if (!p1 || !idx_out || !dist_out || (N2 > 0 && !p2)) { set_error("trase_knn_points: null pointer"); return TRASE_ERR_INVALID; }
+  if (!ws || ws_bytes < knn_ws_bytes(N2)) { set_error("trase_knn_points: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  LaunchCtx c{stream, 0, 0};
+  const int blocks = (N1 + 255) / 256;
+  if (N2 == 0) {   // nothing to find: pytorch3d pads with idx 0 / dist 0 -- keep that convention
+    TRASE_CHECK(hipMemsetAsync(idx_out, 0, sizeof(int64_t) * (size_t)N1 * K, stream));
+    TRASE_CHECK(hipMemsetAsync(dist_out, 0, sizeof(float) * (size_t)N1 * K, stream));
+    return TRASE_OK;
+  }
+  KnnWs w = knn_carve(ws, N2);
+  const int bits = knn_bits(N2);
+  const uint32_t mask = (1u << bits) - 1u;
+  int idx = 0;
+  int rc = knn_build(c, p2, N2, w, mask, bits, &idx);
+  if (rc) return rc;
+  {
+    ProfScope ps("knn_points_query", stream);
+#define TRASE_KQ(KT) hipLaunchKernelGGL((knn_points_kernel<KT>), dim3(blocks), dim3(256), 0, stream, p1, N1, p2, N2, K, w.prm, mask, w.sort.vals[idx], w.buckets, idx_out, dist_out)
+    if (K <= 1) TRASE_KQ(1); else if (K <= 4) TRASE_KQ(4); else if (K <= 8) TRASE_KQ(8); else TRASE_KQ(16);
+#undef TRASE_KQ
+  }
+  TRASE_POST_LAUNCH("knn_points_query", stream, 0);
   return TRASE_OK;
 }
 

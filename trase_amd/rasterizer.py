@@ -305,6 +305,44 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# pytorch3d.ops.knn_points (scene/gaussian_model.py:88-92, render.py:222, utils/loss_utils.py:141,192)
+# --------------------------------------------------------------------------------------
+class _KNN(NamedTuple):
+    dists: torch.Tensor
+    idx: torch.Tensor
+    knn: Optional[torch.Tensor]
+
+
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1=None, lengths2=None, norm: int = 2, K: int = 1,
+               version: int = -1, return_nn: bool = False, return_sorted: bool = True):
+    """Same call contract as pytorch3d.ops.knn_points for the shapes TRASE uses: p1 (B,N1,3),
+    p2 (B,N2,3) -> (dists (B,N1,K) squared L2, idx (B,N1,K) int64, knn).  K <= 16, L2 only, full lengths."""
+    if norm != 2 or lengths1 is not None or lengths2 is not None:
+        raise NotImplementedError("knn_points: only norm=2 with full-length clouds is supported")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != 3 or p2.shape[2] != 3:
+        raise ValueError("knn_points expects p1 (B,N1,3) and p2 (B,N2,3)")
+    if p1.device.type != "cuda":
+        raise RuntimeError("knn_points runs on the GPU only (there is no CPU path)")
+    lib = _lib.load()
+    B, N1, N2 = p1.shape[0], p1.shape[1], p2.shape[1]
+    dev = p1.device
+    dists = torch.empty(B, N1, K, device=dev)
+    idx = torch.empty(B, N1, K, dtype=torch.int64, device=dev)
+    nbytes = C.c_size_t()
+    _lib.check(lib.trase_knn_sizes(N2, C.byref(nbytes)), "trase_knn_sizes")
+    ws = _bytes(nbytes.value, dev)
+    d = dev.index if dev.index is not None else torch.cuda.current_device()
+    for b in range(B):
+        a, q = p1[b].detach().float().contiguous(), p2[b].detach().float().contiguous()
+        _lib.check(lib.trase_knn_points(_lib.ptr(a), N1, _lib.ptr(q), N2, K, _lib.ptr(idx[b]), _lib.ptr(dists[b]),
+                                        _lib.ptr(ws), ws.numel(), d, _stream(dev)), "trase_knn_points")
+    knn = None
+    if return_nn:
+        knn = torch.gather(p2[:, None].expand(B, N1, N2, 3), 2, idx[..., None].expand(B, N1, K, 3))
+    return _KNN(dists=dists, idx=idx, knn=knn)
+
+
+# --------------------------------------------------------------------------------------
 # per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg
 # --------------------------------------------------------------------------------------
 def profile_enable(mode: int):
