@@ -162,6 +162,31 @@ int trase_knn_dist2(const float* points, int32_t N, float* out, void* ws, size_t
 int trase_knn_points(const float* p1, int32_t N1, const float* p2, int32_t N2, int32_t K, int64_t* idx,
                      float* dists, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
 
+/* Deformation MLP (utils/time_utils.py:60-131 DeformNetwork.forward, reached through
+ * scene/deform_model.py:34-35 DeformModel.step at train.py:202-204, render.py:195, gui.py:965).
+ * Weights are the reference's nn.Linear parameters as they are (fp32, [out][in] row-major, device
+ * pointers); they are re-packed to bf16 on every call.  Forward only (no_grad call sites). */
+typedef struct TraseMlpWeights {
+  int32_t D;             /* hidden layers (8) */
+  int32_t W;             /* hidden width (256) */
+  int32_t xyz_multires;  /* 10 -> 63 input channels */
+  int32_t t_multires;    /* 10 -> 21 input channels */
+  int32_t is_blender;    /* must be 0 */
+  int32_t is_6dof;       /* must be 0 */
+  const float* weight[8];/* linear.{i}.weight: (256, 84) / (256, 256) / (256, 340) for the skip layer i = 5 */
+  const float* bias[8];  /* linear.{i}.bias  : (256,) */
+  const float* w_warp;     const float* b_warp;      /* gaussian_warp     (3,256), (3,) */
+  const float* w_rotation; const float* b_rotation;  /* gaussian_rotation (4,256), (4,) */
+  const float* w_scaling;  const float* b_scaling;   /* gaussian_scaling  (3,256), (3,) */
+} TraseMlpWeights;
+
+int trase_mlp_sizes(size_t* ws_bytes);
+/* x (N,3); t: one float per row at stride t_stride floats (0 = the same scalar for every row, as the
+ * reference's expand() produces at train.py:196); outputs d_xyz (N,3), d_rotation (N,4), d_scaling (N,3). */
+int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                      float* d_xyz, float* d_rotation, float* d_scaling, void* ws, size_t ws_bytes, int32_t device,
+                      trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

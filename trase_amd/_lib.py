@@ -67,6 +67,16 @@ class RastGrads(C.Structure):
     ]
 
 
+class MlpWeights(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("W", C.c_int32), ("xyz_multires", C.c_int32), ("t_multires", C.c_int32),
+        ("is_blender", C.c_int32), ("is_6dof", C.c_int32),
+        ("weight", C.c_void_p * 8), ("bias", C.c_void_p * 8),
+        ("w_warp", C.c_void_p), ("b_warp", C.c_void_p), ("w_rotation", C.c_void_p), ("b_rotation", C.c_void_p),
+        ("w_scaling", C.c_void_p), ("b_scaling", C.c_void_p),
+    ]
+
+
 # every symbol include/trase_rast.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("trase_rast_sizes", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(RastSizes)]),
@@ -83,6 +93,9 @@ SYMBOLS = [
     ("trase_knn_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_knn_points", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_mlp_sizes", C.c_int, [C.POINTER(C.c_size_t)]),
+    ("trase_mlp_forward", C.c_int, [C.POINTER(MlpWeights), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),
