@@ -267,9 +267,8 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-    rc = launch_gather_ids(c, b.pair_slot, t.pair_gauss, g.hdr + HDR_R_EFF, cap, b.point_list);
-    if (rc) return rc;
-    rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T);
+    rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T, b.pair_slot, t.pair_gauss,
+                                   b.point_list);
     if (rc) return rc;
   } else {
     TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, stream));

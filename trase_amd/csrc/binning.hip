@@ -435,15 +435,36 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
 }
 
 // ---- tile ranges ---------------------------------------------------------------------------------
+// GATHER: also translate every list entry's emit-order slot into its Gaussian id (one pass over the list)
+template <bool GATHER>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                          uint2* __restrict__ ranges) {
+                                                          uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ pair_slot,
+                                                          const uint32_t* __restrict__ pair_gauss,
+                                                          uint32_t* __restrict__ point_list) {
   const uint32_t n = dev_n(n_ptr, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t t = keys[i];
+    if (GATHER) point_list[i] = pair_gauss[pair_slot[i]];
     if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
     if (i == n - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
   }
+}
+
+int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
+                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list) {
+  TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
+  int blocks = (int)((cap + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  {
+    ProfScope ps("tile_ranges", c.stream);
+    hipLaunchKernelGGL(tile_ranges_kernel<true>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, pair_slot,
+                       pair_gauss, point_list);
+  }
+  TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
+  return TRASE_OK;
 }
 
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T) {
@@ -453,7 +474,8 @@ int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t*
   if (blocks < 1) blocks = 1;
   {
     ProfScope ps("tile_ranges", c.stream);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, nullptr,
+                       nullptr, nullptr);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;

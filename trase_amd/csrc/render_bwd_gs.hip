@@ -20,6 +20,7 @@
 namespace trase {
 
 constexpr int GWPB = 4;   // waves (sub-tiles) per workgroup
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct BwdGsArgs {
   const uint2* ranges; const uint32_t* point_list;
@@ -103,13 +104,13 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
     const float4 col = a.rgbd[id];
-    float f[F > 0 ? F : 1];
+    f32x2 f2[F > 0 ? F / 2 : 1];
     if (F > 0) {
       const float4* fr = reinterpret_cast<const float4*>(a.feats + (size_t)id * F);
 #pragma unroll
       for (int c4 = 0; c4 < F / 4; ++c4) {
         const float4 v = fr[c4];
-        f[4 * c4] = v.x; f[4 * c4 + 1] = v.y; f[4 * c4 + 2] = v.z; f[4 * c4 + 3] = v.w;
+        f2[2 * c4] = f32x2{v.x, v.y}; f2[2 * c4 + 1] = f32x2{v.z, v.w};
       }
     }
     const PairPoly k = pair_poly(gxy, co, bx, by);
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     // pixel-moment sums of q = alpha_raw * dL/dalpha (geometry gradients are linear in them)
     float S0 = 0.f, Sj = 0.f, Si = 0.f, Sjj = 0.f, Sij = 0.f, Sii = 0.f;
     float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
-    float af[F > 0 ? F : 1];
+    f32x2 af2[F > 0 ? F / 2 : 1];
 #pragma unroll
-    for (int c = 0; c < F; ++c) af[c] = 0.f;
+    for (int c = 0; c < F / 2; ++c) af2[c] = f32x2{0.f, 0.f};
     for (int i = 0; i < SUB; ++i) {
       const float fi = (float)i, fii = (float)(i * i);
       const float base = poly_row_base(k, fi, fii);
@@ -144,14 +145,17 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
         const float* cot = s_cot[wave][p];
         const float4 cg = *reinterpret_cast<const float4*>(cot);
         float s = col.x * cg.x + col.y * cg.y + col.z * cg.z + col.w * cg.w;
-        float gf[F > 0 ? F : 1];
+        f32x2 gf2[F > 0 ? F / 2 : 1];
         if (F > 0) {
+          f32x2 sacc = {0.f, 0.f};
 #pragma unroll
           for (int c4 = 0; c4 < F / 4; ++c4) {
             const float4 v = *reinterpret_cast<const float4*>(cot + 4 + 4 * c4);
-            gf[4 * c4] = v.x; gf[4 * c4 + 1] = v.y; gf[4 * c4 + 2] = v.z; gf[4 * c4 + 3] = v.w;
-            s += f[4 * c4] * v.x + f[4 * c4 + 1] * v.y + f[4 * c4 + 2] * v.z + f[4 * c4 + 3] * v.w;
+            gf2[2 * c4] = f32x2{v.x, v.y}; gf2[2 * c4 + 1] = f32x2{v.z, v.w};
+            sacc = f2[2 * c4] * gf2[2 * c4] + sacc;           // v_pk_fma_f32
+            sacc = f2[2 * c4 + 1] * gf2[2 * c4 + 1] + sacc;
           }
+          s += sacc.x + sacc.y;
         }
         const float ws = w * s;
         const float incl = ASM ? wave_scan_add_asm(ws) : wave_scan_add(ws);
@@ -168,8 +172,9 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
         R2 = fmaf(q, (float)(j * j), R2);
         a_r = fmaf(w, cg.x, a_r); a_g = fmaf(w, cg.y, a_g); a_b = fmaf(w, cg.z, a_b); a_d = fmaf(w, cg.w, a_d);
         if (F > 0) {
+          const f32x2 w2 = {w, w};
 #pragma unroll
-          for (int c = 0; c < F; ++c) af[c] = fmaf(w, gf[c], af[c]);
+          for (int c = 0; c < F / 2; ++c) af2[c] = w2 * gf2[c] + af2[c];   // v_pk_fma_f32
         }
       }
       S0 += R0; Sj += R1; Sjj += R2;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
       float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
       if (F > 0) {
 #pragma unroll
-        for (int q = 0; q < F / 4; ++q) row[q] = make_float4(af[4 * q], af[4 * q + 1], af[4 * q + 2], af[4 * q + 3]);
+        for (int q = 0; q < F / 4; ++q) row[q] = make_float4(af2[2 * q].x, af2[2 * q].y, af2[2 * q + 1].x, af2[2 * q + 1].y);
       }
       row[F / 4 + 0] = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
       row[F / 4 + 1] = make_float4(a_cc, a_op, a_r, a_g);
