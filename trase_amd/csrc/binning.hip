@@ -37,15 +37,48 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
+  // Keys arrive in runs (consecutive pairs of one Gaussian share the high bits of the sub-tile id):
+  // aggregate runs inside the wave so that a 64-lane run costs one LDS atomic instead of 64 serialized ones.
+  const unsigned lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+    const bool valid = idx < n;
+    const uint32_t dg = valid ? ((keys[idx] >> shift) & mask) : 0xffffffffu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)dg, 1);
+    const bool start = valid && (lane == 0 || prev != dg);
+    const unsigned long long starts = __ballot(start);
+    const unsigned long long vmask = __ballot(valid);
+    if (start) {
+      const unsigned long long later = (lane == 63) ? 0ull : (starts >> (lane + 1));
+      const unsigned nvalid = (unsigned)__popcll(vmask);           // valid lanes are a prefix of the wave
+      const unsigned next = later ? (lane + 1 + (unsigned)__builtin_ctzll(later)) : nvalid;
+      atomicAdd(&h[dg], next - lane);
+    }
   }
   __syncthreads();
-  const uint32_t c = h[threadIdx.x];
-  hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = c;
-  if (c) atomicAdd(&digit_total[threadIdx.x], c);
+  hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- pass kernel 1b: per-digit totals (one workgroup per digit sums its histogram row) --------------
+// (kept out of the histogram kernel: thousands of workgroups hammering 256 global counters with atomics
+// cost more than the whole histogram)
+__global__ __launch_bounds__(256) void radix_total_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                          const uint32_t* __restrict__ hist,
+                                                          uint32_t* __restrict__ digit_total, int nb_max) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  const int nb = (int)((n + RS_TILE - 1) / RS_TILE);
+  const uint32_t* row = hist + (size_t)blockIdx.x * nb_max;
+  uint32_t s = 0;
+  for (int b = threadIdx.x; b < nb; b += 256) s += row[b];
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < (unsigned)k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = sh[0];
 }
 
 // ---- pass kernel 2: one workgroup per digit scans its row of the histogram --------------------
@@ -118,11 +151,14 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     v[i] = valid ? (IOTA ? idx : vals_in[idx]) : 0u;
     const uint32_t dg = (k[i] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
+    const uint32_t dg0 = __builtin_amdgcn_readfirstlane(dg);
+    if (!__all(!valid || dg == dg0)) {      // fast path: every valid lane of the round holds the same digit
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      const bool set = (dg >> bit) & 1u;
-      const unsigned long long bal = __ballot(set);
-      peers &= set ? bal : ~bal;
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool set = (dg >> bit) & 1u;
+        const unsigned long long bal = __ballot(set);
+        peers &= set ? bal : ~bal;
+      }
     }
     const uint32_t in_round = (uint32_t)__popcll(peers & lt);
     const uint32_t total = (uint32_t)__popcll(peers);
@@ -166,7 +202,6 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
   if (nb > t.nb_max) { set_error("radix_sort_pairs: nb %d > nb_max %d", nb, t.nb_max); return TRASE_ERR_WORKSPACE; }
   const int passes = radix_passes(bit_lo, bit_hi);
   if (passes > 8) return TRASE_ERR_INVALID;
-  TRASE_CHECK(hipMemsetAsync(t.digit_total, 0, sizeof(uint32_t) * 256 * 8, c.stream));
   for (int p = 0; p < passes; ++p) {
     const int shift = bit_lo + 8 * p;
     const int nbits = (bit_hi - shift) < 8 ? (bit_hi - shift) : 8;
@@ -181,6 +216,7 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
     TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
     {
       ProfScope ps("radix_scan", c.stream);
+      hipLaunchKernelGGL(radix_total_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
       hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_scan", c.stream, c.debug);
