@@ -149,6 +149,45 @@ int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, co
 int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                         const TraseRastWorkspace* ws, const TraseRastGrads* g, trase_stream_t stream);
 
+/* ---- render() with the reference's A1 "prep" fused in --------------------------
+ * Takes the RAW GaussianModel parameters (scene/gaussian_model.py:56-63) and the per-view deformation and
+ * applies gaussian_renderer/__init__.py:82-121 inside the per-Gaussian kernels: means3D = _xyz + d_xyz,
+ * scales = exp(_scaling) + d_scaling, rotations = normalize(_rotation) + d_rotation, opacity =
+ * sigmoid(_opacity), shs = cat(_features_dc, _features_rest), sh_objs = f / (||f|| + 1e-9).  d_* may be
+ * NULL (warm-up passes the float 0.0, train.py:192-193).  SH layout: features_dc (P,1,3), features_rest
+ * (P,15,3).  featn is a caller-owned (P,F) buffer that must live until the backward. */
+typedef struct TraseRastRawInputs {
+  int32_t P;
+  int32_t F;
+  int32_t norm_features;            /* norm_gaussian_features flag of render() */
+  const float* xyz;                 /* (P,3)    */
+  const float* d_xyz;               /* (P,3) or NULL */
+  const float* features_dc;         /* (P,1,3)  */
+  const float* features_rest;       /* (P,15,3) */
+  const float* opacity;             /* (P,1) logits */
+  const float* scaling;             /* (P,3) log-scales */
+  const float* d_scaling;           /* (P,3) or NULL */
+  const float* rotation;            /* (P,4) raw quaternion */
+  const float* d_rotation;          /* (P,4) or NULL */
+  const float* gaussian_features;   /* (P,1,F) raw, or NULL when F == 0 */
+  float* featn;                     /* (P,F) work buffer */
+} TraseRastRawInputs;
+
+typedef struct TraseRastRawGrads {
+  const float* dL_dimage; const float* dL_dfeats; const float* dL_ddepth;   /* cotangents, NULL if unused */
+  float* dL_dxyz; float* dL_dd_xyz; float* dL_dmeans2D;
+  float* dL_dfeatures_dc; float* dL_dfeatures_rest; float* dL_dopacity;
+  float* dL_dscaling; float* dL_dd_scaling; float* dL_drotation; float* dL_dd_rotation;
+  float* dL_dgaussian_features;
+} TraseRastRawGrads;
+
+int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                              const TraseRastWorkspace* ws, trase_stream_t stream);
+int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                          const TraseRastWorkspace* ws, trase_stream_t stream);
+int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                            const TraseRastWorkspace* ws, const TraseRastRawGrads* g, trase_stream_t stream);
+
 /* simple_knn._C.distCUDA2 (scene/gaussian_model.py:237): mean squared distance
  * to the 3 nearest neighbours.  ws_bytes from trase_knn_sizes. */
 int trase_knn_sizes(int32_t N, size_t* ws_bytes);

@@ -35,7 +35,9 @@ def test_struct_field_order_matches_header():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     for cname, cls in (("TraseRastSettings", _lib.RastSettings), ("TraseRastInputs", _lib.RastInputs),
                        ("TraseRastOutputs", _lib.RastOutputs), ("TraseRastWorkspace", _lib.RastWorkspace),
-                       ("TraseRastSizes", _lib.RastSizes), ("TraseRastGrads", _lib.RastGrads)):
+                       ("TraseRastSizes", _lib.RastSizes), ("TraseRastGrads", _lib.RastGrads),
+                       ("TraseRastRawInputs", _lib.RastRawInputs), ("TraseRastRawGrads", _lib.RastRawGrads),
+                       ("TraseMlpWeights", _lib.MlpWeights)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         names = []
         for decl in body.split(";"):
@@ -43,7 +45,8 @@ def test_struct_field_order_matches_header():
             if not decl:
                 continue
             for part in decl.split(","):
-                names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
+                part = re.sub(r"\[[^\]]*\]", "", part).strip()          # drop array declarators
+                names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part)[0])
         assert names == [f[0] for f in cls._fields_], cname
 
 

@@ -67,6 +67,25 @@ class RastGrads(C.Structure):
     ]
 
 
+class RastRawInputs(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("F", C.c_int32), ("norm_features", C.c_int32),
+        ("xyz", C.c_void_p), ("d_xyz", C.c_void_p), ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
+        ("opacity", C.c_void_p), ("scaling", C.c_void_p), ("d_scaling", C.c_void_p), ("rotation", C.c_void_p),
+        ("d_rotation", C.c_void_p), ("gaussian_features", C.c_void_p), ("featn", C.c_void_p),
+    ]
+
+
+class RastRawGrads(C.Structure):
+    _fields_ = [
+        ("dL_dimage", C.c_void_p), ("dL_dfeats", C.c_void_p), ("dL_ddepth", C.c_void_p),
+        ("dL_dxyz", C.c_void_p), ("dL_dd_xyz", C.c_void_p), ("dL_dmeans2D", C.c_void_p),
+        ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("dL_dopacity", C.c_void_p),
+        ("dL_dscaling", C.c_void_p), ("dL_dd_scaling", C.c_void_p), ("dL_drotation", C.c_void_p),
+        ("dL_dd_rotation", C.c_void_p), ("dL_dgaussian_features", C.c_void_p),
+    ]
+
+
 class MlpWeights(C.Structure):
     _fields_ = [
         ("D", C.c_int32), ("W", C.c_int32), ("xyz_multires", C.c_int32), ("t_multires", C.c_int32),
@@ -89,6 +108,12 @@ SYMBOLS = [
                                      C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_backward", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastInputs), C.POINTER(RastOutputs),
                                       C.POINTER(RastWorkspace), C.POINTER(RastGrads), C.c_void_p]),
+    ("trase_rast_preprocess_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                            C.POINTER(RastWorkspace), C.c_void_p]),
+    ("trase_rast_render_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                        C.POINTER(RastWorkspace), C.c_void_p]),
+    ("trase_rast_backward_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                          C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_void_p]),
     ("trase_knn_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     ("trase_knn_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_knn_points", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

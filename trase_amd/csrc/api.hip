@@ -332,6 +332,103 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);
 }
 
+// ---- render() with A1 fused in (raw parameters) ---------------------------------------------------------
+static int validate_raw(const TraseRastSettings* s, const TraseRastRawInputs* r) {
+  if (!s || !r) { set_error("null settings/inputs"); return TRASE_ERR_INVALID; }
+  if (r->P < 0 || s->image_width <= 0 || s->image_height <= 0) { set_error("bad sizes"); return TRASE_ERR_INVALID; }
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) { set_error("bg/viewmatrix/projmatrix/campos are required"); return TRASE_ERR_INVALID; }
+  if (r->F != 0 && r->F != 16 && r->F != 32) { set_error("feature width %d not compiled in (0,16,32)", r->F); return TRASE_ERR_UNSUPPORTED; }
+  if (s->sh_degree < 0 || s->sh_degree > 3) { set_error("sh_degree %d outside 0..3", s->sh_degree); return TRASE_ERR_INVALID; }
+  if (r->P == 0) return TRASE_OK;
+  if (!r->xyz || !r->features_dc || !r->features_rest || !r->opacity || !r->scaling || !r->rotation) {
+    set_error("raw inputs: xyz/features_dc/features_rest/opacity/scaling/rotation are required"); return TRASE_ERR_INVALID;
+  }
+  if (r->F > 0 && (!r->gaussian_features || !r->featn)) { set_error("raw inputs: gaussian_features/featn required when F > 0"); return TRASE_ERR_INVALID; }
+  return TRASE_OK;
+}
+
+static TraseRastInputs raw_as_inputs(const TraseRastRawInputs* r) {
+  TraseRastInputs in;
+  memset(&in, 0, sizeof(in));
+  in.P = r->P; in.M = 16; in.F = r->F; in.sh_objs = r->featn;
+  return in;
+}
+
+int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                              const TraseRastWorkspace* ws, trase_stream_t stream_) {
+  int rc = validate_raw(s, raw);
+  if (rc) return rc;
+  if (!out || (raw->P > 0 && !out->radii)) { set_error("radii output required"); return TRASE_ERR_INVALID; }
+  const TraseRastInputs in = raw_as_inputs(raw);
+  rc = check_ws(&in, s, ws, WS_GEOM | WS_PRE);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  GeomBuf g = carve_geom(ws->geom, in.P);
+  PreBuf t = carve_pre(ws->pre, in.P);
+  TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
+  if (in.P == 0) return TRASE_OK;
+  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[0]);
+  if (rc) return rc;
+  int idx = 0;
+  rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)in.P, 0, 32, true, &idx);
+  if (rc) return rc;
+  if (idx != 0) { set_error("internal: depth sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
+  return launch_scan_tiles(c, g, t.sort.vals[0], in.P, t, 0xffffffffu);
+}
+
+int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                          const TraseRastWorkspace* ws, trase_stream_t stream) {
+  int rc = validate_raw(s, raw);
+  if (rc) return rc;
+  // stage 2 only needs P, F and the feature rows: reuse the regular entry point on a synthetic input record
+  TraseRastInputs in = raw_as_inputs(raw);
+  static const float dummy = 0.f;
+  in.means3D = &dummy; in.opacities = &dummy; in.shs = &dummy; in.scales = &dummy; in.rotations = &dummy;   // never dereferenced in stage 2
+  if (in.F > 0 && !in.sh_objs) { set_error("featn required"); return TRASE_ERR_INVALID; }
+  return trase_rast_render(s, &in, out, ws, stream);
+}
+
+int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                            const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream_) {
+  int rc = validate_raw(s, raw);
+  if (rc) return rc;
+  if (!gr || !out || (raw->P > 0 && !out->radii)) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
+  TraseRastInputs in = raw_as_inputs(raw);
+  rc = check_ws(&in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG);
+  if (rc) return rc;
+  if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in.P, in.F, ws->capacity)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  const int gx = (s->image_width + SUB - 1) / SUB, gy = (s->image_height + SUB - 1) / SUB;
+  GeomBuf g = carve_geom(ws->geom, in.P);
+  BinBuf b = carve_bin(ws->bin, ws->capacity, gx * gy);
+  ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
+  PreBuf pre = carve_pre(ws->pre, in.P);
+  float* acc = (float*)ws->tmp;
+  uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in.P);
+  float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
+  if (in.P == 0) return TRASE_OK;
+  TraseRastGrads g2;
+  memset(&g2, 0, sizeof(g2));
+  g2.dL_dimage = gr->dL_dimage; g2.dL_dfeats = gr->dL_dfeats;
+  g2.dL_ddepth = (s->variant & 0x100) ? gr->dL_ddepth : nullptr;
+  float* d_feats = gr->dL_dgaussian_features;
+  if (!g2.dL_dfeats) {
+    if (d_feats && raw->F > 0) TRASE_CHECK(hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
+    in.F = 0;
+    d_feats = nullptr;
+  }
+  TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+  rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+  if (rc) return rc;
+  rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features);
+  if (rc) return rc;
+  return launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr);
+}
+
 int trase_prof_enable(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;

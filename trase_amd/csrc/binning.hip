@@ -409,7 +409,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ hdr,
                                                           const float* __restrict__ rows,
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
-                                                          float* __restrict__ d_feats) {
+                                                          float* __restrict__ d_feats,
+                                                          const float* __restrict__ raw_feats, int norm_features) {
   constexpr int F = ROW - 16;
   const int r = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -444,25 +445,34 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
       }
     }
   }
-  if (col) {
-    const float tot = (s0 + s1) + (s2 + s3);
-    if (lane < F) {
-      if (d_feats) d_feats[(size_t)id * F + lane] = tot;
-    } else if (lane < F + 10) {
-      acc[(size_t)id * BWD_ACC + (lane - F)] = tot;
+  const float tot = col ? (s0 + s1) + (s2 + s3) : 0.f;
+  if (F > 0 && raw_feats && d_feats) {
+    // fused backward of y = x / (||x|| + 1e-9) (gaussian_renderer/__init__.py:120-121): lanes 0..F-1 hold dL/dy
+    const bool fl = lane < F;
+    const float x = fl ? raw_feats[(size_t)id * F + lane] : 0.f;
+    float dx = tot;
+    if (norm_features) {
+      const float n2 = wave_sum_all(x * x);
+      const float dot = wave_sum_all(fl ? x * tot : 0.f);
+      const float n = sqrtf(n2), den = n + 1e-9f;
+      dx = tot / den - ((n > 0.f) ? x * dot / (n * den * den) : 0.f);
     }
+    if (fl) d_feats[(size_t)id * F + lane] = dx;
+  } else if (lane < F) {
+    if (d_feats) d_feats[(size_t)id * F + lane] = tot;
   }
+  if (lane >= F && lane < F + 10) acc[(size_t)id * BWD_ACC + (lane - F)] = tot;
 }
 
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
-                       const uint8_t* row_flags, float* acc, float* d_feats) {
+                       const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats, int norm_features) {
   const int blocks = (P + 3) / 4;
   {
     ProfScope ps("reduce_rows", c.stream);
     switch (F) {
-      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
-      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
-      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats); break;
+      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
       default: set_error("reduce_rows: feature width %d not compiled in", F); return TRASE_ERR_UNSUPPORTED;
     }
   }

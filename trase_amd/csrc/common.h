@@ -235,6 +235,11 @@ int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const 
 int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
                           const GeomBuf& g, const float* acc, const TraseRastGrads& gr);
 
+int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
+                              const GeomBuf& g, uint32_t* depth_keys);
+int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
+                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr);
+
 // stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
 int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
@@ -246,8 +251,10 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap);
 int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
                       uint32_t cap, uint32_t* point_list);
+// raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
-                       const uint8_t* row_flags, float* acc, float* d_feats);
+                       const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
+                       int norm_features = 0);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
                               int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list);

@@ -1,0 +1,242 @@
+// preprocess_raw.hip -- the per-Gaussian forward/backward with the reference's A1 "prep" fused in.
+//
+// gaussian_renderer.render() prepares the rasterizer inputs with ~10 small PyTorch kernels
+// (gaussian_renderer/__init__.py:82-121; activations scene/gaussian_model.py:43-51,183-205):
+//     means3D   = _xyz + d_xyz                         opacity = sigmoid(_opacity)
+//     scales    = exp(_scaling) + d_scaling             rotations = normalize(_rotation) + d_rotation
+//     shs       = cat(_features_dc, _features_rest)     sh_objs = f / (||f||_2 + 1e-9)
+// and autograd runs their backward as ~15 more.  Here they happen in registers inside the per-Gaussian
+// kernels: the forward reads the RAW parameters (plus the per-view deformation), the backward chains the
+// activation derivatives and writes gradients of the raw parameters (and of the deformation, which the
+// deformation MLP consumes).  The only extra buffer is the normalised feature row the compositing
+// kernels read.  
+#include "common.h"
+
+namespace trase {
+
+struct RawFwdArgs {
+  const float* xyz; const float* d_xyz; const float* f_dc; const float* f_rest; const float* opacity;
+  const float* scaling; const float* d_scaling; const float* rotation; const float* d_rotation;
+  const float* features; float* featn;
+  const float* vm; const float* pm; const float* cam;
+  int P, F, deg, W, H, norm_features;
+  float tanx, tany, mod;
+};
+
+__device__ __forceinline__ void raw_view(const RawFwdArgs& a, View& v) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v.V[i] = a.vm[i]; v.PM[i] = a.pm[i]; }
+  v.cam[0] = a.cam[0]; v.cam[1] = a.cam[1]; v.cam[2] = a.cam[2];
+  v.tanx = a.tanx; v.tany = a.tany;
+  v.fx = (float)a.W / (2.0f * a.tanx); v.fy = (float)a.H / (2.0f * a.tany);
+  v.mod = a.mod; v.W = a.W; v.H = a.H;
+  v.gx = (a.W + TILE - 1) / TILE; v.gy = (a.H + TILE - 1) / TILE;
+  v.deg = a.deg;
+}
+
+struct Activated { float p[3], sc[3], q[4], opac, qn[4], inv_n, es[3], sig; };
+
+// activations of one Gaussian (also returns what the backward needs: unit quaternion, 1/norm, exp, sigmoid)
+__device__ __forceinline__ void activate(const RawFwdArgs& a, int i, Activated& o) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    o.p[k] = a.xyz[3 * i + k] + (a.d_xyz ? a.d_xyz[3 * i + k] : 0.f);
+    o.es[k] = __expf(a.scaling[3 * i + k]);
+    o.sc[k] = o.es[k] + (a.d_scaling ? a.d_scaling[3 * i + k] : 0.f);
+  }
+  const float4 r = reinterpret_cast<const float4*>(a.rotation)[i];
+  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  o.inv_n = 1.0f / fmaxf(n, 1e-12f);                       // torch.nn.functional.normalize eps
+  o.qn[0] = r.x * o.inv_n; o.qn[1] = r.y * o.inv_n; o.qn[2] = r.z * o.inv_n; o.qn[3] = r.w * o.inv_n;
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.d_rotation) dq = reinterpret_cast<const float4*>(a.d_rotation)[i];
+  o.q[0] = o.qn[0] + dq.x; o.q[1] = o.qn[1] + dq.y; o.q[2] = o.qn[2] + dq.z; o.q[3] = o.qn[3] + dq.w;
+  o.sig = 1.0f / (1.0f + __expf(-a.opacity[i]));
+  o.opac = o.sig;
+}
+
+__device__ __forceinline__ void load_sh_split(const RawFwdArgs& a, int i, float shl[48]) {
+  const int n3 = 3 * ncoef(a.deg);
+  const float* dc = a.f_dc + 3 * (size_t)i;
+  const float* rest = a.f_rest + 45 * (size_t)i;
+  shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
+#pragma unroll
+  for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? rest[k - 3] : 0.f;
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
+                                                                 float2* __restrict__ xy, float4* __restrict__ conic_o,
+                                                                 float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
+                                                                 uint32_t* __restrict__ clamped,
+                                                                 uint32_t* __restrict__ depth_keys,
+                                                                 uint32_t* __restrict__ hdr) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;
+  const bool active = gi < a.P;
+  const int i = active ? gi : a.P - 1;
+  View v;
+  raw_view(a, v);
+  Activated act;
+  activate(a, i, act);
+  float shl[48];
+  load_sh_split(a, i, shl);
+  const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
+  Splat o;
+  const bool vis = splat_forward<false, true>(v, act.p, act.sc, act.q, cv, shl, col, o) && active;
+  if (active) radii[i] = vis ? o.radius : 0;
+  const float rect_area = vis ? (float)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0.f;
+  const float wave_area = wave_sum_lane63(rect_area);
+  if ((threadIdx.x & 63) == 63 && wave_area > 0.f) atomicAdd(&hdr[HDR_R], (uint32_t)wave_area);
+  uint32_t live = 0;
+  if (vis) {
+    for (int ty = o.y0; ty < o.y1; ++ty)
+      for (int tx = o.x0; tx < o.x1; ++tx) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
+          if (bx < a.W && by < a.H && subtile_live(o.px, o.py, o.ca, o.cb, o.cc, act.opac, bx, by, a.W, a.H)) ++live;
+        }
+      }
+  }
+  if (active) {
+    tiles[i] = live;
+    depth_keys[i] = (vis && live) ? __float_as_uint(o.depth) : 0xffffffffu;
+  }
+  if (vis) {
+    xy[i] = make_float2(o.px, o.py);
+    conic_o[i] = make_float4(o.ca, o.cb, o.cc, act.opac);
+    rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    clamped[i] = o.clamped;
+  }
+  // feature row the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121)
+  if (F > 0 && active && vis && live) {
+    const float4* src = reinterpret_cast<const float4*>(a.features + (size_t)i * F);
+    float4 r[F > 0 ? F / 4 : 1];
+    float n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < F / 4; ++k) { r[k] = src[k]; n2 += r[k].x * r[k].x + r[k].y * r[k].y + r[k].z * r[k].z + r[k].w * r[k].w; }
+    const float s = a.norm_features ? 1.0f / (sqrtf(n2) + 1e-9f) : 1.0f;
+    float4* dst = reinterpret_cast<float4*>(a.featn + (size_t)i * F);
+#pragma unroll
+    for (int k = 0; k < F / 4; ++k) dst[k] = make_float4(r[k].x * s, r[k].y * s, r[k].z * s, r[k].w * s);
+  }
+}
+
+int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
+                              const GeomBuf& g, uint32_t* depth_keys) {
+  RawFwdArgs a;
+  a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
+  a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
+  a.features = raw.gaussian_features; a.featn = raw.featn;
+  a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
+  a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
+  a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  const dim3 grid((raw.P + 255) / 256), block(256);
+  {
+    ProfScope ps("preprocess_fwd", c.stream);
+#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr)
+    switch (raw.F) {
+      case 0: TRASE_PRF(0); break;
+      case 16: TRASE_PRF(16); break;
+      case 32: TRASE_PRF(32); break;
+      default: set_error("preprocess_fwd_raw: feature width %d not compiled in (0,16,32)", raw.F); return TRASE_ERR_UNSUPPORTED;
+    }
+#undef TRASE_PRF
+  }
+  TRASE_POST_LAUNCH("preprocess_fwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+// ---- backward -----------------------------------------------------------------------------------------
+struct RawBwdOut {
+  float* d_xyz; float* d_dxyz; float* d_means2D; float* d_f_dc; float* d_f_rest; float* d_opacity;
+  float* d_scaling; float* d_dscaling; float* d_rotation; float* d_drotation;
+};
+
+__global__ __launch_bounds__(256) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
+                                                                 const uint32_t* __restrict__ clamped,
+                                                                 const float* __restrict__ acc, RawBwdOut o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.P) return;
+  const bool vis = radii[i] > 0;
+  SplatGradOut go;
+  float dsh[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+  SplatGradIn gi;
+  gi.d_ndcx = gi.d_ndcy = gi.d_ca = gi.d_cb = gi.d_cc = gi.d_depth = 0.f;
+  gi.d_rgb[0] = gi.d_rgb[1] = gi.d_rgb[2] = 0.f;
+  float d_op = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { go.d_p[k] = 0.f; go.d_scale[k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) go.d_quat[k] = 0.f;
+  Activated act;
+  act.inv_n = 0.f; act.sig = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) act.es[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) act.qn[k] = 0.f;
+  if (vis) {
+    const float4* r4 = reinterpret_cast<const float4*>(acc + (size_t)i * BWD_ACC);
+    const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+    gi.d_ndcx = r0.x; gi.d_ndcy = r0.y; gi.d_ca = r0.z; gi.d_cb = r0.w;
+    gi.d_cc = r1.x; d_op = r1.y; gi.d_rgb[0] = r1.z; gi.d_rgb[1] = r1.w;
+    gi.d_rgb[2] = r2.x; gi.d_depth = r2.y;
+    View v;
+    raw_view(a, v);
+    activate(a, i, act);
+    float shl[48];
+    load_sh_split(a, i, shl);
+    const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    splat_backward<false, true>(v, act.p, act.sc, act.q, cv, shl, clamped[i], gi, go, dsh);
+  }
+  // chain through the activations
+  if (o.d_xyz) { o.d_xyz[3 * i] = go.d_p[0]; o.d_xyz[3 * i + 1] = go.d_p[1]; o.d_xyz[3 * i + 2] = go.d_p[2]; }
+  if (o.d_dxyz) { o.d_dxyz[3 * i] = go.d_p[0]; o.d_dxyz[3 * i + 1] = go.d_p[1]; o.d_dxyz[3 * i + 2] = go.d_p[2]; }
+  if (o.d_means2D) { o.d_means2D[3 * i] = gi.d_ndcx; o.d_means2D[3 * i + 1] = gi.d_ndcy; o.d_means2D[3 * i + 2] = 0.f; }
+  if (o.d_opacity) o.d_opacity[i] = d_op * act.sig * (1.0f - act.sig);
+  if (o.d_scaling) {
+    o.d_scaling[3 * i] = go.d_scale[0] * act.es[0]; o.d_scaling[3 * i + 1] = go.d_scale[1] * act.es[1];
+    o.d_scaling[3 * i + 2] = go.d_scale[2] * act.es[2];
+  }
+  if (o.d_dscaling) { o.d_dscaling[3 * i] = go.d_scale[0]; o.d_dscaling[3 * i + 1] = go.d_scale[1]; o.d_dscaling[3 * i + 2] = go.d_scale[2]; }
+  if (o.d_drotation) reinterpret_cast<float4*>(o.d_drotation)[i] = make_float4(go.d_quat[0], go.d_quat[1], go.d_quat[2], go.d_quat[3]);
+  if (o.d_rotation) {
+    // y = q / ||q||  =>  dq = (g - y <y,g>) / ||q||
+    const float dot = act.qn[0] * go.d_quat[0] + act.qn[1] * go.d_quat[1] + act.qn[2] * go.d_quat[2] + act.qn[3] * go.d_quat[3];
+    reinterpret_cast<float4*>(o.d_rotation)[i] =
+        make_float4((go.d_quat[0] - act.qn[0] * dot) * act.inv_n, (go.d_quat[1] - act.qn[1] * dot) * act.inv_n,
+                    (go.d_quat[2] - act.qn[2] * dot) * act.inv_n, (go.d_quat[3] - act.qn[3] * dot) * act.inv_n);
+  }
+  if (o.d_f_dc) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
+  if (o.d_f_rest) {
+    float* dst = o.d_f_rest + 45 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 45; ++k) dst[k] = dsh[3 + k];
+  }
+}
+
+int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
+                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr) {
+  RawFwdArgs a;
+  a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
+  a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
+  a.features = raw.gaussian_features; a.featn = raw.featn;
+  a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
+  a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
+  a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  RawBwdOut o;
+  o.d_xyz = gr.dL_dxyz; o.d_dxyz = gr.dL_dd_xyz; o.d_means2D = gr.dL_dmeans2D; o.d_f_dc = gr.dL_dfeatures_dc;
+  o.d_f_rest = gr.dL_dfeatures_rest; o.d_opacity = gr.dL_dopacity; o.d_scaling = gr.dL_dscaling;
+  o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
+  {
+    ProfScope ps("preprocess_bwd", c.stream);
+    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((raw.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped, acc, o);
+  }
+  TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+}  // namespace trase

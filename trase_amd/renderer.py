@@ -1,0 +1,239 @@
+"""``render()`` with the reference's signature and return dict (gaussian_renderer/__init__.py:37-155) on
+top of the fused raw-parameter path: the A1 "prep" (activations, deformation add, SH concat, feature
+L2-normalisation) runs inside the per-Gaussian HIP kernels instead of ~25 small PyTorch kernels per
+iteration.  Importable as ``gaussian_renderer.render`` through the top-level shim,
+so train.py / train_style_transfer_nnfm.py / render.py keep their ``from gaussian_renderer import render``.
+
+Anything the fused kernels do not cover (is_6dof, override_color, mask, the Python SH / covariance
+fallbacks, KNN-smoothed features) takes the reference's own composition of PyTorch ops around the HIP
+``GaussianRasterizer`` -- still the HIP rasterizer, never a CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _bytes, _fill_settings, _prep,
+                         _stream)
+
+
+class _RenderRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat, means2D,
+                raster_settings, norm_features):
+        lib = _lib.load()
+        device = xyz.device
+        if device.type != "cuda":
+            raise RuntimeError("trase_amd render runs on the GPU only (there is no CPU path)")
+        T = lambda t, n: _prep(t, n, device)
+        xyz, f_dc, f_rest, opacity = T(xyz, "xyz"), T(f_dc, "features_dc"), T(f_rest, "features_rest"), T(opacity, "opacity")
+        scaling, rotation = T(scaling, "scaling"), T(rotation, "rotation")
+        d_xyz, d_scaling, d_rotation = T(d_xyz, "d_xyz"), T(d_scaling, "d_scaling"), T(d_rotation, "d_rotation")
+        gfeat = T(gfeat, "gaussian_features")
+        P = xyz.shape[0]
+        F = gfeat.shape[-1] if gfeat is not None else 0
+        if f_rest.shape[1] != 15 or f_dc.shape[1] != 1:
+            raise ValueError("fused render expects features_dc (P,1,3) and features_rest (P,15,3)")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        keep: list = []
+        s = _fill_settings(raster_settings, device, keep)
+        featn = torch.empty(P, max(F, 1), device=device)
+        raw = _lib.RastRawInputs()
+        raw.P, raw.F, raw.norm_features = P, F, int(bool(norm_features))
+        raw.xyz, raw.d_xyz = _lib.ptr(xyz), _lib.ptr(d_xyz)
+        raw.features_dc, raw.features_rest, raw.opacity = _lib.ptr(f_dc), _lib.ptr(f_rest), _lib.ptr(opacity)
+        raw.scaling, raw.d_scaling = _lib.ptr(scaling), _lib.ptr(d_scaling)
+        raw.rotation, raw.d_rotation = _lib.ptr(rotation), _lib.ptr(d_rotation)
+        raw.gaussian_features = _lib.ptr(gfeat) if F > 0 else None
+        raw.featn = _lib.ptr(featn)
+
+        image = torch.empty(3, H, W, device=device)
+        feats = torch.empty(F, H, W, device=device)
+        depth = torch.empty(1, H, W, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        out = _lib.RastOutputs()
+        out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
+        out.feats = _lib.ptr(feats) if F > 0 else None
+        sizes = _lib.RastSizes()
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, 1, C.byref(sizes)), "trase_rast_sizes")
+        geom, pre, img = _bytes(sizes.geom_bytes, device), _bytes(sizes.pre_bytes, device), _bytes(sizes.img_bytes, device)
+        ws = _lib.RastWorkspace()
+        ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
+        ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
+        ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
+        stream = _stream(device)
+        _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                   "trase_rast_preprocess_raw")
+        if _Policy.sync:
+            st = (C.c_int64 * 3)()
+            _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
+            capacity = max(int(st[2]), 1)
+        else:
+            capacity = max(int(_Policy.capacity), 1)
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
+        binb, tmp = _bytes(sizes.bin_bytes, device), _bytes(sizes.tmp_bytes, device)
+        ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
+        ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
+        ws.capacity = capacity
+        _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                   "trase_rast_render_raw")
+        _Policy.last_geom, _Policy.last_capacity = geom, capacity
+        ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
+        ctx.norm_features = bool(norm_features)
+        ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        z = xyz.new_empty(0)
+        ctx.save_for_backward(xyz, d_xyz if d_xyz is not None else z, f_dc, f_rest, opacity, scaling,
+                              d_scaling if d_scaling is not None else z, rotation,
+                              d_rotation if d_rotation is not None else z, gfeat if gfeat is not None else z,
+                              radii, geom, binb, img, pre, featn)
+        return image, radii, feats, depth
+
+    @staticmethod
+    def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
+        lib = _lib.load()
+        (xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat,
+         radii, geom, binb, img, pre, featn) = ctx.saved_tensors
+        has_dxyz, has_dscale, has_drot, has_feat = ctx.opt
+        P, F, H, W = ctx.dims
+        device = xyz.device
+        keep: list = []
+        s = _fill_settings(ctx.raster_settings, device, keep)
+        raw = _lib.RastRawInputs()
+        raw.P, raw.F, raw.norm_features = P, F, int(ctx.norm_features)
+        raw.xyz, raw.d_xyz = _lib.ptr(xyz), (_lib.ptr(d_xyz) if has_dxyz else None)
+        raw.features_dc, raw.features_rest, raw.opacity = _lib.ptr(f_dc), _lib.ptr(f_rest), _lib.ptr(opacity)
+        raw.scaling, raw.d_scaling = _lib.ptr(scaling), (_lib.ptr(d_scaling) if has_dscale else None)
+        raw.rotation, raw.d_rotation = _lib.ptr(rotation), (_lib.ptr(d_rotation) if has_drot else None)
+        raw.gaussian_features = _lib.ptr(gfeat) if (has_feat and F > 0) else None
+        raw.featn = _lib.ptr(featn)
+        out = _lib.RastOutputs()
+        out.radii = _lib.ptr(radii)
+        sizes = _lib.RastSizes()
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")
+        tmp = _bytes(sizes.bwd_tmp_bytes, device)
+        ws = _lib.RastWorkspace()
+        ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
+        ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
+        ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
+        ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
+        ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
+        ws.capacity = ctx.capacity
+        need = ctx.needs_input_grad   # xyz0 d_xyz1 f_dc2 f_rest3 opacity4 scaling5 d_scaling6 rotation7 d_rotation8 gfeat9 means2D10
+
+        def alloc(flag, like):
+            return torch.empty_like(like) if flag else None
+
+        g_xyz = torch.empty(P, 3, device=device)
+        g_dxyz = alloc(need[1] and has_dxyz, xyz)
+        g_m2d = torch.empty(P, 3, device=device)
+        g_dc, g_rest = alloc(need[2], f_dc), alloc(need[3], f_rest)
+        g_op, g_sc, g_rot = alloc(need[4], opacity), alloc(need[5], scaling), alloc(need[6 + 1], rotation)
+        g_dsc = alloc(need[6] and has_dscale, scaling)
+        g_drot = alloc(need[8] and has_drot, rotation)
+        g_feat = alloc(need[9] and has_feat and F > 0, gfeat) if has_feat else None
+        g = _lib.RastRawGrads()
+        g.dL_dimage = _lib.ptr(_prep(grad_image, "grad_image", device))
+        g.dL_dfeats = _lib.ptr(_prep(grad_feats, "grad_feats", device)) if F > 0 else None
+        g.dL_ddepth = _lib.ptr(_prep(grad_depth, "grad_depth", device))
+        g.dL_dxyz, g.dL_dd_xyz, g.dL_dmeans2D = _lib.ptr(g_xyz), _lib.ptr(g_dxyz), _lib.ptr(g_m2d)
+        g.dL_dfeatures_dc, g.dL_dfeatures_rest, g.dL_dopacity = _lib.ptr(g_dc), _lib.ptr(g_rest), _lib.ptr(g_op)
+        g.dL_dscaling, g.dL_dd_scaling = _lib.ptr(g_sc), _lib.ptr(g_dsc)
+        g.dL_drotation, g.dL_dd_rotation = _lib.ptr(g_rot), _lib.ptr(g_drot)
+        g.dL_dgaussian_features = _lib.ptr(g_feat)
+        _lib.check(lib.trase_rast_backward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), C.byref(g),
+                                               _stream(device)), "trase_rast_backward_raw")
+        if P == 0:
+            for t in (g_xyz, g_dxyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat):
+                if t is not None:
+                    t.zero_()
+        return (g_xyz if need[0] else None, g_dxyz, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat,
+                g_m2d if need[10] else None, None, None)
+
+
+def _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth) -> bool:
+    if is_6dof or override_color is not None or mask is not None or is_smooth:
+        return False
+    if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
+        return False
+    for d in (d_xyz, d_rotation, d_scaling):
+        if torch.is_tensor(d) and d.dim() != 2:
+            return False
+        if not torch.is_tensor(d) and float(d) != 0.0:
+            return False
+    return pc._features_rest.shape[1] == 15 and pc._features_dc.shape[1] == 1
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation, d_scaling, is_6dof=False,
+           scaling_modifier=1.0, override_color=None, mask=None, norm_gaussian_features=True,
+           is_smooth_gaussian_features=False, smooth_K=16):
+    """Same contract as the reference's render() (gaussian_renderer/__init__.py:37-155)."""
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False,
+        debug=getattr(pipe, "debug", False))
+
+    if _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth_gaussian_features):
+        T = lambda d: d if torch.is_tensor(d) else None
+        rendered_image, radii, rendered_feats, depth = _RenderRaw.apply(
+            pc._xyz, T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, T(d_scaling),
+            pc._rotation, T(d_rotation), pc._gaussian_features, screenspace_points, raster_settings,
+            norm_gaussian_features)
+    else:
+        # the reference's own composition around the (HIP) rasterizer
+        rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+        if is_6dof:
+            if torch.is_tensor(d_xyz) is False:
+                means3D = pc.get_xyz
+            else:
+                ones = torch.ones_like(pc.get_xyz[:, :1])
+                hom = torch.cat([pc.get_xyz, ones], dim=-1)
+                res = torch.bmm(d_xyz, hom.unsqueeze(-1)).squeeze(-1)
+                means3D = res[:, :3] / res[:, 3:]
+        else:
+            means3D = pc.get_xyz + d_xyz
+        means2D, opacity = screenspace_points, pc.get_opacity
+        scales = rotations = cov3D_precomp = None
+        if getattr(pipe, "compute_cov3D_python", False):
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales = pc.get_scaling + d_scaling
+            rotations = pc.get_rotation + d_rotation
+        shs = colors_precomp = None
+        if override_color is None:
+            if getattr(pipe, "convert_SHs_python", False):
+                raise NotImplementedError("convert_SHs_python: use the rasterizer's SH evaluation")
+            shs = pc.get_features
+        else:
+            colors_precomp = override_color
+        sh_objs = pc.get_gaussian_features if not is_smooth_gaussian_features else \
+            pc.get_smoothed_gaussian_features(K=smooth_K, dropout=0.5)
+        if norm_gaussian_features:
+            sh_objs = sh_objs / (sh_objs.norm(dim=2, keepdim=True) + 1e-9)
+        if mask is not None:
+            means3D, means2D, opacity, sh_objs = means3D[mask], means2D[mask], opacity[mask], sh_objs[mask]
+            if colors_precomp is not None:
+                colors_precomp = colors_precomp[mask]
+            else:
+                shs = shs[mask]
+            scales, rotations = scales[mask], rotations[mask]
+            if cov3D_precomp is not None:
+                cov3D_precomp = cov3D_precomp[mask]
+        rendered_image, radii, rendered_feats, depth = rasterizer(
+            means3D=means3D, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=colors_precomp,
+            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "render_gaussian_features": rendered_feats, "depth": depth}

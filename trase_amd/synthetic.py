@@ -142,3 +142,54 @@ def make_scene(n: int, feat_dim: int = 32, seed: int = 0, extent: float = 1.3,
     feats = rgb2sh(torch.rand(n, 1, feat_dim, generator=g))
     return SynthScene(xyz.float(), dc.float(), rest.float(), scaling.float(), rotation.float(),
                       opacity.float(), feats.float())
+
+
+class SynthGaussianModel:
+    """The slice of the reference's GaussianModel that render() reads (scene/gaussian_model.py:56-63 raw
+    parameters, :43-51,183-205 activated getters), over a SynthScene."""
+
+    def __init__(self, scene: SynthScene, sh_degree: int = 3, requires_grad: bool = True):
+        self.max_sh_degree = 3
+        self.active_sh_degree = sh_degree
+        mk = lambda t: t.detach().clone().requires_grad_(requires_grad)
+        self._xyz = mk(scene.xyz)
+        self._features_dc = mk(scene.features_dc)
+        self._features_rest = mk(scene.features_rest)
+        self._scaling = mk(scene.scaling)
+        self._rotation = mk(scene.rotation)
+        self._opacity = mk(scene.opacity)
+        self._gaussian_features = mk(scene.gaussian_features)
+
+    def parameters(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity,
+                self._gaussian_features]
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_gaussian_features(self):
+        return self._gaussian_features
+
+
+class SynthPipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
