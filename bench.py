@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--feat", type=int, default=32)
     ap.add_argument("--scale-mult", type=float, default=0.27)
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=None)
+    ap.add_argument("--unfused", action="store_true",
+                    help="time the reference's PyTorch prep ops around GaussianRasterizer instead of the fused render()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-step", type=int, default=37)
     ap.add_argument("--cpu-budget-s", type=float, default=6.0, help="forward wall-time budget of the CPU sample")
@@ -114,9 +116,11 @@ def main():
     N, W, H, F = args.gaussians, args.width, args.height, args.feat
     P = W * H
     scene_cpu = make_scene(N, feat_dim=F, seed=0, scale_mult=args.scale_mult)
-    scene = scene_cpu.to(device)
-    names = ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity", "gaussian_features")
-    params = [getattr(scene, k).requires_grad_(True) for k in names]
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe
+    from gaussian_renderer import render          # the drop-in for the reference's render()
+    pc = SynthGaussianModel(scene_cpu.to(device))
+    pipe = SynthPipe()
+    params = pc.parameters()
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
     # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
@@ -125,6 +129,8 @@ def main():
     n_views = 16
     cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
     settings = [settings_for(c, device) for c in cams]
+    cams_dev = [c.to(device) for c in cams]
+    bg = torch.zeros(3, device=device)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     g_img = torch.randn(3, H, W, generator=g).to(device) / P
     g_feat = torch.randn(F, H, W, generator=g).to(device) / P
@@ -135,17 +141,20 @@ def main():
         else:
             for p_ in params:
                 p_.grad = None
-        st = settings[i % n_views]
-        xyz, f_dc, f_rest, scaling, rotation, opacity, gfeat = params
-        means2D = torch.zeros_like(xyz, requires_grad=True)            # gaussian_renderer/__init__.py:48
-        scales = torch.exp(scaling)
-        rots = torch.nn.functional.normalize(rotation)
-        opac = torch.sigmoid(opacity)
-        shs = torch.cat((f_dc, f_rest), dim=1)
-        sh_objs = gfeat / (gfeat.norm(dim=2, keepdim=True) + 1e-9)
-        img, radii, feats, depth = GaussianRasterizer(raster_settings=st)(
-            means3D=xyz, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=None, opacities=opac,
-            scales=scales, rotations=rots, cov3D_precomp=None)
+        if not args.unfused:
+            # render() drop-in: the A1 prep (activations, SH concat, feature normalisation) is fused into the
+            # per-Gaussian HIP kernels
+            out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
+            img, radii, feats = out["render"], out["radii"], out["render_gaussian_features"]
+        else:
+            # the reference's render() body verbatim: PyTorch prep ops around the GaussianRasterizer operator
+            st = settings[i % n_views]
+            means2D = torch.zeros_like(pc.get_xyz, requires_grad=True)            # gaussian_renderer/__init__.py:48
+            gfeat = pc.get_gaussian_features
+            sh_objs = gfeat / (gfeat.norm(dim=2, keepdim=True) + 1e-9)
+            img, radii, feats, depth = GaussianRasterizer(raster_settings=st)(
+                means3D=pc.get_xyz, means2D=means2D, shs=pc.get_features, sh_objs=sh_objs, colors_precomp=None,
+                opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
         torch.autograd.backward([img, feats], [g_img, g_feat])
         if bucket is not None:
             bucket.allreduce()
@@ -226,7 +235,9 @@ def main():
                                    + (", view-DP + RCCL all-reduce of Gaussian grads" if world > 1 else ""),
                        "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
                        "subtile_pairs_mean": round(reff_mean),
-                       "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant},
+                       "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant,
+                       "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
+                                else "gaussian_renderer.render() drop-in, A1 prep fused"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
