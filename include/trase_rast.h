@@ -212,6 +212,8 @@ typedef struct TraseMlpWeights {
   int32_t t_multires;    /* 10 -> 21 input channels */
   int32_t is_blender;    /* must be 0 */
   int32_t is_6dof;       /* must be 0 */
+  int32_t variant;       /* 0 = default kernel; bit 0 = first-generation kernel (A/B) */
+  int32_t reserved;
   const float* weight[8];/* linear.{i}.weight: (256, 84) / (256, 256) / (256, 340) for the skip layer i = 5 */
   const float* bias[8];  /* linear.{i}.bias  : (256,) */
   const float* w_warp;     const float* b_warp;      /* gaussian_warp     (3,256), (3,) */

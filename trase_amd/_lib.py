@@ -89,7 +89,7 @@ class RastRawGrads(C.Structure):
 class MlpWeights(C.Structure):
     _fields_ = [
         ("D", C.c_int32), ("W", C.c_int32), ("xyz_multires", C.c_int32), ("t_multires", C.c_int32),
-        ("is_blender", C.c_int32), ("is_6dof", C.c_int32),
+        ("is_blender", C.c_int32), ("is_6dof", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32),
         ("weight", C.c_void_p * 8), ("bias", C.c_void_p * 8),
         ("w_warp", C.c_void_p), ("b_warp", C.c_void_p), ("w_rotation", C.c_void_p), ("b_rotation", C.c_void_p),
         ("w_scaling", C.c_void_p), ("b_scaling", C.c_void_p),

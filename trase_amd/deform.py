@@ -9,6 +9,7 @@ train_style_transfer_nnfm.py:184-185, render.py:195, gui.py:965)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping, Tuple
 
 import torch
@@ -39,6 +40,7 @@ def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch
     w = _lib.MlpWeights()
     w.D, w.W, w.xyz_multires, w.t_multires = 8, 256, 10, 10
     w.is_blender, w.is_6dof = int(is_blender), int(is_6dof)
+    w.variant = int(os.environ.get("TRASE_MLP_VARIANT", "0"), 0)
     for i in range(8):
         wt, bs = P(f"linear.{i}.weight"), P(f"linear.{i}.bias")
         want = (256, 84) if i == 0 else ((256, 340) if i == 5 else (256, 256))
