@@ -110,3 +110,32 @@ def test_storage_order_invariance():
     # only move the result where two equal-depth Gaussians overlap -- allow a vanishing fraction of pixels
     diff = ((i0 - i1).abs().amax(0) > 1e-6) | ((f0 - f1).abs().amax(0) > 1e-6)
     assert diff.float().mean().item() < 1e-3
+
+
+def test_binning_count_and_emit_agree_at_s3_size(monkeypatch):
+    """Regression: the live-sub-tile count (preprocess) and its re-evaluation (emit) once disagreed for one pair
+    in ~8 M (different FMA contraction of two inlined copies), leaving a hole in the pair list.  BASELINE config 3
+    (1 M Gaussians, 1352x1014, ragged bottom sub-tile row) with poisoned workspaces; trase_rast_status raises if
+    the binning guards trip; exact- and over-sized capacity must give identical images."""
+    from trase_amd import rasterizer as R
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    from gaussian_renderer import render
+    monkeypatch.setattr(R, "_POISON", True)
+    dev = torch.device("cuda", 0)
+    n, w, h = 1_000_000, 1352, 1014
+    pc = SynthGaussianModel(make_scene(n, feat_dim=32, seed=0, scale_mult=0.27).to(dev), requires_grad=False)
+    bg = torch.zeros(3, device=dev)
+    try:
+        with torch.no_grad():
+            for k in (0, 5):
+                cam = orbit_camera(w, h, angle=2 * math.pi * k / 16).to(dev)
+                R.set_sync(True)
+                a = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0)
+                st = R.last_status()
+                R.set_sync(False, capacity=int(st[2] * 1.25) + 1024)
+                b = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0)
+                assert R.last_status() == st
+                assert torch.equal(a["render"], b["render"]) and torch.equal(a["render_gaussian_features"], b["render_gaussian_features"])
+                assert torch.isfinite(a["render"]).all()
+    finally:
+        R.set_sync(True)

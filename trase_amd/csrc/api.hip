@@ -75,7 +75,8 @@ GeomBuf carve_geom(void* ptr, int P) {
   g.clamped = (uint32_t*)c;
   return g;
 }
-size_t bin_bytes(int64_t cap, int T) { return align_up(sizeof(uint32_t) * (size_t)cap) * 2 + align_up(sizeof(uint2) * (size_t)T); }
+// ranges holds T sub-tiles + 1 sentinel ("trash") entry
+size_t bin_bytes(int64_t cap, int T) { return align_up(sizeof(uint32_t) * (size_t)cap) * 2 + align_up(sizeof(uint2) * ((size_t)T + 1)); }
 BinBuf carve_bin(void* ptr, int64_t cap, int T) {
   char* c = (char*)ptr;
   BinBuf b;
@@ -226,11 +227,15 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
 
 int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream_) {
   if (!ws || !ws->geom || !status) { set_error("trase_rast_status: bad arguments"); return TRASE_ERR_INVALID; }
-  uint32_t h[4];
+  uint32_t h[32];
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipMemcpyAsync(h, ws->geom, sizeof(h), hipMemcpyDeviceToHost, stream));
   TRASE_CHECK(hipStreamSynchronize(stream));
   status[0] = h[HDR_R]; status[1] = h[HDR_OVERFLOW]; status[2] = h[HDR_R_EFF];
+  if (h[16] || h[20]) {   // internal consistency guards of the binning stage (hdr words 16..22)
+    set_error("binning guard tripped: key flag %u (i=%u key=%u), slot flag %u (i=%u slot=%u)", h[16], h[17], h[18], h[20], h[21], h[22]);
+    return TRASE_ERR_HIP;
+  }
   return TRASE_OK;
 }
 
@@ -254,7 +259,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
   const uint32_t cap = (uint32_t)ws->capacity;
   if (in->P > 0) {
     int bits = 1;
-    while ((1 << bits) < T) ++bits;
+    while ((1 << bits) < T + 1) ++bits;          // keys 0..T (T = sentinel sub-tile)
     // the sort carries each pair's emit-order slot (generated on the fly in the first pass); arrange
     // the value ping-pong so that the last pass lands in the saved pair_slot array
     const int passes = radix_passes(0, bits);
@@ -267,11 +272,11 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-    rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T, b.pair_slot, t.pair_gauss,
-                                   b.point_list);
+    rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, b.pair_slot, t.pair_gauss,
+                                   b.point_list, g.hdr + 16);
     if (rc) return rc;
   } else {
-    TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, stream));
+    TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * ((size_t)T + 1), stream));
   }
   return launch_render_fwd(c, *s, *in, *out, g, b, im);
 }

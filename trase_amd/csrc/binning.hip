@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          const int32_t* __restrict__ radii,
                                                          const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
-                                                         uint32_t cap, uint32_t* __restrict__ hdr) {
+                                                         uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r == 0) {
     if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
@@ -348,12 +348,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   int x0, y0, x1, y1;
   tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
   const int gx8 = (W + SUB - 1) / SUB;
+  const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
   for (int ty = y0; ty < y1; ++ty)
     for (int tx = x0; tx < x1; ++tx) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-        if (bx < W && by < H && subtile_live(p.x, p.y, co.x, co.y, co.z, co.w, bx, by, W, H)) {
+        if (off < end && bx < W && by < H && subtile_live(p.x, p.y, co.x, co.y, co.z, co.w, bx, by, W, H)) {
           if (off < cap) {
             keys[off] = (uint32_t)((by / SUB) * gx8 + (bx / SUB));
             pair_gauss[off] = id;
@@ -362,6 +363,11 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
         }
       }
     }
+  // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused
+  // slots go to the sentinel sub-tile `trash_key` that no kernel renders (a dropped or padded borderline pair
+  // is below the alpha gate by the culling slack, so the image is unaffected)
+  for (; off < end; ++off)
+    if (off < cap) { keys[off] = trash_key; pair_gauss[off] = id; }
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
@@ -370,7 +376,8 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
   {
     ProfScope ps("emit_pairs", c.stream);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
-                       g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr);
+                       g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
+                       (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)));
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
   return TRASE_OK;
@@ -488,18 +495,28 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
                                                           uint2* __restrict__ ranges,
                                                           const uint32_t* __restrict__ pair_slot,
                                                           const uint32_t* __restrict__ pair_gauss,
-                                                          uint32_t* __restrict__ point_list) {
+                                                          uint32_t* __restrict__ point_list, uint32_t T,
+                                                          uint32_t* __restrict__ dbg) {
   const uint32_t n = dev_n(n_ptr, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t t = keys[i];
-    if (GATHER) point_list[i] = pair_gauss[pair_slot[i]];
+    uint32_t t = keys[i];
+    if (t >= T) {                                   // cannot happen unless the sort is broken: record, stay in bounds
+      if (dbg) { dbg[0] = 1; dbg[1] = i; dbg[2] = t; }
+      t = T - 1;
+    }
+    if (GATHER) {
+      uint32_t slot = pair_slot[i];
+      if (slot >= n) { if (dbg) { dbg[4] = 1; dbg[5] = i; dbg[6] = slot; } slot = 0; }
+      point_list[i] = pair_gauss[slot];
+    }
     if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
     if (i == n - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
   }
 }
 
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
-                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list) {
+                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
+                              uint32_t* dbg) {
   TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
   int blocks = (int)((cap + 255) / 256);
   if (blocks > 8192) blocks = 8192;
@@ -507,7 +524,7 @@ int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const ui
   {
     ProfScope ps("tile_ranges", c.stream);
     hipLaunchKernelGGL(tile_ranges_kernel<true>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, pair_slot,
-                       pair_gauss, point_list);
+                       pair_gauss, point_list, (uint32_t)T, dbg);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;
@@ -521,7 +538,7 @@ int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t*
   {
     ProfScope ps("tile_ranges", c.stream);
     hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, nullptr,
-                       nullptr, nullptr);
+                       nullptr, nullptr, (uint32_t)T, nullptr);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;

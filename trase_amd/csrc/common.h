@@ -160,6 +160,7 @@ bool prof_on();
     int _rc = ::trase::check_hip(hipGetLastError(), name);                              \
     if (_rc != 0) return _rc;                                                           \
     if (debug) {                                                                        \
+      if ((debug) > 1) fprintf(stderr, "[trase] %s\n", name);                           \
       _rc = ::trase::check_hip(hipStreamSynchronize(stream), name " (debug sync)");     \
       if (_rc != 0) return _rc;                                                         \
     }                                                                                   \
@@ -257,7 +258,8 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
                        int norm_features = 0);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
-                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list);
+                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
+                              uint32_t* dbg);
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im);

@@ -17,9 +17,11 @@
 
 #if defined(__HIPCC__)
 #define TRASE_HD __host__ __device__ __forceinline__
+#define TRASE_HD_NOINLINE inline __host__ __device__ __noinline__
 #define TRASE_UNROLL _Pragma("unroll")
 #else
 #define TRASE_HD inline
+#define TRASE_HD_NOINLINE inline
 #define TRASE_UNROLL
 #endif
 
@@ -203,7 +205,9 @@ TRASE_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0,
 // float32 rounding difference can never drop a pair the compositing kernel would have blended).
 constexpr int SUB = 8;   // sub-tile edge
 
-TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+// NOT inlined on the device: the count (preprocess) and the emit kernel must take bit-identical decisions, and
+// two inlined copies may be contracted into FMAs differently (seen once per ~8 M pairs).
+TRASE_HD_NOINLINE bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
   const float tau_raw = 2.0f * logf(255.0f * opacity);
   if (!(tau_raw >= 0.0f)) return false;   // opacity < 1/255 (or NaN): can never pass the gate
   const float tau = tau_raw * 1.001f + 1e-3f;

@@ -89,7 +89,12 @@ def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor
     return t.contiguous()
 
 
+_POISON = os.environ.get("TRASE_POISON", "0") != "0"   # debug: fill every workspace with 0xFF to expose reads of unwritten memory
+
+
 def _bytes(n: int, device) -> torch.Tensor:
+    if _POISON:
+        return torch.full((max(int(n), 1),), 255, dtype=torch.uint8, device=device)
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
 
@@ -99,7 +104,7 @@ def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _li
     s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
     s.scale_modifier = float(rs.scale_modifier)
     s.sh_degree = int(rs.sh_degree)
-    s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(rs.debug)   # debug=2 additionally names every kernel on stderr
     s.device = device.index if device.index is not None else torch.cuda.current_device()
     s.variant = _Policy.variant
     for name in ("bg", "viewmatrix", "projmatrix", "campos"):
