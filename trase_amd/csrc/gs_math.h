@@ -205,9 +205,13 @@ TRASE_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0,
 // float32 rounding difference can never drop a pair the compositing kernel would have blended).
 constexpr int SUB = 8;   // sub-tile edge
 
-// NOT inlined on the device: the count (preprocess) and the emit kernel must take bit-identical decisions, and
-// two inlined copies may be contracted into FMAs differently (seen once per ~8 M pairs).
-TRASE_HD_NOINLINE bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+// The count (preprocess) and the emit kernel must take bit-identical decisions.  Two inlined copies were once
+// contracted into FMAs differently (one pair in ~8 M disagreed), so contraction is switched off for this body:
+// every operation below is then an individually rounded IEEE op wherever the function is inlined.
+TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   const float tau_raw = 2.0f * logf(255.0f * opacity);
   if (!(tau_raw >= 0.0f)) return false;   // opacity < 1/255 (or NaN): can never pass the gate
   const float tau = tau_raw * 1.001f + 1e-3f;
