@@ -228,6 +228,30 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
                       float* d_xyz, float* d_rotation, float* d_scaling, void* ws, size_t ws_bytes, int32_t device,
                       trase_stream_t stream);
 
+/* Training pair (train.py:202-204 runs the MLP with gradients in the GAUSSIAN state; loss.backward() at
+ * train.py:299 reaches utils/time_utils.py:106-131 through autograd).
+ *   trase_mlp_forward_train: the same fused forward; additionally fills the opaque `saved` buffer (bf16
+ *     activations and encoding as transposed images, the ReLU gates as bits -- 4.2 KB per Gaussian).
+ *   trase_mlp_backward: from the cotangents of the three outputs (any may be NULL = zero) and `saved`, the
+ *     gradients of every parameter (fp32, overwritten; NULL entries are skipped).  Fused data chain on the
+ *     matrix cores, then one split-N MFMA GEMM per layer input and a partial-sum reduction.  x and t are
+ *     detached at the reference's call site, so nothing is propagated into the encoding. */
+typedef struct TraseMlpGrads {
+  float* weight[8];        /* same shapes as TraseMlpWeights */
+  float* bias[8];
+  float* w_warp;     float* b_warp;
+  float* w_rotation; float* b_rotation;
+  float* w_scaling;  float* b_scaling;
+} TraseMlpGrads;
+
+int trase_mlp_train_sizes(int32_t N, size_t* fwd_ws_bytes, size_t* saved_bytes, size_t* bwd_ws_bytes);
+int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                            float* d_xyz, float* d_rotation, float* d_scaling, void* saved, size_t saved_bytes,
+                            void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_xyz, const float* dL_dd_rotation,
+                       const float* dL_dd_scaling, const void* saved, size_t saved_bytes, const TraseMlpGrads* grads,
+                       void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

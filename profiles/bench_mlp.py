@@ -1,71 +1,79 @@
 #!/usr/bin/env python
-"""Secondary measurement (reported separately from views/s): the fused bf16-MFMA deformation MLP
-forward at N Gaussians vs the same network in PyTorch fp32 (what the reference runs).
-Algorithmic flops: 2 * 504 320 MAC/Gaussian = 1.009 MFLOP/Gaussian."""
+"""Secondary measurement (reported separately from views/s): the fused bf16-MFMA deformation MLP at N
+Gaussians -- inference forward and training forward+backward -- vs the same network in PyTorch fp32
+(what the reference runs).  Algorithmic flops: forward 2 * 504 320 MAC/Gaussian = 1.009 MFLOP/Gaussian
+(SURVEY.md 8d); backward = data chain (7 x 256 x 256 + 10 x 256 MAC) + parameter GEMMs (= forward MACs)."""
 import sys, os, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trase_amd.deform import deform_forward
+from trase_amd.synthetic import SynthDeformNetwork
 from trase_amd import rasterizer as R
 
 
-class RefNet(torch.nn.Module):       # same layer shapes as utils/time_utils.py:60-104
-    def __init__(self):
-        super().__init__()
-        self.linear = torch.nn.ModuleList([torch.nn.Linear(84, 256)] + [torch.nn.Linear(340 if i == 4 else 256, 256) for i in range(7)])
-        self.gaussian_warp = torch.nn.Linear(256, 3)
-        self.gaussian_rotation = torch.nn.Linear(256, 4)
-        self.gaussian_scaling = torch.nn.Linear(256, 3)
-
-    @staticmethod
-    def pe(v, nf):
-        out = [v]
-        for f in range(nf):
-            out += [torch.sin(v * 2.0 ** f), torch.cos(v * 2.0 ** f)]
-        return torch.cat(out, -1)
-
-    def forward(self, x, t):
-        e = torch.cat([self.pe(x, 10), self.pe(t, 10)], -1)
-        h = e
-        for i, l in enumerate(self.linear):
-            h = torch.relu(l(h))
-            if i == 4:
-                h = torch.cat([e, h], -1)
-        return self.gaussian_warp(h), self.gaussian_rotation(h), self.gaussian_scaling(h)
+def timed(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    net = RefNet().to(dev)
+    net = SynthDeformNetwork().to(dev)
     x = (torch.rand(n, 3, device=dev) * 2 - 1) * 1.3
     t = torch.tensor([[0.4]], device=dev).expand(n, -1)
+    tc = t.contiguous()
     params = dict(net.state_dict())
+    live = dict(net.named_parameters())
+    g = [torch.randn(n, c, device=dev) for c in (3, 4, 3)]
+
+    def train_hip():
+        net.zero_grad(set_to_none=True)
+        torch.autograd.backward(deform_forward(live, x, t), g)
+
+    def train_ref():
+        net.zero_grad(set_to_none=True)
+        torch.autograd.backward(net(x, tc), g)
+
     with torch.no_grad():
-        for _ in range(3):
-            a = deform_forward(params, x, t)
-            b = net(x, t.contiguous())
-        torch.cuda.synchronize()
+        a = deform_forward(params, x, t)
+        b = net(x, tc)
         err = max((u - v).abs().max().item() for u, v in zip(a, b))
+        t_hip = timed(lambda: deform_forward(params, x, t))
+        t_ref = timed(lambda: net(x, tc))
         R.profile_enable(1)
-        t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(5):
             deform_forward(params, x, t)
-        torch.cuda.synchronize()
-        t_hip = (time.perf_counter() - t0) / 10
         prof = R.profile_report(); R.profile_enable(0)
-        t0 = time.perf_counter()
-        for _ in range(10):
-            net(x, t.contiguous())
-        torch.cuda.synchronize()
-        t_ref = (time.perf_counter() - t0) / 10
+    tt_hip = timed(train_hip)
+    tt_ref = timed(train_ref)
+    R.profile_enable(1)
+    for _ in range(5):
+        train_hip()
+    tprof = R.profile_report(); R.profile_enable(0)
+    train_ref()
+    want = {k: p.grad.clone() for k, p in live.items()}
+    train_hip()
+    gerr = max(float((p.grad - want[k]).abs().max() / want[k].abs().max()) for k, p in live.items())
     flops = 2 * 504320 * n
+    bwd_data_flops = 2 * (7 * 256 * 256 + 16 * 256) * n
     k_ms = prof["mlp_fwd"]["ms"]
-    print(json.dumps({"n": n, "mlp_fwd_kernel_ms": round(k_ms, 4), "mlp_call_ms": round(t_hip * 1e3, 4),
-                      "tflops_kernel": round(flops / (k_ms * 1e-3) / 1e12, 2), "peak_bf16_tflops": 2500.0,
-                      "frac_mfma_peak": round(flops / (k_ms * 1e-3) / 2.5e15, 4),
-                      "torch_fp32_ms": round(t_ref * 1e3, 4), "max_abs_diff_vs_fp32": err}))
+    out = {"n": n, "mlp_fwd_kernel_ms": round(k_ms, 4), "mlp_call_ms": round(t_hip * 1e3, 4),
+           "tflops_kernel": round(flops / (k_ms * 1e-3) / 1e12, 2), "peak_bf16_tflops": 2500.0,
+           "frac_mfma_peak": round(flops / (k_ms * 1e-3) / 2.5e15, 4),
+           "torch_fp32_ms": round(t_ref * 1e3, 4), "max_abs_diff_vs_fp32": err,
+           "train_step_ms": round(tt_hip * 1e3, 4), "torch_fp32_train_step_ms": round(tt_ref * 1e3, 4),
+           "train_kernels_ms": {k: round(v["ms"], 4) for k, v in tprof.items()},
+           "bwd_data_tflops": round(bwd_data_flops / (tprof["mlp_bwd_data"]["ms"] * 1e-3) / 1e12, 2),
+           "max_rel_grad_diff_vs_fp32": gerr}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

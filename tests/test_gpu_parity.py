@@ -305,8 +305,76 @@ def test_deform_mlp_matches_reference_golden():
     with torch.no_grad():
         dx2, _, _ = deform_forward(params, x[:37], t[:37])
     assert torch.equal(dx2, dx[:37])
+    # training pair: parameter gradients for the golden cotangents (the reference's autograd, fp32).  The bf16
+    # network's ReLU gates differ from the fp32 network's wherever a pre-activation is within bf16 rounding of
+    # zero (~0.25 % of the units per layer); each flipped gate moves the back-propagated signal by its full value,
+    # so the distance to the fp32 gradient is a few percent in relative L2 per layer (the same holds for
+    # torch.autocast(bfloat16)).  The tight check against a bf16-evaluated reference is the next test.
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    dxg, drg, dsg = deform_forward(leaf, x, t)
+    assert torch.equal(dxg, dx) and torch.equal(drg, dr) and torch.equal(dsg, ds)
+    gx, gr, gs = (torch.from_numpy(d[k]).cuda() for k in ("gx", "gr", "gs"))
+    torch.autograd.backward((dxg, drg, dsg), (gx, gr, gs))
+    for k, p in leaf.items():
+        want = torch.from_numpy(d["grad_" + k]).cuda()
+        assert p.grad.shape == want.shape
+        rel = float((p.grad - want).norm() / want.norm())
+        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else 0.2)
+        assert rel < tol, f"grad {k}: relative L2 distance to the fp32 golden gradient {rel:.3e}"
     with pytest.raises(NotImplementedError):
-        deform_forward({k: v.clone().requires_grad_(True) for k, v in params.items()}, x, t)
+        deform_forward(leaf, x.clone().requires_grad_(True), t)
+
+
+def _bf16_evaluated_net(net, x, t):
+    """The same network evaluated the way the kernel evaluates it -- bf16 operands (encoding, weights, activations),
+    fp32 accumulation, fp32 bias -- with straight-through rounding so that PyTorch autograd yields the gradient of
+    exactly that computation."""
+    import torch.nn.functional as Fn
+
+    def rb(v):
+        return v + (v.to(torch.bfloat16).float() - v).detach()
+    e = rb(torch.cat([net.embed(x, 10), net.embed(t, 10)], -1))
+    h = e
+    for i, l in enumerate(net.linear):
+        h = rb(torch.relu(Fn.linear(h, rb(l.weight)) + l.bias))
+        if i == 4:
+            h = torch.cat([e, h], -1)
+    return tuple(Fn.linear(h, rb(m.weight)) + m.bias for m in (net.gaussian_warp, net.gaussian_rotation, net.gaussian_scaling))
+
+
+@pytest.mark.parametrize("n", [20_011, 77])
+def test_deform_mlp_training_step_matches_bf16_evaluated_autograd(n):
+    """Forward + backward of the fused MLP (trase_mlp_forward_train / trase_mlp_backward) against PyTorch autograd
+    of the same bf16-operand / fp32-accumulate evaluation (utils/time_utils.py:106-131 is the network).  Sizes span
+    many workgroups with a ragged last 32-row tile, and fewer rows than one workgroup.  Tolerance: 5e-2 relative
+    L2 and 1e-1 of the gradient's scale per element (the kernel also rounds the back-propagated signal to bf16
+    between layers; a handful of ReLU gates at |z| ~ 1e-7 may still differ).  One run gives only the d_xyz
+    cotangent (autograd passes zeros for the others)."""
+    from trase_amd.deform import DeformNetworkHIP
+    from trase_amd.synthetic import SynthDeformNetwork
+    torch.manual_seed(3)
+    net = SynthDeformNetwork().cuda()
+    x = (torch.rand(n, 3, device="cuda") * 2 - 1) * 1.3
+    t = torch.tensor([[0.61]], device="cuda").expand(n, -1)
+    wx, wr, ws = torch.randn(n, 3, device="cuda"), torch.randn(n, 4, device="cuda"), torch.randn(n, 3, device="cuda")
+    for use in ((1, 1, 1), (1, 0, 0)):
+        net.zero_grad()
+        a = _bf16_evaluated_net(net, x, t.contiguous())
+        sum(u * (v * w).sum() for u, v, w in zip(use, a, (wx, wr, ws))).backward()
+        want = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net.zero_grad()
+        b = DeformNetworkHIP(net)(x, t)
+        for u, v in zip(a, b):
+            assert float((u - v).detach().abs().max()) < 2e-3 * float(u.detach().abs().max()) + 1e-5
+        sum(u * (v * w).sum() for u, v, w in zip(use, b, (wx, wr, ws))).backward()
+        for k, p in net.named_parameters():
+            if float(want[k].abs().max()) == 0.0:
+                assert float(p.grad.abs().max()) == 0.0, k
+                continue
+            scale = float(want[k].abs().max())
+            err = float((p.grad - want[k]).abs().max())
+            rel = float((p.grad - want[k]).norm() / want[k].norm())
+            assert rel < 5e-2 and err < 1e-1 * scale + 1e-6, f"{use} grad {k}: rel L2 {rel:.3e}, max abs {err:.3e} vs scale {scale:.3e}"
 
 
 @pytest.mark.parametrize("with_deform", [False, True])

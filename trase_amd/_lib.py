@@ -96,6 +96,14 @@ class MlpWeights(C.Structure):
     ]
 
 
+class MlpGrads(C.Structure):
+    _fields_ = [
+        ("weight", C.c_void_p * 8), ("bias", C.c_void_p * 8),
+        ("w_warp", C.c_void_p), ("b_warp", C.c_void_p), ("w_rotation", C.c_void_p), ("b_rotation", C.c_void_p),
+        ("w_scaling", C.c_void_p), ("b_scaling", C.c_void_p),
+    ]
+
+
 # every symbol include/trase_rast.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("trase_rast_sizes", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(RastSizes)]),
@@ -121,6 +129,13 @@ SYMBOLS = [
     ("trase_mlp_sizes", C.c_int, [C.POINTER(C.c_size_t)]),
     ("trase_mlp_forward", C.c_int, [C.POINTER(MlpWeights), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_mlp_train_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("trase_mlp_forward_train", C.c_int, [C.POINTER(MlpWeights), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_mlp_backward", C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.POINTER(MlpGrads), C.c_void_p, C.c_size_t, C.c_int32,
+                                     C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),

@@ -6,11 +6,12 @@
 //   PE(x) 63 | PE(t) 21  -> 84 -> [Linear 256 + ReLU] x 8, layer 5 sees cat(PE, h) = 340 -> heads 3 | 4 | 3.
 // Fusion: a workgroup of 4 waves owns 128 Gaussians, each wave 32 rows.  Activations never leave the CU:
 // they live in LDS as bf16 (64 KiB, XOR-swizzled 16-byte chunks so that the row-per-lane fragment reads are
-// conflict free), the positional encoding is regenerated in registers whenever a layer consumes it (layer 0
-// and the skip layer), weights stream from L2 (1 MB of bf16 for the whole net), bias+ReLU+bf16 happen in the
-// MFMA epilogue.  Waves never synchronise with each other.
-// Forward only in this round (the FEATURE state, style transfer, render.py and the GUIs call the MLP under
-// torch.no_grad()); the training backward is listed under "next" in DESIGN.md.
+// conflict free), the positional encoding is generated once per wave into six register fragments, weights
+// stream from L2 (1 MB of bf16 for the whole net), bias (as the accumulator's initial value) + ReLU + bf16
+// happen in the MFMA epilogue.  Waves never synchronise with each other; two waves share a SIMD.
+// Training (GAUSSIAN state, train.py:202-204 / :299): the same forward additionally saves the activations as
+// "transposed images" and the ReLU gates as bits; the backward is a fused data chain of the same shape plus
+// split-N MFMA GEMMs for the parameter gradients (see "training backward" below).
 #include "common.h"
 
 namespace trase {
@@ -239,24 +240,63 @@ __device__ __forceinline__ void load_w4(bf16x8 (&w)[4], const __bf16* __restrict
     w[nb] = *reinterpret_cast<const bf16x8*>(W + ((size_t)kstep * MW + row_base + nb * 32 + m) * 16 + 8 * h);
 }
 
-template <int KS>
-__device__ __forceinline__ void emb_steps_rec(f32x16 (&acc)[4], const __bf16* __restrict__ W, int row_base, int m, int h,
-                                              float x0, float x1, float x2, float tt) {
-  if constexpr (KS < EMBP / 16) {
-    bf16x8 w[4];
-    load_w4(w, W, row_base, m, h, KS);
-    const bf16x8 a = pe_fragment_ct<KS>(h, x0, x1, x2, tt);
-    mma4(acc, w, a);
-    __builtin_amdgcn_sched_barrier(0);      // keep the 6 unrolled steps from hoisting all their loads (register blow-up)
-    emb_steps_rec<KS + 1>(acc, W, row_base, m, h, x0, x1, x2, tt);
+// positional-encoding K-steps of layers 0 and 5: the six fragments are computed once per wave and stay in registers
+__device__ __forceinline__ void emb_steps(f32x16 (&acc)[4], const __bf16* __restrict__ W, int row_base, int m, int h,
+                                          const bf16x8 (&pe)[EMBP / 16]) {
+  bf16x8 w0[4], w1[4];
+  load_w4(w0, W, row_base, m, h, 0);
+#pragma unroll
+  for (int ks = 0; ks < EMBP / 16; ks += 2) {
+    load_w4(w1, W, row_base, m, h, ks + 1);
+    mma4(acc, w0, pe[ks]);
+    if (ks + 2 < EMBP / 16) load_w4(w0, W, row_base, m, h, ks + 2);
+    mma4(acc, w1, pe[ks + 1]);
   }
 }
 
-__global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel_v3(MlpNet net, const float* __restrict__ x,
-                                                                    const float* __restrict__ t, int t_stride, int N,
-                                                                    float* __restrict__ d_xyz, float* __restrict__ d_rot,
-                                                                    float* __restrict__ d_scale) {
-  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
+template <int KS>
+__device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0, float x1, float x2, float tt) {
+  if constexpr (KS < EMBP / 16) {
+    pe[KS] = pe_fragment_ct<KS>(h, x0, x1, x2, tt);
+    pe_fill<KS + 1>(pe, h, x0, x1, x2, tt);
+  }
+}
+
+// ---- saved state of the training forward ---------------------------------------------------------------
+// "Transposed image" of an [N][M] bf16 matrix: [tile = row/32][column][row%32].  A 32x32x16 MFMA whose reduction
+// index is the ROW (the weight-gradient GEMMs dZ^T . input) then reads its operand fragments -- one column, 8
+// consecutive rows per lane -- as contiguous 16-byte loads.  The chain kernels hold lane = row, registers =
+// columns: a 4x4 transpose inside every lane quad (two DPP exchange rounds) turns "4 columns of my row" into
+// "4 rows of my column", and one store instruction of the wave covers 8 columns x 32 rows = 512 contiguous bytes.
+__device__ __forceinline__ void store_transposed(__bf16* __restrict__ img_tile, int f0, int m, s16x4 pk) {
+  const bool odd = m & 1, hi = m & 2;
+  unsigned d[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {        // round 1: lanes m^1 swap -> d[p] = column f0 + 2p + odd, rows (m&~1, m|1)
+    const unsigned a = (unsigned short)pk[2 * p], b = (unsigned short)pk[2 * p + 1];
+    const unsigned send = odd ? a : b;
+    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    d[p] = odd ? (recv | (b << 16)) : (a | (recv << 16));
+  }
+  // round 2: lanes m^2 swap -> column f0 + (m&3), rows (m&~3) .. +3
+  const unsigned send2 = hi ? d[0] : d[1];
+  const unsigned recv2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send2, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+  uint2 out;
+  out.x = hi ? recv2 : d[0];
+  out.y = hi ? d[1] : recv2;
+  // quad position q = m&3 owns column f0 + (q&1) + 2*(q>>1)... round 1 gave odd lanes the odd columns, round 2 the
+  // upper lane pair the columns +2: column = f0 + (m&1) + (m&2)
+  *reinterpret_cast<uint2*>(img_tile + (size_t)(f0 + (m & 3)) * 32 + (m & ~3)) = out;
+}
+
+// SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations
+// (input of the next layer's weight-gradient GEMM) and the ReLU gate as one bit per (row, feature)
+template <bool SAVE>
+__device__ __forceinline__ void mlp_fwd_body(__bf16 (*s_act)[MROWS * MW], const MlpNet& net, const float* __restrict__ x,
+                                             const float* __restrict__ t, int t_stride, int N,
+                                             float* __restrict__ d_xyz, float* __restrict__ d_rot,
+                                             float* __restrict__ d_scale, __bf16* __restrict__ actsT,
+                                             uint4* __restrict__ gates) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int row0 = (blockIdx.x * MWAVES + wave) * MROWS;
@@ -266,6 +306,8 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel_v3(MlpNet net, co
   const float x0 = x[3 * gm], x1 = x[3 * gm + 1], x2 = x[3 * gm + 2];
   const float tt = t[(size_t)gm * t_stride];
   __bf16* act = s_act[wave];
+  bf16x8 pe[EMBP / 16];
+  pe_fill<0>(pe, h, x0, x1, x2, tt);
   for (int l = 0; l < MD; ++l) {
     const bool has_emb = (l == 0 || l == SKIP);
     const int hid_steps = (l == 0) ? 0 : MW / 16;
@@ -273,16 +315,21 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel_v3(MlpNet net, co
     const __bf16* __restrict__ W = net.w[l];
     const float* __restrict__ B = net.b[l];
     s16x4 held[4][4];                                      // first half, packed bf16: [block][run of 4 features]
+    unsigned gate[4] = {0u, 0u, 0u, 0u};                   // SAVE: this lane's 128 ReLU gates of the layer
+    __bf16* const tileT = SAVE ? actsT + ((size_t)l * ((N + 31) >> 5) + (row0 >> 5)) * (MW * 32) : nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int row_base = half * 128;
       __builtin_amdgcn_sched_barrier(0);                  // the two halves must not be interleaved (register budget)
-      f32x16 acc[4];
+      f32x16 acc[4];                                       // accumulators start at the bias
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-      if (has_emb) emb_steps_rec<0>(acc, W, row_base, m, h, x0, x1, x2, tt);
+        for (int q = 0; q < 4; ++q) {
+          const float4 bias = *reinterpret_cast<const float4*>(B + row_base + nb * 32 + 8 * q + 4 * h);
+          acc[nb][4 * q + 0] = bias.x; acc[nb][4 * q + 1] = bias.y; acc[nb][4 * q + 2] = bias.z; acc[nb][4 * q + 3] = bias.w;
+        }
+      if (has_emb) emb_steps(acc, W, row_base, m, h, pe);
       if (hid_steps) {
         bf16x8 w0[4], w1[4];
         load_w4(w0, W, row_base, m, h, kst0);
@@ -301,17 +348,21 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel_v3(MlpNet net, co
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f0 = row_base + nb * 32 + 8 * q + 4 * h;
-          const float4 bias = *reinterpret_cast<const float4*>(B + f0);
           s16x4 pk;
-          pk[0] = bf16_bits(fmaxf(acc[nb][4 * q + 0] + bias.x, 0.f));
-          pk[1] = bf16_bits(fmaxf(acc[nb][4 * q + 1] + bias.y, 0.f));
-          pk[2] = bf16_bits(fmaxf(acc[nb][4 * q + 2] + bias.z, 0.f));
-          pk[3] = bf16_bits(fmaxf(acc[nb][4 * q + 3] + bias.w, 0.f));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = bf16_bits(fmaxf(acc[nb][4 * q + e], 0.f));
           if (half == 0) held[nb][q] = pk;                 // inputs are still needed by the second half
           else *reinterpret_cast<s16x4*>(act + act_off(m, f0)) = pk;
+          if constexpr (SAVE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gate[half * 2 + (nb >> 1)] |= (pk[e] & 0x7fff) ? 1u << ((nb & 1) * 16 + q * 4 + e) : 0u;
+            store_transposed(tileT, f0, m, grow < N ? pk : s16x4{0, 0, 0, 0});   // padding rows contribute nothing
+          }
         }
       }
     }
+    if constexpr (SAVE)
+      if (grow < N) gates[((size_t)l * N + grow) * 2 + h] = uint4{gate[0], gate[1], gate[2], gate[3]};
     // both halves have consumed the old tile: now the first half may land
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -346,6 +397,291 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel_v3(MlpNet net, co
   }
 }
 
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_kernel_v3(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                       float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
+  mlp_fwd_body<false>(s_act, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
+}
+
+// the training forward spends a third of its time draining the saved-state stores (vmcnt is shared by loads and
+// stores, so a wave waiting for its next weight fragment also waits for its stores): two waves per SIMD let one
+// wave compute while the other drains
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_train_kernel(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                          float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
+                          __bf16* __restrict__ actsT, uint4* __restrict__ gates) {
+  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
+  mlp_fwd_body<true>(s_act, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, gates);
+}
+
+// ---- training backward ------------------------------------------------------------------------------------
+// (1) data chain:  dZ_l = dH_l * [h_l > 0];  dH_{l-1} = dZ_l . W_l[:, hidden columns]  (x and t are detached at the
+//     call site, train.py:196-204 `deform.step(gaussians.get_xyz.detach(), time_input)`: nothing flows into the PE).
+//     Same fused structure as the forward: a wave owns 32 rows, the dZ tile lives in swizzled LDS, the TRANSPOSED
+//     weights stream K-slice-major from L2, lane = batch row.  Every dZ_l leaves as a transposed image.
+// (2) parameter gradients: dW_l = dZ_l^T . input_l, a GEMM whose reduction runs over the N rows.  A workgroup owns a
+//     contiguous range of row tiles and the whole M x NK output (accumulators never leave the registers), reads
+//     both operands as transposed images, and writes one fp32 partial; db_l comes from one extra MFMA against a
+//     fragment of ones.  (3) a small kernel sums the partials into the caller's gradient tensors.
+struct MlpNetT {
+  const __bf16* wt[MD];   // l >= 1: [256/16][256][16], wt[l][k'=feature f][n=input column j] = W_l[f][hidden_off + j]
+  const __bf16* wt_head;  // [1][256][16]: [n = j][k' = o] = W_head[o][j], o < 10
+};
+
+struct MlpPackTArgs {
+  const float* w[MD];
+  const float* w_warp; const float* w_rot; const float* w_scale;
+  __bf16* out_wt[MD]; __bf16* out_wth;
+};
+
+__global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
+  const int l = blockIdx.y;                    // 1..7 hidden layers, 0 = heads
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= 1) {
+    if (idx < MW * MW) {
+      const int f = idx / MW, j = idx % MW;
+      const int kin = l == SKIP ? EMB + MW : MW, off = l == SKIP ? EMB : 0;
+      a.out_wt[l][((size_t)(f >> 4) * MW + j) * 16 + (f & 15)] = (__bf16)a.w[l][f * kin + off + j];
+    }
+  } else if (idx < MW * 16) {
+    const int j = idx >> 4, o = idx & 15;
+    float v = 0.f;
+    if (o < 3) v = a.w_warp[o * MW + j];
+    else if (o < 7) v = a.w_rot[(o - 3) * MW + j];
+    else if (o < 10) v = a.w_scale[(o - 7) * MW + j];
+    a.out_wth[j * 16 + o] = (__bf16)v;
+  }
+}
+
+// transposed image of the bf16 positional encoding, [tile][96][32] (columns 84..95 and padding rows zero):
+// the GEMM input of layers 0 and 5
+__global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
+                                                     int N, __bf16* __restrict__ peT) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)((N + 31) >> 5) * EMBP * 32;
+  if (idx >= total) return;
+  const int r = (int)(idx & 31), c = (int)((idx >> 5) % EMBP);
+  const int row = (int)(idx / (EMBP * 32)) * 32 + r;
+  float v = 0.f;
+  if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride]);
+  peT[idx] = (__bf16)v;
+}
+
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_bwd_data_kernel(MlpNetT net, const float* __restrict__ g_xyz,
+                                                                      const float* __restrict__ g_rot,
+                                                                      const float* __restrict__ g_scale, int N,
+                                                                      const uint4* __restrict__ gates,
+                                                                      __bf16* __restrict__ dzT, __bf16* __restrict__ gT) {
+  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int row0 = (blockIdx.x * MWAVES + wave) * MROWS;
+  if (row0 >= N) return;
+  const int grow = row0 + m;
+  const int gm = min(grow, N - 1);
+  const bool live = grow < N;
+  const int tiles = (N + 31) >> 5, tile = row0 >> 5;
+  __bf16* act = s_act[wave];
+  // cotangent of the ten head outputs as one 16-wide K-step: columns 0-2 d_xyz, 3-6 rotation, 7-9 scaling
+  bf16x8 g8;
+  {
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    if (live) {
+      if (h == 0) {
+        if (g_xyz) { g[0] = g_xyz[3 * (size_t)gm]; g[1] = g_xyz[3 * (size_t)gm + 1]; g[2] = g_xyz[3 * (size_t)gm + 2]; }
+        if (g_rot) { g[3] = g_rot[4 * (size_t)gm]; g[4] = g_rot[4 * (size_t)gm + 1]; g[5] = g_rot[4 * (size_t)gm + 2]; g[6] = g_rot[4 * (size_t)gm + 3]; }
+        if (g_scale) g[7] = g_scale[3 * (size_t)gm];
+      } else if (g_scale) { g[0] = g_scale[3 * (size_t)gm + 1]; g[1] = g_scale[3 * (size_t)gm + 2]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g8[j] = (__bf16)g[j];
+    // transposed image of the cotangent, [tile][32 columns][32 rows] (columns 10..31 zero): operand of the head GEMM
+    __bf16* gt = gT + (size_t)tile * (HEADP * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gt[(8 * h + j) * 32 + m] = g8[j];
+      gt[(16 + 8 * h + j) * 32 + m] = (__bf16)0.f;
+    }
+  }
+  for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
+    const __bf16* __restrict__ W = (l == MD) ? net.wt_head : net.wt[l];
+    const uint4 gv = gates[((size_t)(l - 1) * N + gm) * 2 + h];
+    const unsigned gate[4] = {gv.x, gv.y, gv.z, gv.w};
+    __bf16* const tileT = dzT + ((size_t)(l - 1) * tiles + tile) * (MW * 32);
+    s16x4 held[4][4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row_base = half * 128;
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+      if (l == MD) {
+        bf16x8 w0[4];
+        load_w4(w0, W, row_base, m, h, 0);
+        mma4(acc, w0, g8);
+      } else {
+        bf16x8 w0[4], w1[4];
+        load_w4(w0, W, row_base, m, h, 0);
+        for (int ks = 0; ks < MW / 16; ks += 2) {
+          load_w4(w1, W, row_base, m, h, ks + 1);
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(act + act_off(m, ks * 16 + 8 * h));
+          mma4(acc, w0, a0);
+          if (ks + 2 < MW / 16) load_w4(w0, W, row_base, m, h, ks + 2);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(act + act_off(m, (ks + 1) * 16 + 8 * h));
+          mma4(acc, w1, a1);
+        }
+      }
+      // epilogue: ReLU gate recorded by the forward, bf16, LDS tile for the next stage + transposed image
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = row_base + nb * 32 + 8 * q + 4 * h;
+          const unsigned bits = live ? gate[half * 2 + (nb >> 1)] >> ((nb & 1) * 16 + q * 4) : 0u;
+          s16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (bits >> e & 1u) ? bf16_bits(acc[nb][4 * q + e]) : (short)0;
+          if (half == 0) held[nb][q] = pk;
+          else *reinterpret_cast<s16x4*>(act + act_off(m, f0)) = pk;
+          store_transposed(tileT, f0, m, pk);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<s16x4*>(act + act_off(m, nb * 32 + 8 * q + 4 * h)) = held[nb][q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+// ---- parameter-gradient GEMM: out[f][k] = sum over rows of A[row][f] * B[row][k] ------------------------------
+struct WgradJob {
+  const __bf16* A;     // transposed image, M columns
+  const __bf16* B;     // transposed image, NK columns
+  float* partial;      // [G][M][NK]
+  float* bias_partial; // [G][M] or null
+};
+constexpr int WG_MAX_JOBS = 8;
+struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
+
+// WM x WN waves (= 4), each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
+template <int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradJobs jobs, int tiles, int G) {
+  constexpr int M = WM * MB * 32, NK = WN * NB * 32;
+  const WgradJob job = jobs.j[blockIdx.y];
+  const int g = blockIdx.x;
+  const int t_begin = (int)((long long)tiles * g / G), t_end = (int)((long long)tiles * (g + 1) / G);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const bool do_bias = job.bias_partial != nullptr && wn == 0;
+  f32x16 acc[MB][NB], accb[MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[a][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // fragment (tile, K-step s): 8 consecutive rows 16s + 8h .. of column f
+  const __bf16* pa = job.A + (size_t)(wm * MB * 32 + i) * 32 + 8 * h;
+  const __bf16* pb = job.B + (size_t)(wn * NB * 32 + i) * 32 + 8 * h;
+  bf16x8 fa[2][MB], fb[2][NB];
+  auto load = [&](int buf, int step) {      // step = tile * 2 + s
+    const size_t ta = (size_t)(step >> 1) * (M * 32) + (step & 1) * 16;
+    const size_t tb = (size_t)(step >> 1) * (NK * 32) + (step & 1) * 16;
+#pragma unroll
+    for (int a = 0; a < MB; ++a) fa[buf][a] = *reinterpret_cast<const bf16x8*>(pa + ta + (size_t)a * 32 * 32);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fb[buf][b] = *reinterpret_cast<const bf16x8*>(pb + tb + (size_t)b * 32 * 32);
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][a], fb[buf][b], acc[a][b], 0, 0, 0);
+    if (do_bias)
+#pragma unroll
+      for (int a = 0; a < MB; ++a) accb[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][a], ones, accb[a], 0, 0, 0);
+  };
+  const int s_begin = 2 * t_begin, s_end = 2 * t_end;     // always an even number of steps
+  if (s_begin < s_end) load(0, s_begin);
+  for (int s = s_begin; s < s_end; s += 2) {
+    load(1, s + 1);
+    mma(0);
+    if (s + 2 < s_end) load(0, s + 2);
+    mma(1);
+  }
+  // D[f_local][k_local]: lane = k_local (+32 for the odd f quads), register r = f_local%4 + 4*(f_local/8)
+  float* out = job.partial + (size_t)g * M * NK;
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = (wm * MB + a) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        out[(size_t)f * NK + (wn * NB + b) * 32 + i] = acc[a][b][r];
+      }
+  if (do_bias && i == 0) {
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        job.bias_partial[(size_t)g * M + (wm * MB + a) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] = accb[a][r];
+  }
+}
+
+struct WreduceJob {
+  const float* partial; const float* bias_partial;   // [G][M][NK], [G][M] (or null)
+  float* out; float* bias_out;                        // out[f * stride + col_off + k], k < k_valid, f < m_valid
+  int M, NK, stride, col_off, k_valid, m_valid, G, head;
+  float* head_w[3]; float* head_b[3];                 // head job: rows 0-2 / 3-6 / 7-9 go to three tensors
+};
+constexpr int WR_MAX_JOBS = 12;
+struct WreduceJobs { WreduceJob j[WR_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
+  const WreduceJob job = jobs.j[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = job.M * job.NK;
+  if (idx < total) {
+    const int f = idx / job.NK, k = idx % job.NK;
+    if (f < job.m_valid && k < job.k_valid) {
+      float s = 0.f;
+      for (int g = 0; g < job.G; ++g) s += job.partial[(size_t)g * total + idx];
+      if (job.head) {
+        const int seg = f < 3 ? 0 : (f < 7 ? 1 : 2), base = f < 3 ? 0 : (f < 7 ? 3 : 7);
+        if (job.head_w[seg]) job.head_w[seg][(f - base) * job.stride + k] = s;
+      } else if (job.out) job.out[(size_t)f * job.stride + job.col_off + k] = s;
+    }
+  }
+  if (job.bias_partial && idx < job.m_valid) {
+    float s = 0.f;
+    for (int g = 0; g < job.G; ++g) s += job.bias_partial[(size_t)g * job.M + idx];
+    if (job.head) {
+      const int seg = idx < 3 ? 0 : (idx < 7 ? 1 : 2), base = idx < 3 ? 0 : (idx < 7 ? 3 : 7);
+      if (job.head_b[seg]) job.head_b[seg][idx - base] = s;
+    } else if (job.bias_out) job.bias_out[idx] = s;
+  }
+}
+
 static size_t mlp_ws_bytes() {
   size_t b = 0;
   for (int l = 0; l < MD; ++l) {
@@ -356,39 +692,68 @@ static size_t mlp_ws_bytes() {
   return b;
 }
 
-}  // namespace trase
+// ---- buffer plans of the training pair ---------------------------------------------------------------------
+struct MlpSaved {            // written by the training forward, read by the backward
+  __bf16* actsT; __bf16* peT; uint4* gates; size_t bytes;
+};
+static MlpSaved mlp_saved_plan(void* base, int N) {
+  const size_t tiles = (size_t)(N + 31) / 32;
+  char* c = (char*)base;
+  MlpSaved p;
+  p.actsT = (__bf16*)c; c += align_up(sizeof(__bf16) * MD * tiles * MW * 32);
+  p.peT = (__bf16*)c;   c += align_up(sizeof(__bf16) * tiles * EMBP * 32);
+  p.gates = (uint4*)c;  c += align_up(sizeof(uint4) * (size_t)MD * N * 2);
+  p.bytes = (size_t)(c - (char*)base);
+  return p;
+}
 
-using namespace trase;
+struct MlpBwdPlan {
+  __bf16* wt[MD]; __bf16* wt_head; __bf16* dzT; __bf16* gT;
+  float* part_hidden; float* bias_hidden;   // 7 jobs (layers 1..7): [7][Gh][256][256], [7][Gh][256]
+  float* part_pe; float* bias_pe;           // 2 jobs (layers 0, 5):  [2][Gp][256][96],  [Gp][256] (layer 0 only)
+  float* part_head; float* bias_head;       // 1 job:                 [Gd][32][256],     [Gd][32]
+  int Gh, Gp, Gd; size_t bytes;
+};
+static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
+  const size_t tiles = (size_t)(N + 31) / 32;
+  char* c = (char*)base;
+  MlpBwdPlan p;
+  p.wt[0] = nullptr;
+  for (int l = 1; l < MD; ++l) { p.wt[l] = (__bf16*)c; c += align_up(sizeof(__bf16) * (size_t)MW * MW); }
+  p.wt_head = (__bf16*)c; c += align_up(sizeof(__bf16) * (size_t)MW * 16);
+  p.dzT = (__bf16*)c; c += align_up(sizeof(__bf16) * MD * tiles * MW * 32);
+  p.gT = (__bf16*)c;  c += align_up(sizeof(__bf16) * tiles * HEADP * 32);
+  // one workgroup per CU for the big GEMMs (252 = 7 x 36), more and shorter ones for the narrow jobs
+  p.Gh = (int)(tiles < 36 ? tiles : 36); p.Gp = (int)(tiles < 128 ? tiles : 128); p.Gd = p.Gp;
+  if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
+  p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW * MW);
+  p.bias_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW);
+  p.part_pe = (float*)c;     c += align_up(sizeof(float) * 2 * (size_t)p.Gp * MW * EMBP);
+  p.bias_pe = (float*)c;     c += align_up(sizeof(float) * (size_t)p.Gp * MW);
+  p.part_head = (float*)c;   c += align_up(sizeof(float) * (size_t)p.Gd * HEADP * MW);
+  p.bias_head = (float*)c;   c += align_up(sizeof(float) * (size_t)p.Gd * HEADP);
+  p.bytes = (size_t)(c - (char*)base);
+  return p;
+}
 
-extern "C" {
-
-int trase_mlp_sizes(size_t* ws_bytes) {
-  if (!ws_bytes) { set_error("trase_mlp_sizes: null"); return TRASE_ERR_INVALID; }
-  *ws_bytes = mlp_ws_bytes();
+static int mlp_check_weights(const TraseMlpWeights* w, const char* who) {
+  if (!w) { set_error("%s: null weights", who); return TRASE_ERR_INVALID; }
+  if (w->D != MD || w->W != MW || w->xyz_multires != 10 || w->t_multires != 10 || w->is_blender || w->is_6dof) {
+    set_error("%s: only the default DeformNetwork (D=8, W=256, multires=10, t_multires=10, "
+              "not blender, not 6dof) is compiled in", who);
+    return TRASE_ERR_UNSUPPORTED;
+  }
+  for (int l = 0; l < MD; ++l)
+    if (!w->weight[l] || !w->bias[l]) { set_error("%s: null layer %d", who, l); return TRASE_ERR_INVALID; }
+  if (!w->w_warp || !w->b_warp || !w->w_rotation || !w->b_rotation || !w->w_scaling || !w->b_scaling) {
+    set_error("%s: null head", who); return TRASE_ERR_INVALID;
+  }
   return TRASE_OK;
 }
 
-int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
-                      float* d_xyz, float* d_rotation, float* d_scaling, void* ws, size_t ws_bytes, int32_t device,
-                      trase_stream_t stream_) {
-  if (!w || N < 0) { set_error("trase_mlp_forward: bad arguments"); return TRASE_ERR_INVALID; }
-  if (w->D != MD || w->W != MW || w->xyz_multires != 10 || w->t_multires != 10 || w->is_blender || w->is_6dof) {
-    set_error("trase_mlp_forward: only the default DeformNetwork (D=8, W=256, multires=10, t_multires=10, "
-              "not blender, not 6dof) is compiled in");
-    return TRASE_ERR_UNSUPPORTED;
-  }
-  if (N == 0) return TRASE_OK;
-  if (!x || !t || !d_xyz || !d_rotation || !d_scaling) { set_error("trase_mlp_forward: null pointer"); return TRASE_ERR_INVALID; }
-  for (int l = 0; l < MD; ++l)
-    if (!w->weight[l] || !w->bias[l]) { set_error("trase_mlp_forward: null layer %d", l); return TRASE_ERR_INVALID; }
-  if (!w->w_warp || !w->b_warp || !w->w_rotation || !w->b_rotation || !w->w_scaling || !w->b_scaling) {
-    set_error("trase_mlp_forward: null head"); return TRASE_ERR_INVALID;
-  }
-  if (!ws || ws_bytes < mlp_ws_bytes()) { set_error("trase_mlp_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
-  hipStream_t stream = (hipStream_t)stream_;
-  TRASE_CHECK(hipSetDevice(device));
+// pack the fp32 parameters into the forward layout inside `ws`
+static int mlp_pack_forward(const TraseMlpWeights* w, void* ws, MlpNet& net, hipStream_t stream) {
   MlpPackArgs pa;
-  MlpNet net;
   char* c = (char*)ws;
   for (int l = 0; l < MD; ++l) {
     const int kp = l == 0 ? EMBP : (l == SKIP ? EMBP + MW : MW);
@@ -405,6 +770,41 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((MW * (EMBP + MW) + 255) / 256, MD + 1), dim3(256), 0, stream, pa);
   }
   TRASE_POST_LAUNCH("mlp_pack", stream, 0);
+  return TRASE_OK;
+}
+
+}  // namespace trase
+
+using namespace trase;
+
+extern "C" {
+
+int trase_mlp_sizes(size_t* ws_bytes) {
+  if (!ws_bytes) { set_error("trase_mlp_sizes: null"); return TRASE_ERR_INVALID; }
+  *ws_bytes = mlp_ws_bytes();
+  return TRASE_OK;
+}
+
+int trase_mlp_train_sizes(int32_t N, size_t* fwd_ws_bytes, size_t* saved_bytes, size_t* bwd_ws_bytes) {
+  if (!fwd_ws_bytes || !saved_bytes || !bwd_ws_bytes || N < 0) { set_error("trase_mlp_train_sizes: bad arguments"); return TRASE_ERR_INVALID; }
+  *fwd_ws_bytes = mlp_ws_bytes();
+  *saved_bytes = mlp_saved_plan(nullptr, N).bytes;
+  *bwd_ws_bytes = mlp_bwd_plan(nullptr, N).bytes;
+  return TRASE_OK;
+}
+
+int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                      float* d_xyz, float* d_rotation, float* d_scaling, void* ws, size_t ws_bytes, int32_t device,
+                      trase_stream_t stream_) {
+  if (N < 0) { set_error("trase_mlp_forward: bad arguments"); return TRASE_ERR_INVALID; }
+  if (int rc = mlp_check_weights(w, "trase_mlp_forward")) return rc;
+  if (N == 0) return TRASE_OK;
+  if (!x || !t || !d_xyz || !d_rotation || !d_scaling) { set_error("trase_mlp_forward: null pointer"); return TRASE_ERR_INVALID; }
+  if (!ws || ws_bytes < mlp_ws_bytes()) { set_error("trase_mlp_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  MlpNet net;
+  if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
   const int rows_per_block = MWAVES * MROWS;
   {
     ProfScope ps("mlp_fwd", stream);
@@ -415,6 +815,129 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
       hipLaunchKernelGGL(mlp_fwd_kernel_v3, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
   }
   TRASE_POST_LAUNCH("mlp_fwd", stream, 0);
+  return TRASE_OK;
+}
+
+int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                            float* d_xyz, float* d_rotation, float* d_scaling, void* saved, size_t saved_bytes, void* ws,
+                            size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (N < 0) { set_error("trase_mlp_forward_train: bad arguments"); return TRASE_ERR_INVALID; }
+  if (int rc = mlp_check_weights(w, "trase_mlp_forward_train")) return rc;
+  if (N == 0) return TRASE_OK;
+  if (!x || !t || !d_xyz || !d_rotation || !d_scaling) { set_error("trase_mlp_forward_train: null pointer"); return TRASE_ERR_INVALID; }
+  if (!ws || ws_bytes < mlp_ws_bytes()) { set_error("trase_mlp_forward_train: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  const MlpSaved sv = mlp_saved_plan(saved, N);
+  if (!saved || saved_bytes < sv.bytes) { set_error("trase_mlp_forward_train: saved-state buffer too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  MlpNet net;
+  if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
+  {
+    ProfScope ps("mlp_pe", stream);
+    const size_t n = (size_t)((N + 31) / 32) * EMBP * 32;
+    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, N, sv.peT);
+  }
+  TRASE_POST_LAUNCH("mlp_pe", stream, 0);
+  const int rows_per_block = MWAVES * MROWS;
+  {
+    ProfScope ps("mlp_fwd_train", stream);
+    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
+    hipLaunchKernelGGL(mlp_fwd_train_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation,
+                       d_scaling, sv.actsT, sv.gates);
+  }
+  TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
+  return TRASE_OK;
+}
+
+int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_xyz, const float* dL_dd_rotation,
+                       const float* dL_dd_scaling, const void* saved, size_t saved_bytes, const TraseMlpGrads* grads,
+                       void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (N < 0 || !grads) { set_error("trase_mlp_backward: bad arguments"); return TRASE_ERR_INVALID; }
+  if (int rc = mlp_check_weights(w, "trase_mlp_backward")) return rc;
+  if (N == 0) { set_error("trase_mlp_backward: N == 0 (the caller zero-fills the gradients)"); return TRASE_ERR_INVALID; }
+  const MlpSaved sv = mlp_saved_plan(const_cast<void*>(saved), N);
+  if (!saved || saved_bytes < sv.bytes) { set_error("trase_mlp_backward: saved-state buffer too small"); return TRASE_ERR_WORKSPACE; }
+  const MlpBwdPlan bp = mlp_bwd_plan(ws, N);
+  if (!ws || ws_bytes < bp.bytes) { set_error("trase_mlp_backward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  const int tiles = (N + 31) / 32;
+  MlpPackTArgs pa;
+  MlpNetT net;
+  pa.out_wt[0] = nullptr; net.wt[0] = nullptr; pa.w[0] = nullptr;
+  for (int l = 1; l < MD; ++l) { pa.w[l] = w->weight[l]; pa.out_wt[l] = bp.wt[l]; net.wt[l] = bp.wt[l]; }
+  pa.out_wth = bp.wt_head; net.wt_head = bp.wt_head;
+  pa.w_warp = w->w_warp; pa.w_rot = w->w_rotation; pa.w_scale = w->w_scaling;
+  {
+    ProfScope ps("mlp_pack_t", stream);
+    hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(MW * MW / 256, MD), dim3(256), 0, stream, pa);
+  }
+  TRASE_POST_LAUNCH("mlp_pack_t", stream, 0);
+  {
+    ProfScope ps("mlp_bwd_data", stream);
+    const int rows_per_block = MWAVES * MROWS;
+    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
+    hipLaunchKernelGGL(mlp_bwd_data_kernel, grid, block, 0, stream, net, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling, N,
+                       (const uint4*)sv.gates, bp.dzT, bp.gT);
+  }
+  TRASE_POST_LAUNCH("mlp_bwd_data", stream, 0);
+  const size_t img = (size_t)tiles * MW * 32;              // one layer's transposed image, elements
+  WreduceJobs rj;
+  int nr = 0;
+  auto reduce_job = [&](const float* partial, const float* bias_partial, float* out, float* bias_out, int M, int NK,
+                        int stride, int col_off, int k_valid, int m_valid, int G) -> WreduceJob& {
+    WreduceJob& r = rj.j[nr++];
+    r.partial = partial; r.bias_partial = bias_partial; r.out = out; r.bias_out = bias_out;
+    r.M = M; r.NK = NK; r.stride = stride; r.col_off = col_off; r.k_valid = k_valid; r.m_valid = m_valid; r.G = G; r.head = 0;
+    for (int k = 0; k < 3; ++k) { r.head_w[k] = nullptr; r.head_b[k] = nullptr; }
+    return r;
+  };
+  {   // hidden inputs: layers 1..7, input = activations of layer l-1 (layer 5: columns 84.. of its 340-wide weight)
+    WgradJobs jobs;
+    for (int l = 1; l < MD; ++l) {
+      WgradJob& j = jobs.j[l - 1];
+      j.A = bp.dzT + (size_t)l * img; j.B = sv.actsT + (size_t)(l - 1) * img;
+      j.partial = bp.part_hidden + (size_t)(l - 1) * bp.Gh * MW * MW;
+      j.bias_partial = bp.bias_hidden + (size_t)(l - 1) * bp.Gh * MW;
+      const int kin = l == SKIP ? EMB + MW : MW;
+      reduce_job(j.partial, j.bias_partial, grads->weight[l], grads->bias[l], MW, MW, kin, l == SKIP ? EMB : 0, MW, MW, bp.Gh);
+    }
+    ProfScope ps("mlp_wgrad_hidden", stream);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, tiles, bp.Gh);
+  }
+  TRASE_POST_LAUNCH("mlp_wgrad_hidden", stream, 0);
+  {   // encoding inputs: layer 0 and the first 84 columns of the skip layer
+    WgradJobs jobs;
+    const int ls[2] = {0, SKIP};
+    for (int k = 0; k < 2; ++k) {
+      WgradJob& j = jobs.j[k];
+      j.A = bp.dzT + (size_t)ls[k] * img; j.B = sv.peT;
+      j.partial = bp.part_pe + (size_t)k * bp.Gp * MW * EMBP;
+      j.bias_partial = k == 0 ? bp.bias_pe : nullptr;
+      reduce_job(j.partial, j.bias_partial, grads->weight[ls[k]], k == 0 ? grads->bias[0] : nullptr, MW, EMBP,
+                 k == 0 ? EMB : EMB + MW, 0, EMB, MW, bp.Gp);
+    }
+    ProfScope ps("mlp_wgrad_pe", stream);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, tiles, bp.Gp);
+  }
+  TRASE_POST_LAUNCH("mlp_wgrad_pe", stream, 0);
+  {   // heads: cotangent image (32 padded columns) x activations of the last layer
+    WgradJobs jobs;
+    WgradJob& j = jobs.j[0];
+    j.A = bp.gT; j.B = sv.actsT + (size_t)(MD - 1) * img; j.partial = bp.part_head; j.bias_partial = bp.bias_head;
+    WreduceJob& r = reduce_job(j.partial, j.bias_partial, nullptr, nullptr, HEADP, MW, MW, 0, MW, 10, bp.Gd);
+    r.head = 1;
+    r.head_w[0] = grads->w_warp; r.head_w[1] = grads->w_rotation; r.head_w[2] = grads->w_scaling;
+    r.head_b[0] = grads->b_warp; r.head_b[1] = grads->b_rotation; r.head_b[2] = grads->b_scaling;
+    ProfScope ps("mlp_wgrad_head", stream);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, tiles, bp.Gd);
+  }
+  TRASE_POST_LAUNCH("mlp_wgrad_head", stream, 0);
+  {
+    ProfScope ps("mlp_wreduce", stream);
+    hipLaunchKernelGGL(mlp_wreduce_kernel, dim3(MW * MW / 256, nr), dim3(256), 0, stream, rj);
+  }
+  TRASE_POST_LAUNCH("mlp_wreduce", stream, 0);
   return TRASE_OK;
 }
 

@@ -3,9 +3,20 @@ scene/deform_model.py:26-57 ``DeformModel.step``) on the bf16 matrix cores.
 
 ``deform_forward(state_dict, x, t)`` takes the reference network's parameters as they are
 (``linear.{i}.weight/bias``, ``gaussian_warp/rotation/scaling.weight/bias``) and returns
-``(d_xyz, d_rotation, d_scaling)`` like ``DeformNetwork.forward``.  Forward only: the call sites that
-run under ``torch.no_grad()`` (FEATURE state train.py:200-202, style transfer
-train_style_transfer_nnfm.py:184-185, render.py:195, gui.py:965)."""
+``(d_xyz, d_rotation, d_scaling)`` like ``DeformNetwork.forward``.
+
+* Under ``torch.no_grad()`` (FEATURE state train.py:200-202, style transfer
+  train_style_transfer_nnfm.py:184-185, render.py:195, gui.py:965) it is one fused kernel
+  (``trase_mlp_forward``).
+* With gradients (GAUSSIAN state, train.py:202-204 + ``loss.backward()`` train.py:299) it is an autograd
+  function over two C entry points: ``trase_mlp_forward_train`` (the fused forward, keeping bf16 activations
+  and the ReLU gates) and ``trase_mlp_backward`` (fused data chain + split-N MFMA GEMMs for every parameter
+  gradient).  The reference detaches ``x`` and ``t`` before the call, so no gradient is produced for them.
+
+Numerics: bf16 operands, fp32 accumulation (the north star asks for a bf16 MFMA GEMM here).  The gradients are
+the exact gradients of that bf16-evaluated network up to bf16 rounding of the back-propagated signal; against
+fp32 autograd of the same parameters they differ by a few percent in relative L2, because ReLU gates whose
+pre-activation is within bf16 rounding of zero open or close differently (same effect as torch.autocast)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,21 +28,15 @@ import torch
 from . import _lib
 from .rasterizer import _bytes, _stream
 
+PARAM_KEYS = tuple(k for i in range(8) for k in (f"linear.{i}.weight", f"linear.{i}.bias")) + (
+    "gaussian_warp.weight", "gaussian_warp.bias", "gaussian_rotation.weight", "gaussian_rotation.bias",
+    "gaussian_scaling.weight", "gaussian_scaling.bias")
+_EMB = 84
 
-def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
-                   is_blender: bool = False, is_6dof: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    if x.device.type != "cuda":
-        raise RuntimeError("deform_forward runs on the GPU only (there is no CPU path)")
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params.values())):
-        raise NotImplementedError("trase_amd.deform: forward-only kernel; call it under torch.no_grad() "
-                                  "(the training backward of the MLP is not built yet)")
-    lib = _lib.load()
-    dev = x.device
-    n = x.shape[0]
-    keep = []
 
-    def P(name):
-        v = params[name].detach()
+def _fill_weights(tensors, dev, keep, is_blender=False, is_6dof=False) -> "_lib.MlpWeights":
+    def P(i):
+        v = tensors[i].detach()
         if v.device != dev or v.dtype != torch.float32 or not v.is_contiguous():
             v = v.to(dev, torch.float32).contiguous()
         keep.append(v)
@@ -42,15 +47,19 @@ def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch
     w.is_blender, w.is_6dof = int(is_blender), int(is_6dof)
     w.variant = int(os.environ.get("TRASE_MLP_VARIANT", "0"), 0)
     for i in range(8):
-        wt, bs = P(f"linear.{i}.weight"), P(f"linear.{i}.bias")
-        want = (256, 84) if i == 0 else ((256, 340) if i == 5 else (256, 256))
+        wt, bs = P(2 * i), P(2 * i + 1)
+        want = (256, _EMB) if i == 0 else ((256, _EMB + 256) if i == 5 else (256, 256))
         if tuple(wt.shape) != want:
             raise ValueError(f"linear.{i}.weight has shape {tuple(wt.shape)}, the compiled network expects {want}")
         w.weight[i], w.bias[i] = wt.data_ptr(), bs.data_ptr()
-    w.w_warp, w.b_warp = P("gaussian_warp.weight").data_ptr(), P("gaussian_warp.bias").data_ptr()
-    w.w_rotation, w.b_rotation = P("gaussian_rotation.weight").data_ptr(), P("gaussian_rotation.bias").data_ptr()
-    w.w_scaling, w.b_scaling = P("gaussian_scaling.weight").data_ptr(), P("gaussian_scaling.bias").data_ptr()
+    w.w_warp, w.b_warp = P(16).data_ptr(), P(17).data_ptr()
+    w.w_rotation, w.b_rotation = P(18).data_ptr(), P(19).data_ptr()
+    w.w_scaling, w.b_scaling = P(20).data_ptr(), P(21).data_ptr()
+    return w
 
+
+def _prep_xt(x, t):
+    n = x.shape[0]
     xs = x.detach().float().contiguous()
     # the reference passes fid.unsqueeze(0).expand(N, -1): a stride-0 view (train.py:196) -- keep it that way
     tt = t.detach().float()
@@ -59,28 +68,102 @@ def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch
     else:
         tt = tt.reshape(n).contiguous()
         t_stride = 1
+    return xs, tt, t_stride
+
+
+def _dev_index(dev):
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+class _DeformMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, *params):
+        lib = _lib.load()
+        dev = x.device
+        n = x.shape[0]
+        keep = []
+        w = _fill_weights(params, dev, keep)
+        xs, tt, t_stride = _prep_xt(x, t)
+        d_xyz = torch.empty(n, 3, device=dev)
+        d_rot = torch.empty(n, 4, device=dev)
+        d_scale = torch.empty(n, 3, device=dev)
+        ws_b, saved_b, bwd_b = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _lib.check(lib.trase_mlp_train_sizes(n, C.byref(ws_b), C.byref(saved_b), C.byref(bwd_b)), "trase_mlp_train_sizes")
+        ws = _bytes(ws_b.value, dev)
+        saved = _bytes(saved_b.value, dev)
+        _lib.check(lib.trase_mlp_forward_train(C.byref(w), _lib.ptr(xs), C.c_void_p(tt.data_ptr()), t_stride, n,
+                                               _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scale), _lib.ptr(saved),
+                                               saved.numel(), _lib.ptr(ws), ws.numel(), _dev_index(dev), _stream(dev)),
+                   "trase_mlp_forward_train")
+        ctx.save_for_backward(saved, *params)
+        ctx.n = n
+        ctx.bwd_bytes = bwd_b.value
+        return d_xyz, d_rot, d_scale
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_scale):
+        lib = _lib.load()
+        saved, *params = ctx.saved_tensors
+        dev = saved.device
+        n = ctx.n
+        need = ctx.needs_input_grad[2:]
+        if n == 0:
+            return (None, None, *[torch.zeros_like(p) if nd else None for p, nd in zip(params, need)])
+        keep = []
+        w = _fill_weights(params, dev, keep)
+        g_xyz, g_rot, g_scale = (None if g is None else g.float().contiguous() for g in (g_xyz, g_rot, g_scale))
+        out = [torch.empty(p.shape, dtype=torch.float32, device=dev) if nd else None for p, nd in zip(params, need)]
+        gr = _lib.MlpGrads()
+        for i in range(8):
+            gr.weight[i] = out[2 * i].data_ptr() if out[2 * i] is not None else None
+            gr.bias[i] = out[2 * i + 1].data_ptr() if out[2 * i + 1] is not None else None
+        gr.w_warp, gr.b_warp, gr.w_rotation, gr.b_rotation, gr.w_scaling, gr.b_scaling = (
+            (o.data_ptr() if o is not None else None) for o in out[16:22])
+        ws = _bytes(ctx.bwd_bytes, dev)
+        _lib.check(lib.trase_mlp_backward(C.byref(w), n, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(g_scale),
+                                          _lib.ptr(saved), saved.numel(), C.byref(gr), _lib.ptr(ws), ws.numel(),
+                                          _dev_index(dev), _stream(dev)), "trase_mlp_backward")
+        return (None, None, *out)
+
+
+def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
+                   is_blender: bool = False, is_6dof: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    if x.device.type != "cuda":
+        raise RuntimeError("deform_forward runs on the GPU only (there is no CPU path)")
+    tensors = [params[k] for k in PARAM_KEYS]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in tensors):
+        if is_blender or is_6dof:
+            raise NotImplementedError("trase_amd.deform: only the default DeformNetwork variant is compiled in")
+        if x.requires_grad or t.requires_grad:
+            raise NotImplementedError("trase_amd.deform: x and t are detached inputs in the reference "
+                                      "(scene/deform_model.py:34-35 called at train.py:202-204); no gradient is produced for them")
+        return _DeformMLP.apply(x, t, *tensors)
+    lib = _lib.load()
+    dev = x.device
+    n = x.shape[0]
+    keep = []
+    w = _fill_weights(tensors, dev, keep, is_blender, is_6dof)
+    xs, tt, t_stride = _prep_xt(x, t)
     d_xyz = torch.empty(n, 3, device=dev)
     d_rot = torch.empty(n, 4, device=dev)
     d_scale = torch.empty(n, 3, device=dev)
     nbytes = C.c_size_t()
     _lib.check(lib.trase_mlp_sizes(C.byref(nbytes)), "trase_mlp_sizes")
     ws = _bytes(nbytes.value, dev)
-    d = dev.index if dev.index is not None else torch.cuda.current_device()
     _lib.check(lib.trase_mlp_forward(C.byref(w), _lib.ptr(xs), C.c_void_p(tt.data_ptr()), t_stride, n, _lib.ptr(d_xyz),
-                                     _lib.ptr(d_rot), _lib.ptr(d_scale), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
-               "trase_mlp_forward")
+                                     _lib.ptr(d_rot), _lib.ptr(d_scale), _lib.ptr(ws), ws.numel(), _dev_index(dev),
+                                     _stream(dev)), "trase_mlp_forward")
     return d_xyz, d_rot, d_scale
 
 
 class DeformNetworkHIP(torch.nn.Module):
-    """Wraps a reference-shaped ``DeformNetwork`` (anything whose state_dict has the reference's keys) and
-    evaluates ``forward(x, t)`` with the fused kernel when gradients are off."""
+    """Wraps a reference-shaped ``DeformNetwork`` (anything whose parameters carry the reference's names) and
+    evaluates ``forward(x, t)`` with the fused kernels, with or without gradients."""
 
     def __init__(self, net: torch.nn.Module):
         super().__init__()
         self.net = net
 
     def forward(self, x, t):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            return self.net(x, t)          # training: the reference's own PyTorch module
-        return deform_forward(dict(self.net.state_dict()), x, t)
+        params = dict(self.net.named_parameters())
+        return deform_forward(params, x, t)

@@ -193,3 +193,34 @@ class SynthPipe:
     convert_SHs_python = False
     compute_cov3D_python = False
     debug = False
+
+
+class SynthDeformNetwork(torch.nn.Module):
+    """Random-init network with the layer shapes and parameter names of the reference's ``DeformNetwork``
+    (utils/time_utils.py:60-104, default TRASE config: D=8, W=256, multires=10, t_multires=10, skip at layer 4's
+    output).  A parameter holder for benches and tests; its eager fp32 ``forward`` is the "what the reference
+    runs" comparison leg, never the product path (that is ``trase_amd.deform.deform_forward``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.linear = torch.nn.ModuleList(
+            [torch.nn.Linear(84, 256)] + [torch.nn.Linear(340 if i == 4 else 256, 256) for i in range(7)])
+        self.gaussian_warp = torch.nn.Linear(256, 3)
+        self.gaussian_rotation = torch.nn.Linear(256, 4)
+        self.gaussian_scaling = torch.nn.Linear(256, 3)
+
+    @staticmethod
+    def embed(v, nf):
+        out = [v]
+        for f in range(nf):
+            out += [torch.sin(v * 2.0 ** f), torch.cos(v * 2.0 ** f)]
+        return torch.cat(out, -1)
+
+    def forward(self, x, t):
+        e = torch.cat([self.embed(x, 10), self.embed(t, 10)], -1)
+        h = e
+        for i, l in enumerate(self.linear):
+            h = torch.relu(l(h))
+            if i == 4:
+                h = torch.cat([e, h], -1)
+        return self.gaussian_warp(h), self.gaussian_rotation(h), self.gaussian_scaling(h)
