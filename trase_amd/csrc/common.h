@@ -85,6 +85,34 @@ __device__ __forceinline__ float wave_scan_add_asm(float v) {
   return v;
 }
 
+// Two independent scans interleaved: the partner's instruction is one of the two wait states a DPP read needs after
+// the VALU write of its source, so a step costs 2 DPP + one s_nop 0 instead of 2 DPP + two s_nop 1.
+#define TRASE_SCAN2_STEP(OP, CTRL)                         \
+  OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void wave_scan_mul2_asm(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               TRASE_SCAN2_STEP("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_mul_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "v_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_mul_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wave_scan_add2_asm(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(a), "+v"(b));
+}
+#undef TRASE_SCAN2_STEP
+
 // ---- per-(sub-tile, Gaussian) blend exponent --------------------------------------------------
 // alpha_raw = opacity * exp(power) is evaluated as exp2(e) with
 //   e(j,i) = log2(e) * power + log2(opacity),   (j,i) = pixel coordinates inside the 8x8 sub-tile,
@@ -219,7 +247,8 @@ size_t img_bytes(int W, int H);
 size_t pre_bytes(int P);
 size_t tmp_bytes(int64_t cap);
 size_t bwd_tmp_bytes(int P, int F, int64_t cap);
-static inline int bwd_row_floats(int F) { return F + 16; }   // per-pair gradient row: F features + 10 scalars, 16-B aligned
+static inline int bwd_row_floats(int F) { return F + 16; }
+static inline size_t bwd_chan_bytes(int P) { return (size_t)P * 96 * 2; }   // render_bwd_mf.hip: [P][hi 48 | lo 48] bf16   // per-pair gradient row: F features + 10 scalars, 16-B aligned
 GeomBuf carve_geom(void* p, int P);
 BinBuf carve_bin(void* p, int64_t cap, int T);
 ImgBuf carve_img(void* p, int W, int H);
@@ -265,6 +294,9 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im);
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
+int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
+                         void* chan);
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

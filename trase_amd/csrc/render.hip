@@ -55,9 +55,10 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
   float T = 1.0f;
   uint32_t last = 0;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
-  float fa[F > 0 ? F : 1];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 fa2[F > 0 ? F / 2 : 1];                          // channel pairs: one v_pk_fma_f32 per pair
 #pragma unroll
-  for (int c = 0; c < F; ++c) fa[c] = 0.f;
+  for (int c = 0; c < F / 2; ++c) fa2[c] = f32x2{0.f, 0.f};
   // a finished pixel (outside the image, or transmittance exhausted) is encoded as live == 0
   float live = inside ? 1.0f : 0.0f;
   for (uint32_t base = range.x; base < range.y; base += WAVE) {
@@ -91,10 +92,11 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
         if (F > 0) {
           // wave-uniform row: read it through the scalar cache (constant address space => s_load)
           const uint32_t id = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
-          typedef __attribute__((address_space(4))) const float cfloat;
-          cfloat* f = (cfloat*)(a.feats + (size_t)id * F);
+          typedef __attribute__((address_space(4))) const f32x2 cfloat2;
+          cfloat2* f = (cfloat2*)(a.feats + (size_t)id * F);
+          const f32x2 w2 = {w, w};
 #pragma unroll
-          for (int c = 0; c < F; ++c) fa[c] = fmaf(w, f[c], fa[c]);
+          for (int c = 0; c < F / 2; ++c) fa2[c] = __builtin_elementwise_fma(w2, f[c], fa2[c]);
         }
         T = ok ? test_T : T;
         last = ok ? (base - range.x + j + 1) : last;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
     out_img[2 * hw + pix] = c2 + T * a.bg[2];
     out_depth[pix] = cd;
 #pragma unroll
-    for (int c = 0; c < F; ++c) out_feat[(size_t)c * hw + pix] = fa[c];
+    for (int c = 0; c < F; ++c) out_feat[(size_t)c * hw + pix] = fa2[c >> 1][c & 1];
   }
 }
 
