@@ -100,6 +100,20 @@ __device__ __forceinline__ void wave_scan_mul2_asm(float& a, float& b) {
                "v_mul_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
                : "+v"(a), "+v"(b));
 }
+// Inclusive add-scans of a and b into fresh registers: with bound_ctrl:0 a lane without a source reads 0, the
+// identity, so the first step needs no copy of the inputs (they stay live for the caller).
+__device__ __forceinline__ void wave_scan_add2_out_asm(float a, float b, float& oa, float& ob) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 0\n\t"
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               TRASE_SCAN2_STEP("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "=&v"(oa), "=&v"(ob) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void wave_scan_add2_asm(float& a, float& b) {
   asm volatile("s_nop 1\n\t"
                TRASE_SCAN2_STEP("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")

@@ -17,8 +17,8 @@
 //     Gaussian to the lane that owns it (lane l owns Gaussian l of the chunk).
 //   * w: after every 16 pixels the lane's 16 weights are split, packed and swapped into the two A fragments of
 //     GEMM 2; the matching cot^T fragments (8 consecutive pixels of one channel) are gathered from the pixel-major
-//     LDS image with ds_read_u16_d16(_hi).  D[g][c] has lane = channel: a store instruction writes two 128-byte
-//     row segments.
+//     LDS image with 16-bit reads.  The product is taken as cot^T x w^T, so the result has lane = Gaussian and a lane
+//     stores 16-byte pieces of its own gradient row.
 #include "common.h"
 
 namespace trase {
@@ -98,8 +98,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
   constexpr int F = 32, ROW = F + 16;
   __shared__ __attribute__((aligned(16))) __bf16 s_hi[MF_WPB][WAVE * MF_LD];   // cotangents, pixel-major, high parts
   __shared__ __attribute__((aligned(16))) __bf16 s_lo[MF_WPB][WAVE * MF_LD];   // low parts
-  __shared__ __attribute__((aligned(16))) float4 s_pix[MF_WPB][WAVE];          // T_end, U_end, last (bits) per pixel |
-                                                                               // .w: row slot of chunk entry (bits)
+  __shared__ __attribute__((aligned(16))) float4 s_pix[MF_WPB][WAVE];          // T_end, U_end, last (bits), -
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
@@ -162,7 +161,6 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
     const uint32_t pos = lane_valid ? (c1 - 1 - lane) : 0;     // lane 0 = farthest entry of the chunk
     const uint32_t id = a.point_list[range.x + pos];
     const uint32_t slot = lane_valid ? a.pair_slot[range.x + pos] : 0xffffffffu;
-    s_pix[wave][lane].w = __uint_as_float(slot);
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
     const PairPoly k = pair_poly(gxy, co, bx, by);
@@ -234,17 +232,17 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           const float ra = __builtin_amdgcn_exp2f(oka ? ea : -INFINITY);   // opacity * exp(power)
           const float rb = __builtin_amdgcn_exp2f(okb ? eb : -INFINITY);
           const float ala = fminf(ALPHA_MAX, ra), alb = fminf(ALPHA_MAX, rb);
-          float Pa = 1.0f - ala, Pb = 1.0f - alb;
-          const float roma = __builtin_amdgcn_rcpf(Pa), romb = __builtin_amdgcn_rcpf(Pb);
+          // T = T_end / prod(1 - alpha) as T_end * prod(1 / (1 - alpha)): the reciprocal is needed anyway (dL/dalpha)
+          const float roma = __builtin_amdgcn_rcpf(1.0f - ala), romb = __builtin_amdgcn_rcpf(1.0f - alb);
+          float Pa = roma, Pb = romb;
           wave_scan_mul2_asm(Pa, Pb);
-          const float Ta = pa.x * __builtin_amdgcn_rcpf(Pa);   // transmittance in front of this Gaussian
-          const float Tb = pb.x * __builtin_amdgcn_rcpf(Pb);
+          const float Ta = pa.x * Pa, Tb = pb.x * Pb;     // transmittance in front of this Gaussian
           wa = ala * Ta; wb = alb * Tb;
           const float sa = (j < 4 ? Sx : Sy)[4 * (i & 3) + (j & 3)];
           const float sb = (j < 4 ? Sx : Sy)[4 * (i & 3) + ((j + 1) & 3)];
           const float wsa = wa * sa, wsb = wb * sb;
-          float ia = wsa, ib = wsb;
-          wave_scan_add2_asm(ia, ib);
+          float ia, ib;
+          wave_scan_add2_out_asm(wsa, wsb, ia, ib);
           const float Ua = pa.y + (ia - wsa), Ub = pb.y + (ib - wsb);
           const float dLa = Ta * sa - Ua * roma, dLb = Tb * sb - Ub * romb;
           if (lane == WAVE - 1) {                        // carries for the next (nearer) chunk
@@ -291,9 +289,10 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
         for (int gb = 0; gb < 2; ++gb)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[gb], Bh[nb], D[gb][nb], 0, 0, 0);
-            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[gb], Bl[nb], D[gb][nb], 0, 0, 0);
-            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[gb], Bh[nb], D[gb][nb], 0, 0, 0);
+            // rows = channels (cot^T fragment), columns = Gaussians (weight fragment): the result has lane = Gaussian
+            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bh[nb], Ah[gb], D[gb][nb], 0, 0, 0);
+            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bl[nb], Ah[gb], D[gb][nb], 0, 0, 0);
+            D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bh[nb], Al[gb], D[gb][nb], 0, 0, 0);
           }
       }
     }
@@ -316,21 +315,27 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
       *reinterpret_cast<float4*>(row + 12) = make_float4(0.f, 0.f, 0.f, 0.f);
       a.row_flags[slot] = 1;
     }
-    wave_lds_sync3();                                     // s_slot written above, carries written by lane 63
-    // D[gb][nb]: lane (m, h) = channel nb*32 + m, register 4q + r = Gaussian gb*32 + 8q + 4h + r
+    // D[gb][nb]: lane (m, h) = Gaussian gb*32 + m, register 4q + r = channel nb*32 + 8q + 4h + r: four consecutive
+    // channels per register quad.  The slot of Gaussian gb*32 + m comes from its owner lane with one swap.
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(slot, slot, false, false);
+      const uint32_t sl[2] = {sw[0], sw[1]};           // slots of Gaussians m and 32 + m
 #pragma unroll
-    for (int gb = 0; gb < 2; ++gb)
+      for (int gb = 0; gb < 2; ++gb) {
+        if (sl[gb] != 0xffffffffu) {
+          float* row = a.rows + (size_t)sl[gb] * ROW;
 #pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int gl = gb * 32 + 8 * (r16 >> 2) + 4 * h + (r16 & 3);
-        const uint32_t sl = __float_as_uint(s_pix[wave][gl].w);
-        if (sl != 0xffffffffu) {
-          float* row = a.rows + (size_t)sl * ROW;
-          row[m] = D[gb][0][r16];
-          if (m < 4) row[F + 6 + m] = D[gb][1][r16];     // r g b depth sums
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(row + 8 * q + 4 * h) =
+                make_float4(D[gb][0][4 * q], D[gb][0][4 * q + 1], D[gb][0][4 * q + 2], D[gb][0][4 * q + 3]);
+          if (h == 0) {                                  // channels 32..35: r g b depth sums
+            *reinterpret_cast<float2*>(row + F + 6) = make_float2(D[gb][1][0], D[gb][1][1]);
+            *reinterpret_cast<float2*>(row + F + 8) = make_float2(D[gb][1][2], D[gb][1][3]);
+          }
         }
       }
-    wave_lds_sync3();                                     // s_slot is rewritten by the next chunk
+    }
+    wave_lds_sync3();                                     // carries written by lane 63 are read by the next chunk
   }
 }
 
