@@ -65,8 +65,10 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
     if (!__any(live != 0.0f)) break;
     const uint32_t n = min((uint32_t)WAVE, range.y - base);
     wave_lds_sync();
+    uint32_t my_id = 0;                                  // lane = list entry: kept for v_readlane in the blend loop
     if ((uint32_t)lane < n) {
       const uint32_t id = a.point_list[base + lane];
+      my_id = id;
       const PairPoly k = pair_poly(a.xy[id], a.conic_o[id], bx, by);
       s_k0[wave][lane] = make_float4(k.k0, k.kj, k.ki, k.kjj);
       s_k1[wave][lane] = make_float4(k.kii, k.kij, k.thr, __uint_as_float(id));
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
         c0 = fmaf(w, col.x, c0); c1 = fmaf(w, col.y, c1); c2 = fmaf(w, col.z, c2); cd = fmaf(w, col.w, cd);
         if (F > 0) {
           // wave-uniform row: read it through the scalar cache (constant address space => s_load)
-          const uint32_t id = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
+          // the row address comes from a register, not from the LDS record: the scalar load does not wait for LDS
+          const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, (int)j);
           typedef __attribute__((address_space(4))) const f32x2 cfloat2;
           cfloat2* f = (cfloat2*)(a.feats + (size_t)id * F);
           const f32x2 w2 = {w, w};
