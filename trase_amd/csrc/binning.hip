@@ -407,8 +407,10 @@ int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint3
 }
 
 // ---- backward phase 2: per-Gaussian sum of its (contiguous) per-pair gradient rows ----------------
-// One wave per depth rank; lane = column of the row.  Writes every Gaussian (zeros where it has no
-// pairs), so neither buffer needs a memset and the sums are bit-reproducible.
+// Four depth ranks per wave: a 16-lane group owns one Gaussian and lane t of the group owns columns 4t..4t+3 of
+// its rows (ROW/4 <= 12 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
+// of dependent loads (rank -> id -> pair range -> flags -> rows) is paid once per four Gaussians.  Writes every
+// Gaussian (zeros where it has no pairs), so neither output needs a memset and the sums are bit-reproducible.
 template <int ROW>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
@@ -418,62 +420,78 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
                                                           float* __restrict__ d_feats,
                                                           const float* __restrict__ raw_feats, int norm_features) {
-  constexpr int F = ROW - 16;
-  const int r = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+  constexpr int F = ROW - 16, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
-  if (r >= P) return;
-  const uint32_t id = sorted_ids[r];
-  const uint32_t nt = tiles[id];
-  uint32_t k1 = offsets[r];
-  uint32_t k0 = k1 - nt;
-  const uint32_t cap = hdr[HDR_WORDS - 2];          // capacity the lists were built with
-  if (k1 > cap) k1 = cap;                           // pairs dropped by an overflow have no row
-  if (k0 > k1) k0 = k1;
-  // rows exist only for pairs that were blended somewhere (flag == 1): fetch 64 flags at a time,
-  // ballot them into a mask and walk its set bits (wave-uniform), four row loads in flight
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const bool col = lane < ROW;
-  for (uint32_t kb = k0; kb < k1; kb += WAVE) {
-    const uint32_t kk = kb + lane;
-    unsigned long long m = __ballot(kk < k1 && flags[kk] != 0);
-    const float* base = rows + (size_t)kb * ROW + lane;
-    while (m) {
-      const int b0 = __builtin_ctzll(m); m &= m - 1;
-      int b1 = -1, b2 = -1, b3 = -1;
-      if (m) { b1 = __builtin_ctzll(m); m &= m - 1; }
-      if (m) { b2 = __builtin_ctzll(m); m &= m - 1; }
-      if (m) { b3 = __builtin_ctzll(m); m &= m - 1; }
-      if (col) {
-        const float v0 = base[(size_t)b0 * ROW];
-        const float v1 = (b1 >= 0) ? base[(size_t)b1 * ROW] : 0.f;
-        const float v2 = (b2 >= 0) ? base[(size_t)b2 * ROW] : 0.f;
-        const float v3 = (b3 >= 0) ? base[(size_t)b3 * ROW] : 0.f;
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  const int grp = lane >> 4, t = lane & 15;
+  const int r = (blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
+  const bool live = r < P;
+  const uint32_t id = live ? sorted_ids[r] : 0;
+  uint32_t k0 = 0, k1 = 0;
+  if (live) {
+    const uint32_t nt = tiles[id];
+    k1 = offsets[r];
+    k0 = k1 - nt;
+    const uint32_t cap = hdr[HDR_WORDS - 2];        // capacity the lists were built with
+    if (k1 > cap) k1 = cap;                         // pairs dropped by an overflow have no row
+    if (k0 > k1) k0 = k1;
+  }
+  // rows exist only for pairs that were blended somewhere (flag == 1): every group fetches 16 of its flags at a
+  // time, the wave ballot is cut into the four group masks, and a group walks its set bits, four rows in flight
+  constexpr int U = 4;                              // rows in flight per group
+  float4 s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool col = t < Q;
+  for (uint32_t kb = k0; __any(kb < k1); kb += 16) {
+    const uint32_t kk = kb + t;
+    const unsigned long long wm = __ballot(kk < k1 && flags[kk] != 0);
+    uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
+    const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * ROW) + t;
+    while (__any(m != 0)) {
+      int b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { b[u] = m ? __builtin_ctz(m) : -1; m &= m - 1; }
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = (col && b[u] >= 0) ? base[(size_t)b[u] * Q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+    }
+  }
+  float4 tot;
+  tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x); tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+  tot.z = (s[0].z + s[1].z) + (s[2].z + s[3].z); tot.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+  if (F > 0 && d_feats) {
+    const bool fl = t < F / 4;                      // lanes holding feature columns
+    float4 dx = tot;
+    if (raw_feats) {
+      // fused backward of y = x / (||x|| + 1e-9) (gaussian_renderer/__init__.py:120-121): tot holds dL/dy
+      const float4 x = (live && fl) ? *reinterpret_cast<const float4*>(raw_feats + (size_t)id * F + 4 * t)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (norm_features) {
+        float n2 = fl ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
+        float dot = fl ? (x.x * tot.x + x.y * tot.y) + (x.z * tot.z + x.w * tot.w) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {          // all-reduce inside the 16-lane group
+          n2 += __shfl_xor(n2, o);
+          dot += __shfl_xor(dot, o);
+        }
+        const float n = sqrtf(n2), den = n + 1e-9f;
+        const float k = (n > 0.f) ? dot / (n * den * den) : 0.f;
+        dx.x = tot.x / den - x.x * k; dx.y = tot.y / den - x.y * k;
+        dx.z = tot.z / den - x.z * k; dx.w = tot.w / den - x.w * k;
       }
     }
+    if (live && fl) *reinterpret_cast<float4*>(d_feats + (size_t)id * F + 4 * t) = dx;
   }
-  const float tot = col ? (s0 + s1) + (s2 + s3) : 0.f;
-  if (F > 0 && raw_feats && d_feats) {
-    // fused backward of y = x / (||x|| + 1e-9) (gaussian_renderer/__init__.py:120-121): lanes 0..F-1 hold dL/dy
-    const bool fl = lane < F;
-    const float x = fl ? raw_feats[(size_t)id * F + lane] : 0.f;
-    float dx = tot;
-    if (norm_features) {
-      const float n2 = wave_sum_all(x * x);
-      const float dot = wave_sum_all(fl ? x * tot : 0.f);
-      const float n = sqrtf(n2), den = n + 1e-9f;
-      dx = tot / den - ((n > 0.f) ? x * dot / (n * den * den) : 0.f);
-    }
-    if (fl) d_feats[(size_t)id * F + lane] = dx;
-  } else if (lane < F) {
-    if (d_feats) d_feats[(size_t)id * F + lane] = tot;
-  }
-  if (lane >= F && lane < F + 10) acc[(size_t)id * BWD_ACC + (lane - F)] = tot;
+  // columns F .. F+11 -> acc[0..11] (the last two are zero padding of the row)
+  if (live && t >= F / 4 && t < F / 4 + 3) *reinterpret_cast<float4*>(acc + (size_t)id * BWD_ACC + 4 * (t - F / 4)) = tot;
 }
 
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats, int norm_features) {
-  const int blocks = (P + 3) / 4;
+  const int blocks = (P + 15) / 16;                  // 4 waves x 4 Gaussians per block
   {
     ProfScope ps("reduce_rows", c.stream);
     switch (F) {
