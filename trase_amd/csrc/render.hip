@@ -69,10 +69,16 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
     if ((uint32_t)lane < n) {
       const uint32_t id = a.point_list[base + lane];
       my_id = id;
+      // pull this entry's 128-B feature row towards the L2 now: the blend loop reads it through the scalar cache up to
+      // 64 entries later.  The loaded word is unused; its register stays reserved until the explicit wait below
+      // (the compiler does not know an asm load is pending).
+      uint32_t sink = 0;
+      if (F > 0) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(a.feats + (size_t)id * F));
       const PairPoly k = pair_poly(a.xy[id], a.conic_o[id], bx, by);
       s_k0[wave][lane] = make_float4(k.k0, k.kj, k.ki, k.kjj);
       s_k1[wave][lane] = make_float4(k.kii, k.kij, k.thr, __uint_as_float(id));
       s_cd[wave][lane] = a.rgbd[id];
+      if (F > 0) asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink));   // every staging load has been consumed by now
     }
     wave_lds_sync();
     for (uint32_t j = 0; j < n; ++j) {
