@@ -207,9 +207,14 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
         for (int r = 0; r < 16; ++r) D[gb][nb][r] = 0.f;
     float S0 = 0.f, Sj = 0.f, Si = 0.f, Sjj = 0.f, Sij = 0.f, Sii = 0.f;
     unsigned wh[8], wl[8];                               // 16 weights of the current K-step, packed bf16 pairs
+    // two passes over 32 pixels (rolled: halves the code -- 12 resident waves share the instruction cache), four
+    // pixel rows unrolled inside so that every register array index below is a compile-time constant
+#pragma unroll 1
+    for (int mb = 0; mb < 2; ++mb) {
+      gemm1(mb);
 #pragma unroll
-    for (int i = 0; i < SUB; ++i) {
-      if ((i & 3) == 0) gemm1(i >> 2);
+      for (int ii = 0; ii < 4; ++ii) {
+      const int i = mb * 4 + ii;
       const float fi = (float)i, fii = (float)(i * i);
       const float base = poly_row_base(k, fi, fii);
       const float slope = poly_row_slope(k, fi);
@@ -238,8 +243,8 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           wave_scan_mul2_asm(Pa, Pb);
           const float Ta = pa.x * Pa, Tb = pb.x * Pb;     // transmittance in front of this Gaussian
           wa = ala * Ta; wb = alb * Tb;
-          const float sa = (j < 4 ? Sx : Sy)[4 * (i & 3) + (j & 3)];
-          const float sb = (j < 4 ? Sx : Sy)[4 * (i & 3) + ((j + 1) & 3)];
+          const float sa = (j < 4 ? Sx : Sy)[4 * ii + (j & 3)];
+          const float sb = (j < 4 ? Sx : Sy)[4 * ii + ((j + 1) & 3)];
           const float wsa = wa * sa, wsb = wb * sb;
           float ia, ib;
           wave_scan_add2_out_asm(wsa, wsb, ia, ib);
@@ -259,13 +264,13 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb) : "v"(wa), "v"(wb));
           const float ra2 = wa - __uint_as_float(hb << 16), rb2 = wb - __uint_as_float(hb & 0xffff0000u);
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lb) : "v"(ra2), "v"(rb2));
-          wh[(p & 15) >> 1] = hb;
-          wl[(p & 15) >> 1] = lb;
+          wh[(8 * (ii & 1) + j) >> 1] = hb;             // position inside the 16-pixel K-step
+          wl[(8 * (ii & 1) + j) >> 1] = lb;
         }
       }
       S0 += R0; Sj += R1; Sjj += R2;
       Si = fmaf(fi, R0, Si); Sii = fmaf(fii, R0, Sii); Sij = fmaf(fi, R1, Sij);
-      if (i & 1) {
+      if (ii & 1) {
         // ---- GEMM 2, K-step t = i/2: pixels 16t .. 16t+15 -----------------------------------------------
         // A fragments: block gb covers Gaussians gb*32 + m; lanes of half h supply pixels 8h .. 8h+7 of the step.
         // Own registers: wh[0..3] = pixels 0..7, wh[4..7] = pixels 8..15 of the lane's own Gaussian.
@@ -294,6 +299,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
             D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bl[nb], Ah[gb], D[gb][nb], 0, 0, 0);
             D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bh[nb], Al[gb], D[gb][nb], 0, 0, 0);
           }
+      }
       }
     }
     // moments about the sub-tile origin -> sums over dx = rx - j, dy = ry - i
