@@ -139,3 +139,31 @@ def test_binning_count_and_emit_agree_at_s3_size(monkeypatch):
                 assert torch.isfinite(a["render"]).all()
     finally:
         R.set_sync(True)
+
+
+def test_mfma_backward_matches_fp32_valu_backward_full_size(monkeypatch):
+    """The default F = 32 backward runs the channel contractions as bf16-split MFMA GEMMs (render_bwd_mf.hip, three
+    products per term).  At the headline size (300k Gaussians, 1080p) every gradient must agree with the packed-FP32
+    formulation of the same algorithm (render_bwd_gs.hip, `variant` bit 0x40) to 5e-5 of the gradient's scale -- the
+    split is exact to ~2^-17 per operand -- and stay bit-reproducible."""
+    from trase_amd import rasterizer as R
+    act, cam, dev, settings_for = _setup(300_000, 1920, 1080)
+    st = settings_for(cam, device=dev)
+    torch.manual_seed(5)
+    g_img = torch.randn(3, 1080, 1920, device=dev)
+    g_feat = torch.randn(32, 1080, 1920, device=dev)
+    grads = {}
+    try:
+        for name, var in (("valu", 0x40), ("mfma", 0), ("mfma2", 0)):
+            R.set_variant(var)
+            (img, radii, feats, depth), a, m2d = _render(act, st, need_grad=True)
+            torch.autograd.backward([img, feats], [g_img, g_feat])
+            grads[name] = {k: v.grad.clone() for k, v in a.items() if v.grad is not None}
+            grads[name]["means2D"] = m2d.grad.clone()
+    finally:
+        R.set_variant(0)
+    for k, ref in grads["valu"].items():
+        scale = float(ref.abs().max())
+        err = float((grads["mfma"][k] - ref).abs().max())
+        assert err <= 5e-5 * scale, f"{k}: max abs diff {err:.3e} vs scale {scale:.3e}"
+        assert torch.equal(grads["mfma"][k], grads["mfma2"][k]), f"{k}: MFMA backward is not bit-reproducible"
