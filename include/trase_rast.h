@@ -252,6 +252,22 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
                        const float* dL_dd_scaling, const void* saved, size_t saved_bytes, const TraseMlpGrads* grads,
                        void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
 
+/* ---- KNN feature smoothing of the FEATURE state ------------------------------------
+ * GaussianModel.get_smoothed_gaussian_features (scene/gaussian_model.py:79-104; gaussian_renderer/__init__.py:118,
+ * train.py:274-275):  out[i] = mean_s normalize(features[knn_idx[i][select[s]]]),  F.normalize eps = 1e-12.
+ *   features (P,32), knn_idx (P,K) int64 (pytorch3d.ops.knn_points(...).idx), select: S distinct slots of 0..K-1
+ *   (the reference's torch.randperm(K)[:int(K*dropout)]), out (P,32).  inv_norm (P floats) is written by the
+ *   forward and read by the backward.
+ * The backward gathers over the REVERSE adjacency instead of scattering with atomics: rev_src holds the flat
+ * positions i*K+k of knn_idx sorted (stably) by the Gaussian they point at, rev_ptr (P+1) the CSR offsets; the host
+ * builds both once per KNN map.  select_mask has bit k set for every selected slot. */
+int trase_smooth_forward(const float* features, const int64_t* knn_idx, int32_t P, int32_t F, int32_t K,
+                         const int32_t* select, int32_t S, float* inv_norm, float* out, int32_t device,
+                         trase_stream_t stream);
+int trase_smooth_backward(const float* features, const float* inv_norm, int32_t P, int32_t F, int32_t K,
+                          uint32_t select_mask, int32_t S, const int32_t* rev_ptr, const int32_t* rev_src,
+                          const float* dL_dout, float* dL_dfeatures, int32_t device, trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

@@ -280,6 +280,87 @@ def test_feature_smoothing_path_with_knn_shim():
     assert torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
 
 
+def _torch_smoothed(feats, idx, sel):
+    """The reference's composition (scene/gaussian_model.py:95-101)."""
+    normed = torch.nn.functional.normalize(feats, dim=-1, p=2)
+    return normed[idx[:, sel], 0, :].mean(dim=1).unsqueeze(1)
+
+
+@pytest.mark.parametrize("n,s", [(4000, 8), (50_003, 16), (37, 3)])
+def test_fused_feature_smoothing_matches_reference_composition(n, s):
+    """trase_smooth_forward / trase_smooth_backward (gather-mean of L2-normalised neighbour rows, backward over the
+    reverse adjacency) against the reference's normalize -> index -> mean composition in PyTorch fp32: values to
+    1e-6, gradients to 1e-5 of their scale (summation order differs), including a zero row (||x|| < eps branch of
+    F.normalize) and a Gaussian nobody points at; the backward is bit-reproducible."""
+    from pytorch3d.ops import knn_points
+    from trase_amd.smooth import smooth_features
+    g = torch.Generator().manual_seed(n)
+    xyz = (torch.rand(n, 3, generator=g) * 2 - 1).cuda()
+    feats0 = torch.randn(n, 1, 32, generator=g)
+    feats0[5] = 0.0                                    # exercises the eps branch
+    idx = knn_points(xyz.unsqueeze(0), xyz.unsqueeze(0), K=16).idx.squeeze()
+    sel = torch.randperm(16, generator=g)[:s]
+    w = torch.randn(n, 1, 32, generator=g).cuda()
+    fa = feats0.clone().cuda().requires_grad_(True)
+    ref = _torch_smoothed(fa, idx, sel.cuda())
+    (ref * w).sum().backward()
+    fb = feats0.clone().cuda().requires_grad_(True)
+    got = smooth_features(fb, idx, sel)
+    assert got.shape == (n, 1, 32)
+    assert float((got - ref).abs().max()) < 1e-6
+    (got * w).sum().backward()
+    scale = float(fa.grad.abs().max())
+    mask = torch.ones(n, dtype=torch.bool, device="cuda"); mask[5] = False   # d normalize at exactly 0 is a convention
+    assert float((fb.grad - fa.grad)[mask].abs().max()) < 1e-5 * scale
+    assert torch.isfinite(fb.grad).all()
+    fc = feats0.clone().cuda().requires_grad_(True)
+    (smooth_features(fc, idx, sel) * w).sum().backward()
+    assert torch.equal(fc.grad, fb.grad)
+
+
+def test_render_with_smoothed_features_matches_reference_composition():
+    """render(..., is_smooth_gaussian_features=True) (FEATURE state, train.py:274-275): the fused path (HIP smoothing
+    + raw-parameter kernels) against the reference's composition of PyTorch ops around the rasterizer operator, with
+    the same neighbour-slot selection (the host RNG is re-seeded before each call)."""
+    from trase_amd.renderer import render
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    from trase_amd.smooth import smoothed_gaussian_features
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    import math
+    dev = torch.device("cuda", 0)
+    scene = make_scene(3000, feat_dim=32, seed=4, scale_mult=0.8).to(dev)
+    cam = orbit_camera(128, 96, angle=0.2).to(dev)
+    bg = torch.zeros(3, device=dev)
+    torch.manual_seed(0)
+    g_feat = torch.randn(32, 96, 128, device=dev)
+    # fused
+    pc = SynthGaussianModel(scene)
+    pc.feature_smooth_map = None
+    torch.manual_seed(11)
+    out = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0, is_smooth_gaussian_features=True, smooth_K=16)
+    (out["render_gaussian_features"] * g_feat).sum().backward()
+    # reference composition
+    pc2 = SynthGaussianModel(scene)
+    pc2.feature_smooth_map = pc.feature_smooth_map
+    torch.manual_seed(11)
+    sel = torch.randperm(16)[:8]
+    sh_objs = _torch_smoothed(pc2._gaussian_features, pc.feature_smooth_map["m"], sel.to(dev))
+    sh_objs = sh_objs / (sh_objs.norm(dim=2, keepdim=True) + 1e-9)
+    st = GaussianRasterizationSettings(image_height=96, image_width=128, tanfovx=math.tan(cam.FoVx * 0.5),
+                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+                                       viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                                       sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
+    m2d = torch.zeros_like(pc2.get_xyz, requires_grad=True)
+    img, radii, feats, depth = GaussianRasterizer(raster_settings=st)(
+        means3D=pc2.get_xyz, means2D=m2d, shs=pc2.get_features, sh_objs=sh_objs, colors_precomp=None,
+        opacities=pc2.get_opacity, scales=pc2.get_scaling, rotations=pc2.get_rotation, cov3D_precomp=None)
+    (feats * g_feat).sum().backward()
+    a, b = out["render_gaussian_features"], feats
+    assert float(((a - b).abs() > 1e-4).float().mean()) < 2e-3          # rare gate flips between the two exp routines
+    ga, gb = pc._gaussian_features.grad, pc2._gaussian_features.grad
+    assert float((ga - gb).norm() / gb.norm()) < 2e-3
+
+
 def test_deform_mlp_matches_reference_golden():
     """Fused bf16-MFMA DeformNetwork forward vs the golden vectors captured from the imported reference
     (tests/golden/deform_mlp.npz, utils/time_utils.py:60-131).  Tolerance: bf16 inputs/activations with

@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import _lib
+from .smooth import smoothed_gaussian_features
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _bytes, _fill_settings, _prep,
                          _stream)
 
@@ -155,7 +156,7 @@ class _RenderRaw(torch.autograd.Function):
 
 
 def _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth) -> bool:
-    if is_6dof or override_color is not None or mask is not None or is_smooth:
+    if is_6dof or override_color is not None or mask is not None:
         return False
     if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
         return False
@@ -188,9 +189,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
 
     if _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth_gaussian_features):
         T = lambda d: d if torch.is_tensor(d) else None
+        # KNN-smoothed features (FEATURE state, gaussian_renderer/__init__.py:118): one HIP gather, then the fused path
+        gfeat = smoothed_gaussian_features(pc, K=smooth_K, dropout=0.5) if is_smooth_gaussian_features \
+            else pc._gaussian_features
         rendered_image, radii, rendered_feats, depth = _RenderRaw.apply(
             pc._xyz, T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, T(d_scaling),
-            pc._rotation, T(d_rotation), pc._gaussian_features, screenspace_points, raster_settings,
+            pc._rotation, T(d_rotation), gfeat, screenspace_points, raster_settings,
             norm_gaussian_features)
     else:
         # the reference's own composition around the (HIP) rasterizer
@@ -220,7 +224,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
         else:
             colors_precomp = override_color
         sh_objs = pc.get_gaussian_features if not is_smooth_gaussian_features else \
-            pc.get_smoothed_gaussian_features(K=smooth_K, dropout=0.5)
+            smoothed_gaussian_features(pc, K=smooth_K, dropout=0.5)
         if norm_gaussian_features:
             sh_objs = sh_objs / (sh_objs.norm(dim=2, keepdim=True) + 1e-9)
         if mask is not None:
