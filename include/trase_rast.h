@@ -268,6 +268,18 @@ int trase_smooth_backward(const float* features, const float* inv_norm, int32_t 
                           uint32_t select_mask, int32_t S, const int32_t* rev_ptr, const int32_t* rev_src,
                           const float* dL_dout, float* dL_dfeatures, int32_t device, trase_stream_t stream);
 
+/* ---- photometric loss heads -----------------------------------------------------------
+ * l1_loss (utils/loss_utils.py:30-31) and ssim (utils/loss_utils.py:56-86: 11x11 Gaussian window, sigma 1.5, zero
+ * padding, C1 = 0.01^2, C2 = 0.03^2, mean over the map), combined at train.py:235-238.
+ *   forward : img, gt (C,H,W) -> out2 = {mean |img - gt|, mean SSIM map} (device floats); keeps the SSIM partial
+ *             derivatives in `ws` (trase_loss_sizes bytes; the caller holds it until the backward).
+ *   backward: g2 = {dL/dl1, dL/dssim} (device floats, so no host sync) -> dL/dimg (C,H,W), overwritten. */
+int trase_loss_sizes(int32_t C, int32_t H, int32_t W, size_t* ws_bytes);
+int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, void* ws,
+                               size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
+                                const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

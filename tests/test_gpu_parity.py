@@ -361,6 +361,53 @@ def test_render_with_smoothed_features_matches_reference_composition():
     assert float((ga - gb).norm() / gb.norm()) < 2e-3
 
 
+def test_fused_l1_ssim_matches_reference_golden_and_torch():
+    """trase_loss_l1_ssim_forward / _backward against (a) the golden vectors captured from the imported reference
+    (tests/golden/losses.npz: utils/loss_utils.py:30-86 l1_loss, ssim and the train.py:235-238 combination with its
+    gradient) and (b) the same composition in PyTorch at a size with ragged tiles.  Tolerance 1e-5 absolute on the
+    scalars, 1e-5 of the gradient's scale (the separable window changes the summation order)."""
+    import os
+    import torch.nn.functional as Fn
+    from trase_amd.losses import l1_loss, ssim, l1_ssim
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+    a = torch.from_numpy(d["a"]).cuda().requires_grad_(True)
+    b = torch.from_numpy(d["b"]).cuda()
+    l1 = l1_loss(a, b)
+    ss = ssim(a, b)
+    total = (1.0 - 0.2) * l1 + 0.2 * (1.0 - ss)
+    total.backward()
+    assert abs(float(l1) - float(d["l1"])) < 1e-5 and abs(float(ss) - float(d["ssim"])) < 1e-5
+    assert abs(float(total) - float(d["total"])) < 1e-5
+    want = torch.from_numpy(d["grad_a"]).cuda()
+    assert float((a.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+    def ref_ssim(x, y):            # utils/loss_utils.py:46-86 restated
+        g = torch.tensor([math.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)])
+        g = (g / g.sum()).unsqueeze(1)
+        win = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(x.shape[0], 1, 11, 11).contiguous().cuda()
+        conv = lambda t: Fn.conv2d(t, win, padding=5, groups=x.shape[0])
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+        m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+        return m.mean()
+    torch.manual_seed(2)
+    x = torch.rand(3, 77, 131, device="cuda")
+    y = (x + 0.15 * torch.randn_like(x)).clamp(0, 1)
+    y[:, :5, :7] = x[:, :5, :7]                                # exact zeros of |x - y|: sign(0) = 0
+    xa = x.clone().requires_grad_(True)
+    (0.8 * (xa - y).abs().mean() + 0.2 * (1 - ref_ssim(xa, y))).backward()
+    xb = x.clone().requires_grad_(True)
+    l1b, ssb = l1_ssim(xb, y)
+    (0.8 * l1b + 0.2 * (1 - ssb)).backward()
+    assert abs(float(l1b) - float((x - y).abs().mean())) < 1e-6
+    assert abs(float(ssb) - float(ref_ssim(x, y))) < 1e-5
+    assert float((xb.grad - xa.grad).abs().max()) < 1e-5 * float(xa.grad.abs().max())
+    xc = x.clone().requires_grad_(True)
+    l1c, ssc = l1_ssim(xc, y)
+    (0.8 * l1c + 0.2 * (1 - ssc)).backward()
+    assert torch.equal(xc.grad, xb.grad) and torch.equal(ssc, ssb)     # deterministic reductions
+
+
 def test_deform_mlp_matches_reference_golden():
     """Fused bf16-MFMA DeformNetwork forward vs the golden vectors captured from the imported reference
     (tests/golden/deform_mlp.npz, utils/time_utils.py:60-131).  Tolerance: bf16 inputs/activations with

@@ -140,6 +140,11 @@ SYMBOLS = [
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_smooth_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("trase_loss_sizes", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("trase_loss_l1_ssim_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_loss_l1_ssim_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),

@@ -1,0 +1,216 @@
+// loss.hip -- photometric loss heads of the training loop:
+//   l1_loss (utils/loss_utils.py:30-31) and ssim (:56-86, 11x11 Gaussian window sigma 1.5, zero padding,
+//   C1 = 0.01^2, C2 = 0.03^2), combined at train.py:235-238.
+// The reference runs five depthwise 11x11 convolutions forward and their transposes backward through autograd.
+// Here the window is applied separably from LDS tiles:
+//   forward : one pass computes mu1, mu2, E[x^2], E[y^2], E[xy] for a 32x32 tile, the SSIM map value and the
+//             three partial derivatives dS/dmu1, dS/dE[x^2], dS/dE[xy], which it stores for the backward; |x-y| and
+//             S are summed per block into a partial array that a one-block kernel reduces (deterministic order).
+//   backward: dL/dx = w_s * (blur(dS/dmu1) + 2 x blur(dS/dE[x^2]) + y blur(dS/dE[xy])) + w_l * sign(x - y)
+//             (the window is symmetric and the padding is zero, so the transposed convolution is the same blur).
+#include "common.h"
+
+namespace trase {
+
+constexpr int LW = 11, LR = 5;            // window, radius
+constexpr int LT = 32;                    // tile edge
+constexpr int LH = LT + 2 * LR;           // 42: tile + halo
+
+struct LossWin { float g[LW]; };
+
+__device__ __forceinline__ float tile_load(const float* __restrict__ p, int H, int W, int y, int x) {
+  return (x >= 0 && x < W && y >= 0 && y < H) ? p[(size_t)y * W + x] : 0.f;    // conv2d zero padding
+}
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
+                                                       LossWin win, float* __restrict__ dmaps /* [3][C][H][W] */,
+                                                       float* __restrict__ partial /* [blocks][2] */) {
+  __shared__ float sx[LH][LH + 1], sy[LH][LH + 1];
+  __shared__ float hb[5][LH][LT + 1];
+  __shared__ float red[2][4];
+  const int c = blockIdx.z;
+  const size_t plane = (size_t)H * W;
+  const float* X = img + c * plane;
+  const float* Y = gt + c * plane;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  for (int i = threadIdx.x; i < LH * LH; i += 256) {
+    const int r = i / LH, q = i % LH;
+    sx[r][q] = tile_load(X, H, W, y0 + r - LR, x0 + q - LR);
+    sy[r][q] = tile_load(Y, H, W, y0 + r - LR, x0 + q - LR);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < LH * LT; i += 256) {       // horizontal pass: 42 rows x 32 columns
+    const int r = i / LT, q = i % LT;
+    float a = 0.f, b = 0.f, p = 0.f, qq = 0.f, rr = 0.f;
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      const float w = win.g[k], x = sx[r][q + k], y = sy[r][q + k];
+      a = fmaf(w, x, a); b = fmaf(w, y, b); p = fmaf(w, x * x, p); qq = fmaf(w, y * y, qq); rr = fmaf(w, x * y, rr);
+    }
+    hb[0][r][q] = a; hb[1][r][q] = b; hb[2][r][q] = p; hb[3][r][q] = qq; hb[4][r][q] = rr;
+  }
+  __syncthreads();
+  float s_l1 = 0.f, s_ss = 0.f;
+  const size_t cp = (size_t)gridDim.z * plane;
+  for (int i = threadIdx.x; i < LT * LT; i += 256) {        // vertical pass + SSIM
+    const int r = i / LT, q = i % LT;
+    const int y = y0 + r, x = x0 + q;
+    if (y >= H || x >= W) continue;
+    float a = 0.f, b = 0.f, p = 0.f, qq = 0.f, rr = 0.f;
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      const float w = win.g[k];
+      a = fmaf(w, hb[0][r + k][q], a); b = fmaf(w, hb[1][r + k][q], b); p = fmaf(w, hb[2][r + k][q], p);
+      qq = fmaf(w, hb[3][r + k][q], qq); rr = fmaf(w, hb[4][r + k][q], rr);
+    }
+    constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float A1 = 2.f * a * b + C1, A2 = 2.f * (rr - a * b) + C2;
+    const float B1 = a * a + b * b + C1, B2 = (p - a * a) + (qq - b * b) + C2;
+    const float iB1 = 1.f / B1, iB2 = 1.f / B2;
+    const float S = A1 * A2 * iB1 * iB2;
+    const size_t o = c * plane + (size_t)y * W + x;
+    dmaps[o] = 2.f * b * (A2 - A1) * iB1 * iB2 - 2.f * a * S * (iB1 - iB2);   // dS/dmu1
+    dmaps[cp + o] = -S * iB2;                                                   // dS/dE[x^2]
+    dmaps[2 * cp + o] = 2.f * A1 * iB1 * iB2;                                   // dS/dE[xy]
+    s_ss += S;
+    s_l1 += fabsf(sx[r + LR][q + LR] - sy[r + LR][q + LR]);
+  }
+  // block reduction in a fixed order
+  s_l1 = wave_sum_all(s_l1); s_ss = wave_sum_all(s_ss);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_l1; red[1][threadIdx.x >> 6] = s_ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[2 * blk] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[2 * blk + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int nblocks, float inv_count,
+                                                          float* __restrict__ out2) {
+  __shared__ double sh[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = (float)(sh[0][0] * inv_count); out2[1] = (float)(sh[1][0] * inv_count); }
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
+                                                       LossWin win, const float* __restrict__ dmaps,
+                                                       const float* __restrict__ g2 /* dL/dl1, dL/dssim */, float inv_count,
+                                                       float* __restrict__ d_img) {
+  __shared__ float sd[3][LH][LH + 1];
+  __shared__ float hb[3][LH][LT + 1];
+  const int c = blockIdx.z;
+  const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  for (int i = threadIdx.x; i < LH * LH; i += 256) {
+    const int r = i / LH, q = i % LH;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) sd[m][r][q] = tile_load(dmaps + m * cp + c * plane, H, W, y0 + r - LR, x0 + q - LR);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < LH * LT; i += 256) {
+    const int r = i / LT, q = i % LT;
+    float a = 0.f, p = 0.f, rr = 0.f;
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      const float w = win.g[k];
+      a = fmaf(w, sd[0][r][q + k], a); p = fmaf(w, sd[1][r][q + k], p); rr = fmaf(w, sd[2][r][q + k], rr);
+    }
+    hb[0][r][q] = a; hb[1][r][q] = p; hb[2][r][q] = rr;
+  }
+  __syncthreads();
+  const float wl = g2[0] * inv_count, ws = g2[1] * inv_count;
+  for (int i = threadIdx.x; i < LT * LT; i += 256) {
+    const int r = i / LT, q = i % LT;
+    const int y = y0 + r, x = x0 + q;
+    if (y >= H || x >= W) continue;
+    float a = 0.f, p = 0.f, rr = 0.f;
+#pragma unroll
+    for (int k = 0; k < LW; ++k) {
+      const float w = win.g[k];
+      a = fmaf(w, hb[0][r + k][q], a); p = fmaf(w, hb[1][r + k][q], p); rr = fmaf(w, hb[2][r + k][q], rr);
+    }
+    const size_t o = c * plane + (size_t)y * W + x;
+    const float xv = img[o], yv = gt[o];
+    const float d = xv - yv;
+    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    d_img[o] = ws * (a + 2.f * xv * p + yv * rr) + wl * sgn;
+  }
+}
+
+static LossWin make_window() {
+  // gaussian(11, 1.5) of utils/loss_utils.py:46-48: Python floats (double) -> float32 tensor -> divided by its float32 sum
+  LossWin w;
+  float g[LW];
+  float sum = 0.f;
+  for (int x = 0; x < LW; ++x) { g[x] = (float)exp(-(double)((x - LW / 2) * (x - LW / 2)) / (2.0 * 1.5 * 1.5)); }
+  for (int x = 0; x < LW; ++x) sum += g[x];
+  for (int x = 0; x < LW; ++x) w.g[x] = g[x] / sum;
+  return w;
+}
+
+static size_t loss_ws_bytes(int C, int H, int W, int* nblocks) {
+  const int bx = (W + LT - 1) / LT, by = (H + LT - 1) / LT;
+  if (nblocks) *nblocks = bx * by * C;
+  return align_up(sizeof(float) * 3 * (size_t)C * H * W) + align_up(sizeof(float) * 2 * (size_t)bx * by * C);
+}
+
+}  // namespace trase
+
+using namespace trase;
+
+extern "C" {
+
+int trase_loss_sizes(int32_t C, int32_t H, int32_t W, size_t* ws_bytes) {
+  if (!ws_bytes || C < 1 || H < 1 || W < 1) { set_error("trase_loss_sizes: bad arguments"); return TRASE_ERR_INVALID; }
+  *ws_bytes = loss_ws_bytes(C, H, W, nullptr);
+  return TRASE_OK;
+}
+
+int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, void* ws,
+                               size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (!img || !gt || !out2 || C < 1 || H < 1 || W < 1) { set_error("trase_loss_l1_ssim_forward: bad arguments"); return TRASE_ERR_INVALID; }
+  int nblocks = 0;
+  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, &nblocks)) { set_error("trase_loss_l1_ssim_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  float* dmaps = (float*)ws;
+  float* partial = (float*)((char*)ws + align_up(sizeof(float) * 3 * (size_t)C * H * W));
+  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  {
+    ProfScope ps("ssim_fwd", stream);
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, stream, img, gt, H, W, make_window(), dmaps, partial);
+  }
+  TRASE_POST_LAUNCH("ssim_fwd", stream, 0);
+  {
+    ProfScope ps("loss_reduce", stream);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, 1.0f / ((float)C * H * W), out2);
+  }
+  TRASE_POST_LAUNCH("loss_reduce", stream, 0);
+  return TRASE_OK;
+}
+
+int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
+                                const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream_) {
+  if (!img || !gt || !g2 || !dL_dimg || C < 1 || H < 1 || W < 1) { set_error("trase_loss_l1_ssim_backward: bad arguments"); return TRASE_ERR_INVALID; }
+  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, nullptr)) { set_error("trase_loss_l1_ssim_backward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  {
+    ProfScope ps("ssim_bwd", stream);
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, stream, img, gt, H, W, make_window(), (const float*)ws, g2,
+                       1.0f / ((float)C * H * W), dL_dimg);
+  }
+  TRASE_POST_LAUNCH("ssim_bwd", stream, 0);
+  return TRASE_OK;
+}
+
+}  // extern "C"
