@@ -575,9 +575,9 @@ struct WgradJob {
 constexpr int WG_MAX_JOBS = 8;
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
-// WM x WN waves (= 4), each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
+// WM x WN waves, each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
 template <int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradJobs jobs, int tiles, int G) {
+__global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, int tiles, int G) {
   constexpr int M = WM * MB * 32, NK = WN * NB * 32;
   const WgradJob job = jobs.j[blockIdx.y];
   const int g = blockIdx.x;
@@ -664,8 +664,14 @@ __global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
   if (idx < total) {
     const int f = idx / job.NK, k = idx % job.NK;
     if (f < job.m_valid && k < job.k_valid) {
-      float s = 0.f;
-      for (int g = 0; g < job.G; ++g) s += job.partial[(size_t)g * total + idx];
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed summation order, four loads in flight
+      int g = 0;
+      for (; g + 4 <= job.G; g += 4) {
+        s0 += job.partial[(size_t)g * total + idx];       s1 += job.partial[(size_t)(g + 1) * total + idx];
+        s2 += job.partial[(size_t)(g + 2) * total + idx]; s3 += job.partial[(size_t)(g + 3) * total + idx];
+      }
+      for (; g < job.G; ++g) s0 += job.partial[(size_t)g * total + idx];
+      const float s = (s0 + s1) + (s2 + s3);
       if (job.head) {
         const int seg = f < 3 ? 0 : (f < 7 ? 1 : 2), base = f < 3 ? 0 : (f < 7 ? 3 : 7);
         if (job.head_w[seg]) job.head_w[seg][(f - base) * job.stride + k] = s;
