@@ -349,12 +349,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
   const int gx8 = (W + SUB - 1) / SUB;
   const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
+  const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
   for (int ty = y0; ty < y1; ++ty)
     for (int tx = x0; tx < x1; ++tx) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-        if (off < end && bx < W && by < H && subtile_live(p.x, p.y, co.x, co.y, co.z, co.w, bx, by, W, H)) {
+        if (off < end && bx < W && by < H && subtile_cull_live(cull, bx, by, W, H)) {
           if (off < cap) {
             keys[off] = (uint32_t)((by / SUB) * gx8 + (bx / SUB));
             pair_gauss[off] = id;

@@ -206,38 +206,61 @@ TRASE_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0,
 constexpr int SUB = 8;   // sub-tile edge
 
 // The count (preprocess) and the emit kernel must take bit-identical decisions.  Two inlined copies were once
-// contracted into FMAs differently (one pair in ~8 M disagreed), so contraction is switched off for this body:
-// every operation below is then an individually rounded IEEE op wherever the function is inlined.
-TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+// contracted into FMAs differently (one pair in ~8 M disagreed), so contraction is switched off for these bodies:
+// every operation below is then an individually rounded IEEE op wherever the functions are inlined.
+// The per-Gaussian part (logarithm, the two divisions) is hoisted into SubtileCull; the per-block test is
+// multiplications, clamps and compares only.
+struct SubtileCull {
+  float gx, gy, A, B, C, tau, nb_c, nb_a;   // nb_c = -B/C, nb_a = -B/A: slopes of the edge minimisers
+  int mode;                                 // 0: test blocks, 1: never live, 2: always live
+};
+
+TRASE_HD SubtileCull subtile_cull_setup(float gx, float gy, float A, float B, float C, float opacity) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
+  SubtileCull s;
+  s.gx = gx; s.gy = gy; s.A = A; s.B = B; s.C = C; s.nb_c = 0.0f; s.nb_a = 0.0f; s.mode = 0;
   const float tau_raw = 2.0f * logf(255.0f * opacity);
-  if (!(tau_raw >= 0.0f)) return false;   // opacity < 1/255 (or NaN): can never pass the gate
-  const float tau = tau_raw * 1.001f + 1e-3f;
+  s.tau = tau_raw * 1.001f + 1e-3f;
+  if (!(tau_raw >= 0.0f)) { s.mode = 1; return s; }   // opacity < 1/255 (or NaN): can never pass the gate
+  if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) { s.mode = 2; return s; }   // not positive definite: keep
+  s.nb_c = -B / C;
+  s.nb_a = -B / A;
+  return s;
+}
+
+TRASE_HD bool subtile_cull_live(const SubtileCull& s, int bx, int by, int W, int H) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  if (s.mode) return s.mode == 2;
   // pixel centres of the block, clipped to the image
   const float x0 = (float)bx, x1 = (float)imin(bx + SUB - 1, W - 1);
   const float y0 = (float)by, y1 = (float)imin(by + SUB - 1, H - 1);
-  if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) return true;   // not positive definite: keep
   // closest point of the box to the centre
-  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
-  if (cx == gx && cy == gy) return true;        // centre inside the block
+  const float cx = fminf(fmaxf(s.gx, x0), x1), cy = fminf(fmaxf(s.gy, y0), y1);
+  if (cx == s.gx && cy == s.gy) return true;    // centre inside the block
   float best = 3.0e38f;
   // candidate 1: vertical edge facing the centre (dx fixed), optimum dy clamped to the edge
-  if (cx != gx) {
-    const float dx = cx - gx;
-    float dy = -B * dx / C;                      // unconstrained minimiser along the edge
-    dy = fminf(fmaxf(dy, y0 - gy), y1 - gy);
-    best = fminf(best, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+  if (cx != s.gx) {
+    const float dx = cx - s.gx;
+    float dy = s.nb_c * dx;                      // unconstrained minimiser along the edge
+    dy = fminf(fmaxf(dy, y0 - s.gy), y1 - s.gy);
+    best = fminf(best, s.A * dx * dx + 2.0f * s.B * dx * dy + s.C * dy * dy);
   }
   // candidate 2: horizontal edge facing the centre
-  if (cy != gy) {
-    const float dy = cy - gy;
-    float dx = -B * dy / A;
-    dx = fminf(fmaxf(dx, x0 - gx), x1 - gx);
-    best = fminf(best, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+  if (cy != s.gy) {
+    const float dy = cy - s.gy;
+    float dx = s.nb_a * dy;
+    dx = fminf(fmaxf(dx, x0 - s.gx), x1 - s.gx);
+    best = fminf(best, s.A * dx * dx + 2.0f * s.B * dx * dy + s.C * dy * dy);
   }
-  return best <= tau;
+  return best <= s.tau;
+}
+
+TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
+  return subtile_cull_live(subtile_cull_setup(gx, gy, A, B, C, opacity), bx, by, W, H);
 }
 
 // Forward of one Gaussian.  `sh` points at 48 floats: this Gaussian's (16,3) coefficients,

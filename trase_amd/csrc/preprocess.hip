@@ -87,12 +87,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   uint32_t live = 0;
   const float opac = a.opac[i];
   if (vis) {
+    const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, opac);
     for (int ty = o.y0; ty < o.y1; ++ty)
       for (int tx = o.x0; tx < o.x1; ++tx) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
           const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-          if (bx < a.W && by < a.H && subtile_live(o.px, o.py, o.ca, o.cb, o.cc, opac, bx, by, a.W, a.H)) ++live;
+          if (bx < a.W && by < a.H && subtile_cull_live(cull, bx, by, a.W, a.H)) ++live;
         }
       }
   }

@@ -90,12 +90,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
   if ((threadIdx.x & 63) == 63 && wave_area > 0.f) atomicAdd(&hdr[HDR_R], (uint32_t)wave_area);
   uint32_t live = 0;
   if (vis) {
+    const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, act.opac);
     for (int ty = o.y0; ty < o.y1; ++ty)
       for (int tx = o.x0; tx < o.x1; ++tx) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
           const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-          if (bx < a.W && by < a.H && subtile_live(o.px, o.py, o.ca, o.cb, o.cc, act.opac, bx, by, a.W, a.H)) ++live;
+          if (bx < a.W && by < a.H && subtile_cull_live(cull, bx, by, a.W, a.H)) ++live;
         }
       }
   }
