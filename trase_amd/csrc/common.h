@@ -157,6 +157,14 @@ __device__ __forceinline__ float poly_eval(const PairPoly& k, float base, float 
   return fmaf(jj, k.kjj, fmaf(j, slope, base));
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Mapping block b to the x-th
+// CONTIGUOUS eighth of the work (x = b mod 8) keeps spatially adjacent tiles -- which share their Gaussians'
+// rows -- on one XCD, so a per-Gaussian row is fetched into one L2 instead of eight.  Bijective for any nb.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+  const int x = b & 7, loc = b >> 3, q = nb >> 3, r = nb & 7;
+  return x * q + (x < r ? x : r) + loc;
+}
+
 // value of lane-1 (lane 0 receives `ident`): DPP wave_shr:1
 __device__ __forceinline__ float wave_shr1(float v, float ident) { return dpp_fill<0x138>(v, ident); }
 

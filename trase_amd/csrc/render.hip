@@ -29,7 +29,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ int subtile_of_wave(const RenderArgs& a, int& px, int& py, int& wave, int& lane) {
   wave = threadIdx.x >> 6;
   lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * WPB + wave;
+  const int tile = xcd_block(blockIdx.x, gridDim.x) * WPB + wave;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   px = tx * SUB + (lane & 7);
   py = ty * SUB + (lane >> 3);

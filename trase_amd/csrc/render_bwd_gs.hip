@@ -47,7 +47,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
   __shared__ __attribute__((aligned(16))) float4 s_pix[GWPB][WAVE];      // T_end, U_end, last (bits), -
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * GWPB + wave;
+  const int tile = xcd_block(blockIdx.x, gridDim.x) * GWPB + wave;
   if (tile >= a.ntiles) return;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];

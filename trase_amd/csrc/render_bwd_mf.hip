@@ -102,7 +102,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x * MF_WPB + wave;
+  const int tile = xcd_block(blockIdx.x, gridDim.x) * MF_WPB + wave;
   if (tile >= a.ntiles) return;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];
