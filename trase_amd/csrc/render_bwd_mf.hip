@@ -222,9 +222,11 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
 #pragma unroll
       for (int j = 0; j < SUB; j += 2) {                 // two pixels per step: their scans are interleaved
         const int p = i * SUB + j;
-        const float4 pa = s_pix[wave][p], pb = s_pix[wave][p + 1];   // uniform reads
-        const uint32_t lasta = __builtin_amdgcn_readfirstlane(__float_as_uint(pa.z));
-        const uint32_t lastb = __builtin_amdgcn_readfirstlane(__float_as_uint(pb.z));
+        // the pixels' last-contributor indices never change: they stay in a register (lane = pixel) and are read
+        // with v_readlane, so the skip test below does not wait for LDS
+        const uint32_t lasta = (uint32_t)__builtin_amdgcn_readlane((int)last, p);
+        const uint32_t lastb = (uint32_t)__builtin_amdgcn_readlane((int)last, p + 1);
+        const float4 pa = s_pix[wave][p], pb = s_pix[wave][p + 1];   // uniform reads: T_end, U_end
         float wa = 0.f, wb = 0.f;
         // a pixel whose last blended entry lies behind this chunk passes no gate (pos >= c0 >= last): processing it
         // next to a live neighbour changes nothing, so the skip is per pair
