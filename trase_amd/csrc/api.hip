@@ -273,9 +273,15 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-    rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, b.pair_slot, t.pair_gauss,
-                                   b.point_list, g.hdr + 16);
-    if (rc) return rc;
+    if (s->variant & 0x200) {       // A/B: dedicated slot -> id gather pass (the render kernel reads ids)
+      rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, b.pair_slot, t.pair_gauss,
+                                     b.point_list, g.hdr + 16);
+      if (rc) return rc;
+    } else {                        // default: ranges only; the forward's staging step does the gather
+      rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, g.hdr + 16);
+      if (rc) return rc;
+      return launch_render_fwd(c, *s, *in, *out, g, b, im, t.pair_gauss, (uint32_t)cap);
+    }
   } else {
     TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * ((size_t)T + 1), stream));
   }

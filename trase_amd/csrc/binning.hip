@@ -549,7 +549,8 @@ int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const ui
   return TRASE_OK;
 }
 
-int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T) {
+int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
+                       uint32_t* dbg) {
   TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
   int blocks = (int)((cap + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -557,7 +558,7 @@ int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t*
   {
     ProfScope ps("tile_ranges", c.stream);
     hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, nullptr,
-                       nullptr, nullptr, (uint32_t)T, nullptr);
+                       nullptr, nullptr, (uint32_t)T, dbg);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;

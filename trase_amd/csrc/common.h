@@ -307,13 +307,15 @@ int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint3
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
                        int norm_features = 0);
-int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T);
+int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
+                       uint32_t* dbg = nullptr);
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
                               int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
                               uint32_t* dbg);
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
-                      const GeomBuf& g, const BinBuf& b, const ImgBuf& im);
+                      const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss = nullptr,
+                      uint32_t cap = 0);
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,

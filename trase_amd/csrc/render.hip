@@ -16,6 +16,9 @@ struct RenderArgs {
   const uint2* ranges; const uint32_t* point_list;
   const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
   int W, H, gx8, ntiles;
+  // forward only: when set, the list still holds emit-order slots; the staging step translates them to Gaussian
+  // ids (slot -> id is one more dependent load, hidden like the others) and records the ids for the backward
+  const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
 };
 
 // LDS produced and consumed by one wave only: order the accesses without a workgroup barrier
@@ -67,7 +70,14 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
     wave_lds_sync();
     uint32_t my_id = 0;                                  // lane = list entry: kept for v_readlane in the blend loop
     if ((uint32_t)lane < n) {
-      const uint32_t id = a.point_list[base + lane];
+      uint32_t id;
+      if (a.point_list_w) {
+        const uint32_t slot = a.pair_slot[base + lane];
+        id = a.pair_gauss[slot < a.cap ? slot : 0];
+        a.point_list_w[base + lane] = id;
+      } else {
+        id = a.point_list[base + lane];
+      }
       my_id = id;
       // pull this entry's 128-B feature row towards the L2 now: the blend loop reads it through the scalar cache up to
       // 64 entries later.  The loaded word is unused; its register stays reserved until the explicit wait below
@@ -132,12 +142,14 @@ static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const Tr
   a.feats = in.sh_objs; a.bg = s.bg; a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  a.pair_slot = nullptr; a.pair_gauss = nullptr; a.point_list_w = nullptr; a.cap = 0;
 }
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
-                      const GeomBuf& g, const BinBuf& b, const ImgBuf& im) {
+                      const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss, uint32_t cap) {
   RenderArgs a;
   fill_render_args(a, s, in, g, b);
+  if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
   const int T = (a.ntiles + WPB - 1) / WPB;
   {
     ProfScope ps("render_fwd", c.stream);
