@@ -406,6 +406,14 @@ def test_fused_l1_ssim_matches_reference_golden_and_torch():
     l1c, ssc = l1_ssim(xc, y)
     (0.8 * l1c + 0.2 * (1 - ssc)).backward()
     assert torch.equal(xc.grad, xb.grad) and torch.equal(ssc, ssb)     # deterministic reductions
+    # the l1_loss / ssim pair shares one evaluation only for the SAME tensor objects; fresh tensors never hit the cache
+    for it in range(3):
+        xi = (x + 0.01 * it).requires_grad_(True)
+        li, si = l1_loss(xi, y), ssim(xi, y)
+        assert abs(float(li.detach()) - float((xi.detach() - y).abs().mean())) < 1e-6
+        (li + si).backward()
+        assert xi.grad is not None and torch.isfinite(xi.grad).all()
+        del xi, li, si
 
 
 def test_deform_mlp_matches_reference_golden():

@@ -9,6 +9,7 @@ tensors (as train.py does) the second call reuses the first call's fused result.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -63,13 +64,18 @@ def l1_ssim(img: torch.Tensor, gt: torch.Tensor):
     return _L1SSIM.apply(img, gt)
 
 
-_last = {"key": None, "val": None}
+_last = {"img": None, "gt": None, "ver": None, "val": None}
 
 
 def _fused(img, gt):
-    key = (id(img), img._version, id(gt), gt._version, torch.is_grad_enabled())
-    if _last["key"] != key:
-        _last["key"], _last["val"] = key, l1_ssim(img, gt)
+    """One fused evaluation shared by l1_loss(x, gt) and ssim(x, gt) when train.py calls them back to back on the same
+    tensors.  The cache holds WEAK references and compares object identity + version counters: a new tensor that
+    happens to reuse a freed tensor's id() can never hit it."""
+    ri, rg = _last["img"], _last["gt"]
+    ver = (img._version, gt._version, torch.is_grad_enabled(), img.requires_grad)
+    if ri is None or ri() is not img or rg() is not gt or _last["ver"] != ver:
+        _last["val"] = l1_ssim(img, gt)
+        _last["img"], _last["gt"], _last["ver"] = weakref.ref(img), weakref.ref(gt), ver
     return _last["val"]
 
 
