@@ -72,3 +72,28 @@ void hs_backward(const HsView* hv, int n, const float* p, const float* scale, co
 extern "C" int hs_subtile_live(float gx, float gy, float A, float B, float C, float opacity, int bx, int by, int W, int H) {
   return trase::subtile_live(gx, gy, A, B, C, opacity, bx, by, W, H) ? 1 : 0;
 }
+
+// live sub-tiles of a splat's tile rect, enumerated (a) over the whole rect and (b) through the row-span pre-filter:
+// both must give the same set.  Returns the number of live sub-tiles of (a); *mismatch counts the differences.
+extern "C" int hs_subtile_enumerate(float gx, float gy, float A, float B, float C, float opacity, int radius, int W, int H,
+                                    int* mismatch, int* tested_full, int* tested_pruned) {
+  using namespace trase;
+  const int gxt = (W + TILE - 1) / TILE, gyt = (H + TILE - 1) / TILE;
+  int x0, y0, x1, y1;
+  tile_rect(gx, gy, radius, gxt, gyt, x0, y0, x1, y1);
+  const SubtileCull cull = subtile_cull_setup(gx, gy, A, B, C, opacity);
+  int live = 0, bad = 0, nf = 0, np = 0;
+  for (int sy = 2 * y0; sy < 2 * y1; ++sy) {
+    int sx0, sx1;
+    subtile_row_span(cull, sy, H, 2 * x0, 2 * x1, sx0, sx1);
+    for (int sx = 2 * x0; sx < 2 * x1; ++sx) {
+      const int bx = sx * SUB, by = sy * SUB;
+      const bool full = bx < W && by < H && subtile_cull_live(cull, bx, by, W, H);
+      const bool in = sx >= sx0 && sx < sx1;
+      ++nf; np += in;
+      if (full) { ++live; if (!in) ++bad; }
+    }
+  }
+  *mismatch = bad; *tested_full = nf; *tested_pruned = np;
+  return live;
+}

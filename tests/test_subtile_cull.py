@@ -45,3 +45,35 @@ def test_subtile_cull_is_conservative_and_tight(hostsim):
     # the continuous-box bound is tight: few kept blocks are dead (the slack is the gap between
     # the pixel lattice and the continuous box)
     assert kept_dead < 0.25 * kept, (kept_dead, kept)
+
+
+def test_row_span_prefilter_never_drops_a_live_subtile(hostsim):
+    """subtile_row_span (gs_math.h) only pre-filters the candidates that subtile_cull_live decides: over random
+    splats -- elongated, rotated, near and beyond the image border, tiny and huge, low opacity -- the pruned
+    enumeration must find exactly the live set of the full-rect enumeration, and should test far fewer candidates."""
+    hostsim.hs_subtile_enumerate.restype = C.c_int
+    hostsim.hs_subtile_enumerate.argtypes = [C.c_float] * 6 + [C.c_int] * 3 + [C.POINTER(C.c_int)] * 3
+    rng = np.random.default_rng(1)
+    W, H = 333, 205                                   # not multiples of 8 or 16
+    tot_live = tot_full = tot_pruned = 0
+    for it in range(40000):
+        gx, gy = rng.uniform(-40, W + 40), rng.uniform(-40, H + 40)
+        big = it % 7 == 0
+        s1 = rng.uniform(0.55, 60.0 if big else 12.0)
+        s2 = s1 * rng.uniform(0.02, 1.0) if it % 3 == 0 else rng.uniform(0.55, 60.0 if big else 12.0)
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cov = R @ np.diag([s1 * s1, max(s2, 0.55) ** 2]) @ R.T
+        con = np.linalg.inv(cov)
+        A, B, Cc = np.float32(con[0, 0]), np.float32(con[0, 1]), np.float32(con[1, 1])
+        op = np.float32(rng.choice([rng.uniform(0.004, 0.02), rng.uniform(0.02, 1.0)]))
+        lam = 0.5 * (cov[0, 0] + cov[1, 1]) + np.sqrt(max(0.1, (0.5 * (cov[0, 0] + cov[1, 1])) ** 2 - np.linalg.det(cov)))
+        radius = int(np.ceil(3.0 * np.sqrt(lam)))
+        mm, nf, npr = C.c_int(), C.c_int(), C.c_int()
+        live = hostsim.hs_subtile_enumerate(np.float32(gx), np.float32(gy), A, B, Cc, op, radius, W, H, C.byref(mm),
+                                            C.byref(nf), C.byref(npr))
+        assert mm.value == 0, (it, gx, gy, float(A), float(B), float(Cc), float(op), radius, live, mm.value)
+        tot_live += live; tot_full += nf.value; tot_pruned += npr.value
+    assert tot_live > 100000
+    assert tot_pruned < 0.75 * tot_full, (tot_pruned, tot_full)       # the pre-filter does prune
+    assert tot_pruned >= tot_live

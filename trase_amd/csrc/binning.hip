@@ -350,20 +350,20 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   const int gx8 = (W + SUB - 1) / SUB;
   const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
   const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
-  for (int ty = y0; ty < y1; ++ty)
-    for (int tx = x0; tx < x1; ++tx) {
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-        if (off < end && bx < W && by < H && subtile_cull_live(cull, bx, by, W, H)) {
-          if (off < cap) {
-            keys[off] = (uint32_t)((by / SUB) * gx8 + (bx / SUB));
-            pair_gauss[off] = id;
-          }
-          ++off;
+  for (int sy = 2 * y0; sy < 2 * y1 && sy * SUB < H; ++sy) {       // same walk as the count in preprocess
+    int sx0, sx1;
+    subtile_row_span(cull, sy, H, 2 * x0, 2 * x1, sx0, sx1);
+    for (int sx = sx0; sx < sx1; ++sx) {
+      const int bx = sx * SUB, by = sy * SUB;
+      if (off < end && bx < W && subtile_cull_live(cull, bx, by, W, H)) {
+        if (off < cap) {
+          keys[off] = (uint32_t)(sy * gx8 + sx);
+          pair_gauss[off] = id;
         }
+        ++off;
       }
     }
+  }
   // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused
   // slots go to the sentinel sub-tile `trash_key` that no kernel renders (a dropped or padded borderline pair
   // is below the alpha gate by the culling slack, so the image is unaffected)

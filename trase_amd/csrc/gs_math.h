@@ -212,6 +212,7 @@ constexpr int SUB = 8;   // sub-tile edge
 // multiplications, clamps and compares only.
 struct SubtileCull {
   float gx, gy, A, B, C, tau, nb_c, nb_a;   // nb_c = -B/C, nb_a = -B/A: slopes of the edge minimisers
+  float det, inv_a, xmax, ymax, dy_xmax;    // row-span pruning: extents of the ellipse q <= tau, dy at which dx = +xmax
   int mode;                                 // 0: test blocks, 1: never live, 2: always live
 };
 
@@ -221,13 +222,51 @@ TRASE_HD SubtileCull subtile_cull_setup(float gx, float gy, float A, float B, fl
 #endif
   SubtileCull s;
   s.gx = gx; s.gy = gy; s.A = A; s.B = B; s.C = C; s.nb_c = 0.0f; s.nb_a = 0.0f; s.mode = 0;
+  s.det = 0.0f; s.inv_a = 0.0f; s.xmax = 0.0f; s.ymax = 0.0f; s.dy_xmax = 0.0f;
   const float tau_raw = 2.0f * logf(255.0f * opacity);
   s.tau = tau_raw * 1.001f + 1e-3f;
   if (!(tau_raw >= 0.0f)) { s.mode = 1; return s; }   // opacity < 1/255 (or NaN): can never pass the gate
   if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) { s.mode = 2; return s; }   // not positive definite: keep
   s.nb_c = -B / C;
   s.nb_a = -B / A;
+  s.det = A * C - B * B;
+  s.inv_a = 1.0f / A;
+  s.xmax = sqrtf(s.tau * C / s.det);        // half-extent of the ellipse in x ...
+  s.ymax = sqrtf(s.tau * A / s.det);        // ... and in y
+  s.dy_xmax = s.nb_c * s.xmax;              // the point (xmax, dy_xmax) is the ellipse's rightmost point
   return s;
+}
+
+// Sub-tile columns [sx0, sx1) of sub-tile row `sy` that can intersect the ellipse q <= tau: the x-extent of the
+// ellipse restricted to the row's band of pixel centres (attained at a band end or at the ellipse's extreme point),
+// padded by more than any rounding error.  Only a pre-filter: every column inside is still decided by
+// subtile_cull_live, so it merely has to be conservative (checked exhaustively on the host build).
+TRASE_HD void subtile_row_span(const SubtileCull& s, int sy, int H, int sxmin, int sxmax, int& sx0, int& sx1) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  sx0 = sxmin; sx1 = sxmax;
+  if (s.mode == 2) return;                           // not positive definite: every block of the rect is kept
+  if (s.mode == 1) { sx1 = sx0; return; }
+  const float y0 = (float)(sy * SUB), y1 = (float)imin(sy * SUB + SUB - 1, H - 1);
+  const float da = y0 - s.gy, db = y1 - s.gy;        // band of dy = pixel centre - mean
+  const float pad = 0.75f;                           // pixels
+  if (da > s.ymax + pad || db < -s.ymax - pad) { sx1 = sx0; return; }
+  // roots of A dx^2 + 2 B dx dy + C dy^2 = tau at the two band ends (clamped discriminant: an end outside the
+  // ellipse contributes its tangent-direction point, which only widens the span)
+  const float Da = fmaxf(s.A * s.tau - s.det * da * da, 0.0f), Db = fmaxf(s.A * s.tau - s.det * db * db, 0.0f);
+  const float ca = -s.B * da * s.inv_a, cb = -s.B * db * s.inv_a;
+  const float ra = sqrtf(Da) * s.inv_a, rb = sqrtf(Db) * s.inv_a;
+  float hi = fmaxf(ca + ra, cb + rb), lo = fminf(ca - ra, cb - rb);
+  if (s.dy_xmax >= da && s.dy_xmax <= db) hi = s.xmax;       // rightmost point inside the band
+  if (-s.dy_xmax >= da && -s.dy_xmax <= db) lo = -s.xmax;    // leftmost point inside the band
+  hi = fminf(fmaxf(hi, -s.xmax), s.xmax) + pad;
+  lo = fmaxf(fminf(lo, s.xmax), -s.xmax) - pad;
+  const float fx0 = floorf((s.gx + lo) * (1.0f / (float)SUB)), fx1 = floorf((s.gx + hi) * (1.0f / (float)SUB));
+  // clamp in float first: the products can exceed the int range for degenerate splats
+  const int c0 = (int)fminf(fmaxf(fx0, (float)sxmin), (float)sxmax);
+  const int c1 = (int)fminf(fmaxf(fx1 + 1.0f, (float)sxmin), (float)sxmax);
+  sx0 = c0; sx1 = c1 > c0 ? c1 : c0;
 }
 
 TRASE_HD bool subtile_cull_live(const SubtileCull& s, int bx, int by, int W, int H) {

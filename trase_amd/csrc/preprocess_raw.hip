@@ -91,14 +91,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
   uint32_t live = 0;
   if (vis) {
     const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, act.opac);
-    for (int ty = o.y0; ty < o.y1; ++ty)
-      for (int tx = o.x0; tx < o.x1; ++tx) {
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          const int bx = tx * TILE + (sub & 1) * SUB, by = ty * TILE + (sub >> 1) * SUB;
-          if (bx < a.W && by < a.H && subtile_cull_live(cull, bx, by, a.W, a.H)) ++live;
-        }
-      }
+    // candidates: per sub-tile row only the columns the ellipse can reach (subtile_row_span), each decided exactly
+    for (int sy = 2 * o.y0; sy < 2 * o.y1 && sy * SUB < a.H; ++sy) {
+      int sx0, sx1;
+      subtile_row_span(cull, sy, a.H, 2 * o.x0, 2 * o.x1, sx0, sx1);
+      for (int sx = sx0; sx < sx1; ++sx)
+        if (sx * SUB < a.W && subtile_cull_live(cull, sx * SUB, sy * SUB, a.W, a.H)) ++live;
+    }
   }
   if (active) {
     tiles[i] = live;
