@@ -280,6 +280,15 @@ int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int
 int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
                                 const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream);
 
+/* ---- multi-tensor Adam (first half) --------------------------------------------------------
+ * One launch steps up to 16 parameter tensors with per-tensor learning rate and step count, in place
+ * (param, exp_avg, exp_avg_sq), with torch.optim.Adam's arithmetic (no weight decay, no amsgrad):
+ * scene/gaussian_model.py:253-300 builds Adam(l, lr=0.0, eps=1e-15) over per-parameter groups; train.py:376-389
+ * steps it.  The tables (pointers to device tensors, sizes, learning rates, steps) are HOST arrays. */
+int trase_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
+                    double beta2, float eps, int32_t device, trase_stream_t stream);
+
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
  * events and returns averaged milliseconds per kernel name. */

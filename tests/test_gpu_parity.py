@@ -416,6 +416,41 @@ def test_fused_l1_ssim_matches_reference_golden_and_torch():
         del xi, li, si
 
 
+def test_fused_adam_matches_torch_adam():
+    """trase_adam_step (one launch over all tensors) against torch.optim.Adam with the reference's configuration:
+    per-group learning rates, eps = 1e-15, lr changed between steps (update_learning_rate, train.py:388-389), a
+    parameter without gradient in one step, odd sizes (scalar tail path).  Same state layout (step / exp_avg /
+    exp_avg_sq), parameters equal to 1e-6 relative after 5 steps."""
+    from trase_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(30_001, 3), (30_001, 1, 3), (30_001, 15, 3), (30_001, 1), (30_001, 3), (30_001, 4), (30_001, 1, 32), (7,)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 2.5e-3, 1e-2]
+    a = [torch.randn(*sh, device="cuda").requires_grad_(True) for sh in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mk = lambda ps: [{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))]
+    ref = torch.optim.Adam(mk(a), lr=0.0, eps=1e-15)
+    opt = FusedAdam(mk(b), lr=0.0, eps=1e-15)
+    for it in range(5):
+        for k, (pa, pb) in enumerate(zip(a, b)):
+            if it == 2 and k == 3:
+                pa.grad = None; pb.grad = None          # a parameter that received no gradient this step
+                continue
+            g = torch.randn_like(pa) * (10.0 ** (k % 3 - 2))
+            pa.grad = g.clone(); pb.grad = g.clone()
+        ref.step(); opt.step()
+        for go, gr in zip(opt.param_groups, ref.param_groups):          # exponential LR decay of xyz
+            if go["name"] == "0":
+                go["lr"] *= 0.97; gr["lr"] *= 0.97
+    for k, (pa, pb) in enumerate(zip(a, b)):
+        assert float((pa - pb).abs().max()) <= 2e-6 * float(pa.abs().max()), k
+        sa, sb = ref.state[pa], opt.state[pb]
+        assert int(sa["step"]) == int(sb["step"])
+        assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 1e-6 * float(sa["exp_avg"].abs().max()) + 1e-12
+        assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 1e-6 * float(sa["exp_avg_sq"].abs().max()) + 1e-20
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
 def test_deform_mlp_matches_reference_golden():
     """Fused bf16-MFMA DeformNetwork forward vs the golden vectors captured from the imported reference
     (tests/golden/deform_mlp.npz, utils/time_utils.py:60-131).  Tolerance: bf16 inputs/activations with

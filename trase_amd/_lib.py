@@ -145,6 +145,8 @@ SYMBOLS = [
                                              C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_loss_l1_ssim_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("trase_adam_step", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),
