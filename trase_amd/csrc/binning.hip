@@ -409,7 +409,7 @@ int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint3
 
 // ---- backward phase 2: per-Gaussian sum of its (contiguous) per-pair gradient rows ----------------
 // Four depth ranks per wave: a 16-lane group owns one Gaussian and lane t of the group owns columns 4t..4t+3 of
-// its rows (ROW/4 <= 12 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
+// its rows (ROW/4 <= 11 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
 // of dependent loads (rank -> id -> pair range -> flags -> rows) is paid once per four Gaussians.  Writes every
 // Gaussian (zeros where it has no pairs), so neither output needs a memset and the sums are bit-reproducible.
 template <int ROW>
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
                                                           float* __restrict__ d_feats,
                                                           const float* __restrict__ raw_feats, int norm_features) {
-  constexpr int F = ROW - 16, Q = ROW / 4;
+  constexpr int F = ROW - 12, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
   const int r = (blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
@@ -496,9 +496,9 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
   {
     ProfScope ps("reduce_rows", c.stream);
     switch (F) {
-      case 0: hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
-      case 16: hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
-      case 32: hipLaunchKernelGGL(reduce_rows_kernel<48>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 0: hipLaunchKernelGGL(reduce_rows_kernel<12>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 16: hipLaunchKernelGGL(reduce_rows_kernel<28>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 32: hipLaunchKernelGGL(reduce_rows_kernel<44>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
       default: set_error("reduce_rows: feature width %d not compiled in", F); return TRASE_ERR_UNSUPPORTED;
     }
   }

@@ -269,8 +269,8 @@ size_t img_bytes(int W, int H);
 size_t pre_bytes(int P);
 size_t tmp_bytes(int64_t cap);
 size_t bwd_tmp_bytes(int P, int F, int64_t cap);
-static inline int bwd_row_floats(int F) { return F + 16; }
-static inline size_t bwd_chan_bytes(int P) { return (size_t)P * 96 * 2; }   // render_bwd_mf.hip: [P][hi 48 | lo 48] bf16   // per-pair gradient row: F features + 10 scalars, 16-B aligned
+static inline int bwd_row_floats(int F) { return F + 12; }
+static inline size_t bwd_chan_bytes(int P) { return (size_t)P * 96 * 2; }   // render_bwd_mf.hip: [P][hi 48 | lo 48] bf16   // per-pair gradient row: F features + 10 scalars + 2 zeros (a multiple of 16 B)
 GeomBuf carve_geom(void* p, int P);
 BinBuf carve_bin(void* p, int64_t cap, int T);
 ImgBuf carve_img(void* p, int W, int H);

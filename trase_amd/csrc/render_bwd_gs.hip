@@ -28,7 +28,7 @@ struct BwdGsArgs {
   const float* d_img; const float* d_feat; const float* d_depth;
   const float* final_T; const uint32_t* n_contrib;
   const uint32_t* pair_slot;   // emit-order slot of every list entry
-  float* rows;         // (capacity, F+16) one gradient row per pair, indexed by slot
+  float* rows;         // (capacity, F+12) one gradient row per pair, indexed by slot
   uint8_t* row_flags;  // (capacity) 1 where a row was written (zeroed by the caller beforehand)
   int W, H, gx8, ntiles;
   int ablate;          // debug/A-B (variant bits 4..7): bit0 skip the row writes, bit1 builtin instead of asm DPP scans
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     const uint32_t pos = lane_valid ? (c1 - 1 - lane) : 0;     // lane 0 = farthest entry of the chunk
     const uint32_t id = a.point_list[range.x + pos];
     const uint32_t slot = a.pair_slot[range.x + pos];
-    constexpr int ROW = F + 16;
+    constexpr int ROW = F + 12;
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
     const float4 col = a.rgbd[id];
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
       row[F / 4 + 0] = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
       row[F / 4 + 1] = make_float4(a_cc, a_op, a_r, a_g);
       row[F / 4 + 2] = make_float4(a_b, a_d, 0.f, 0.f);
-      row[F / 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
       a.row_flags[slot] = 1;
     }
     wave_lds_sync2();   // carries written by lane 63 are read by the next chunk

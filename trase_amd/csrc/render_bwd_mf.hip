@@ -77,7 +77,7 @@ struct BwdMfArgs {
   const float* final_T; const uint32_t* n_contrib;
   const uint32_t* pair_slot;
   const __bf16* chan;  // [P][96]
-  float* rows;         // (capacity, 48)
+  float* rows;         // (capacity, 44)
   uint8_t* row_flags;
   int W, H, gx8, ntiles;
 };
@@ -95,7 +95,7 @@ __device__ __forceinline__ bf16x8 gather_column(const __bf16* __restrict__ col) 
 
 __global__ __launch_bounds__(MF_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void render_bwd_mf_kernel(BwdMfArgs a) {
-  constexpr int F = 32, ROW = F + 16;
+  constexpr int F = 32, ROW = F + 12;
   __shared__ __attribute__((aligned(16))) __bf16 s_hi[MF_WPB][WAVE * MF_LD];   // cotangents, pixel-major, high parts
   __shared__ __attribute__((aligned(16))) __bf16 s_lo[MF_WPB][WAVE * MF_LD];   // low parts
   __shared__ __attribute__((aligned(16))) float4 s_pix[MF_WPB][WAVE];          // T_end, U_end, last (bits), -
@@ -314,13 +314,12 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
     const float a_ny = -(co.z * Qy + co.y * Qx);
     const float a_ca = -0.5f * Qxx, a_cb = -Qxy, a_cc = -0.5f * Qyy;
     const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
-    // ---- one row per pair: [32 feature sums | nx ny ca cb | cc op r g | b d 0 0 | 0 0 0 0] -----------------------
+    // ---- one row per pair: [32 feature sums | nx ny ca cb | cc op r g | b d 0 0] -----------------------
     if (lane_valid) {
       float* row = a.rows + (size_t)slot * ROW + F;
       *reinterpret_cast<float4*>(row) = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
       *reinterpret_cast<float2*>(row + 4) = make_float2(a_cc, a_op);
       *reinterpret_cast<float2*>(row + 10) = make_float2(0.f, 0.f);
-      *reinterpret_cast<float4*>(row + 12) = make_float4(0.f, 0.f, 0.f, 0.f);
       a.row_flags[slot] = 1;
     }
     // D[gb][nb]: lane (m, h) = Gaussian gb*32 + m, register 4q + r = channel nb*32 + 8q + 4h + r: four consecutive
