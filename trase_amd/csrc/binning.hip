@@ -326,6 +326,12 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 }
 
 // ---- emit (tile, id) pairs in depth-rank order --------------------------------------------------
+// Four lanes (a DPP quad) share one depth rank: with one thread per rank the kernel is a single round of ~4.7k
+// waves whose run time is the serial candidate loop of the slowest lane (~150 iterations).  Each lane of the quad
+// evaluates every fourth candidate sub-tile of the splat's rect, 64 candidates per lane and chunk, keeps the
+// decisions as a bit mask, and the quad's prefix sum places the live ones.  The set of live sub-tiles is the one the
+// preprocess counted (same predicate, bit-identical); the ORDER inside a Gaussian's run is irrelevant -- every key
+// of a run is distinct and the list is sorted by key afterwards.
 __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ sorted_ids, int P,
                                                          const uint32_t* __restrict__ offsets,
                                                          const float2* __restrict__ xy, const float4* __restrict__ conic_o,
@@ -333,42 +339,61 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
                                                          uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = gt >> 2, q = gt & 3;
+  if (gt == 0) {
     if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
     hdr[HDR_WORDS - 2] = cap;
   }
-  if (r >= P) return;
-  const uint32_t id = sorted_ids[r];
-  const uint32_t nt = tiles[id];
-  if (nt == 0) return;
+  const bool in = r < P;
+  const uint32_t id = in ? sorted_ids[r] : 0;
+  const uint32_t nt = in ? tiles[id] : 0;
+  if (nt == 0) return;                            // the whole quad leaves together
   uint32_t off = offsets[r] - nt;
+  const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
   const float2 p = xy[id];
   const float4 co = conic_o[id];
   int x0, y0, x1, y1;
   tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
   const int gx8 = (W + SUB - 1) / SUB;
-  const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
   const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
-  for (int sy = 2 * y0; sy < 2 * y1 && sy * SUB < H; ++sy) {       // same walk as the count in preprocess
-    int sx0, sx1;
-    subtile_row_span(cull, sy, H, 2 * x0, 2 * x1, sx0, sx1);
-    for (int sx = sx0; sx < sx1; ++sx) {
+  const int w8 = 2 * (x1 - x0), n = w8 * 2 * (y1 - y0);            // candidates: the rect in sub-tile units, row major
+  const float inv_w = 1.0f / (float)w8;
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    unsigned long long live = 0ull;
+    for (int k = 0; k < 64; ++k) {
+      const int c = c0 + 4 * k + q;
+      if (c >= n) break;
+      const int row = (int)(((float)c + 0.5f) * inv_w);   // exact: c < 2^22, the quotient is >= 0.5/w8 away from an integer
+      const int sx = 2 * x0 + (c - row * w8), sy = 2 * y0 + row;
       const int bx = sx * SUB, by = sy * SUB;
-      if (off < end && bx < W && subtile_cull_live(cull, bx, by, W, H)) {
-        if (off < cap) {
-          keys[off] = (uint32_t)(sy * gx8 + sx);
-          pair_gauss[off] = id;
-        }
-        ++off;
-      }
+      if (bx < W && by < H && subtile_cull_live(cull, bx, by, W, H)) live |= 1ull << k;
     }
+    // exclusive prefix of the lanes' counts inside the quad (DPP quad_perm broadcasts)
+    const uint32_t cnt = (uint32_t)__popcll(live);
+    const uint32_t c_0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x00, 0xf, 0xf, false);   // quad lane 0
+    const uint32_t c_1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x55, 0xf, 0xf, false);   // quad lane 1
+    const uint32_t c_2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xAA, 0xf, 0xf, false);   // quad lane 2
+    const uint32_t c_3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xFF, 0xf, 0xf, false);   // quad lane 3
+    uint32_t pos = off + (q > 0 ? c_0 : 0u) + (q > 1 ? c_1 : 0u) + (q > 2 ? c_2 : 0u);
+    while (live) {
+      const int k = __builtin_ctzll(live);
+      live &= live - 1;
+      if (pos < end && pos < cap) {
+        const int c = c0 + 4 * k + q;
+        const int row = (int)(((float)c + 0.5f) * inv_w);
+        keys[pos] = (uint32_t)((2 * y0 + row) * gx8 + 2 * x0 + (c - row * w8));
+        pair_gauss[pos] = id;
+      }
+      ++pos;
+    }
+    off += c_0 + c_1 + c_2 + c_3;
   }
   // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused
   // slots go to the sentinel sub-tile `trash_key` that no kernel renders (a dropped or padded borderline pair
   // is below the alpha gate by the culling slack, so the image is unaffected)
-  for (; off < end; ++off)
-    if (off < cap) { keys[off] = trash_key; pair_gauss[off] = id; }
+  for (uint32_t o = off + q; o < end; o += 4)
+    if (o < cap) { keys[o] = trash_key; pair_gauss[o] = id; }
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
@@ -376,7 +401,7 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
   const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
   {
     ProfScope ps("emit_pairs", c.stream);
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((4 * P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
                        g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
                        (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)));
   }
