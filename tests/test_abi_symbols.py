@@ -56,7 +56,7 @@ def test_sizes_call_works_without_gpu():
     lib = _lib.load()
     sz = _lib.RastSizes()
     assert lib.trase_rast_sizes(1000, 640, 360, 32, 50000, C.byref(sz)) == 0
-    assert sz.geom_bytes > 1000 * 48 and sz.bin_bytes >= 50000 * 8 and sz.bwd_tmp_bytes >= 50000 * 48 * 4
+    assert sz.geom_bytes > 1000 * 48 and sz.bin_bytes >= 50000 * 8 and sz.bwd_tmp_bytes >= 50000 * 44 * 4
     assert lib.trase_rast_sizes(-1, 640, 360, 32, 1, C.byref(sz)) != 0
     assert b"bad arguments" in lib.trase_last_error()
 
