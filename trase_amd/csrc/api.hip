@@ -267,7 +267,8 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     const int final_idx = passes & 1;
     t.sort.vals[final_idx] = b.pair_slot;
     t.sort.vals[final_idx ^ 1] = t.spare_vals;
-    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap);
+    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap,
+                           (s->variant & 0x200) ? nullptr : b.ranges);
     if (rc) return rc;
     int idx = 0;
     rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
@@ -278,7 +279,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
                                      b.point_list, g.hdr + 16);
       if (rc) return rc;
     } else {                        // default: ranges only; the forward's staging step does the gather
-      rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, g.hdr + 16);
+      rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, g.hdr + 16, false);
       if (rc) return rc;
       return launch_render_fwd(c, *s, *in, *out, g, b, im, t.pair_gauss, (uint32_t)cap);
     }
@@ -336,9 +337,12 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   } else {
     // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
     // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
-    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-    rc = (in2.F == 32 && !(s->variant & 0x40)) ? launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan)
-                                               : launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags);
+    if (in2.F == 32 && !(s->variant & 0x40)) {
+      rc = launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+    } else {
+      TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+      rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags);
+    }
     if (rc) return rc;
     rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
     if (rc) return rc;
@@ -436,9 +440,12 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
     in.F = 0;
     d_feats = nullptr;
   }
-  TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-  rc = (in.F == 32 && !(s->variant & 0x40)) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan)
-                                            : launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+  if (in.F == 32 && !(s->variant & 0x40)) {
+    rc = launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+  } else {
+    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+    rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+  }
   if (rc) return rc;
   rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features);
   if (rc) return rc;

@@ -338,9 +338,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          const int32_t* __restrict__ radii,
                                                          const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
-                                                         uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key) {
+                                                         uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key,
+                                                         uint2* __restrict__ ranges) {
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = gt >> 2, q = gt & 3;
+  // the sub-tile ranges (trash_key + 1 entries incl. the sentinel) are cleared here: tile_ranges runs after the sort
+  if (ranges)
+    for (uint32_t i = (uint32_t)gt; i <= trash_key; i += gridDim.x * blockDim.x) ranges[i] = make_uint2(0u, 0u);
   if (gt == 0) {
     if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
     hdr[HDR_WORDS - 2] = cap;
@@ -397,13 +401,14 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
-                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap) {
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
+                      uint2* ranges_to_clear) {
   const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
   {
     ProfScope ps("emit_pairs", c.stream);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((4 * P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
                        g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
-                       (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)));
+                       (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)), ranges_to_clear);
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
   return TRASE_OK;
@@ -575,8 +580,8 @@ int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const ui
 }
 
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
-                       uint32_t* dbg) {
-  TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
+                       uint32_t* dbg, bool clear) {
+  if (clear) TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
   int blocks = (int)((cap + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;

@@ -300,7 +300,8 @@ int radix_passes(int bit_lo, int bit_hi);
 
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap);
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
-                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap);
+                      const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
+                      uint2* ranges_to_clear = nullptr);
 int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
                       uint32_t cap, uint32_t* point_list);
 // raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)
@@ -308,7 +309,7 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
                        int norm_features = 0);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
-                       uint32_t* dbg = nullptr);
+                       uint32_t* dbg = nullptr, bool clear = true);
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
                               int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
                               uint32_t* dbg);
@@ -320,7 +321,7 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan);
+                         void* chan, size_t flag_bytes);   // clears flag_bytes (a multiple of 16) of row_flags itself
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

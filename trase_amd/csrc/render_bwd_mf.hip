@@ -48,8 +48,11 @@ __device__ __forceinline__ void split2(float x, unsigned& hi, unsigned& lo) {
 
 // ---- per view: channel table [P][hi 48 | lo 48] ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_channels_kernel(const float* __restrict__ feats, const float4* __restrict__ rgbd,
-                                                             int P, __bf16* __restrict__ out) {
+                                                             int P, __bf16* __restrict__ out, uint4* __restrict__ flags16,
+                                                             size_t nflags16) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (Gaussian, group of 8 channels)
+  // the row flags of the backward are cleared here (saves a separate fill launch)
+  for (size_t i = (size_t)idx; i < nflags16; i += (size_t)gridDim.x * blockDim.x) flags16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (idx >= P * 6) return;
   const int g = idx / 6, grp = idx % 6;
   float v[8];
@@ -348,7 +351,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
 
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan) {
+                         void* chan, size_t flag_bytes) {
   BwdMfArgs a;
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
@@ -360,7 +363,7 @@ int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   {
     ProfScope ps("split_channels", c.stream);
     hipLaunchKernelGGL(split_channels_kernel, dim3((in.P * 6 + 255) / 256), dim3(256), 0, c.stream, in.sh_objs, g.rgbd, in.P,
-                       (__bf16*)chan);
+                       (__bf16*)chan, reinterpret_cast<uint4*>(row_flags), flag_bytes / 16);
   }
   TRASE_POST_LAUNCH("split_channels", c.stream, c.debug);
   {
