@@ -171,14 +171,33 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  // Block-local layout: items are first placed in LDS in their sorted order inside the block (digit-major, then
+  // wave, then rank), then written out by consecutive threads -- a digit's run inside the block is contiguous in
+  // the output too, so the stores are coalesced runs instead of 4-byte writes scattered over the whole array.
+  __shared__ uint32_t gbase[256], lstart[256], scan_tmp[256];
+  __shared__ uint32_t st_k[RS_TILE], st_v[RS_TILE];
   {
     const int d = threadIdx.x;
-    uint32_t run = hist[(size_t)d * nb_max + blockIdx.x];
+    uint32_t tot = 0;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) {
-      wbase[w][d] = run;
-      run += wcount[w][d];
+      wbase[w][d] = tot;                           // items of digit d in earlier waves of this block
+      tot += wcount[w][d];
     }
+    gbase[d] = hist[(size_t)d * nb_max + blockIdx.x];
+    scan_tmp[d] = tot;
+  }
+  __syncthreads();
+  {                                                // exclusive scan of the block's digit counts (Hillis-Steele)
+    const int d = threadIdx.x;
+    const uint32_t mine = scan_tmp[d];
+    for (int sft = 1; sft < 256; sft <<= 1) {
+      const uint32_t add = (d >= sft) ? scan_tmp[d - sft] : 0u;
+      __syncthreads();
+      scan_tmp[d] += add;
+      __syncthreads();
+    }
+    lstart[d] = scan_tmp[d] - mine;
   }
   __syncthreads();
 #pragma unroll
@@ -186,10 +205,19 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
     if (idx < n) {
       const uint32_t dg = (k[i] >> shift) & mask;
-      const uint32_t dst = wbase[wave][dg] + rk[i];
-      keys_out[dst] = k[i];
-      vals_out[dst] = v[i];
+      const uint32_t lp = lstart[dg] + wbase[wave][dg] + rk[i];
+      st_k[lp] = k[i];
+      st_v[lp] = v[i];
     }
+  }
+  __syncthreads();
+  const uint32_t nblk = min((uint32_t)RS_TILE, n - base);
+  for (uint32_t j = threadIdx.x; j < nblk; j += RS_THREADS) {
+    const uint32_t kk = st_k[j];
+    const uint32_t dg = (kk >> shift) & mask;
+    const uint32_t dst = gbase[dg] + (j - lstart[dg]);
+    keys_out[dst] = kk;
+    vals_out[dst] = st_v[j];
   }
 }
 
