@@ -60,44 +60,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
   hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = h[threadIdx.x];
 }
 
-// ---- pass kernel 1b: per-digit totals (one workgroup per digit sums its histogram row) --------------
-// (kept out of the histogram kernel: thousands of workgroups hammering 256 global counters with atomics
-// cost more than the whole histogram)
-__global__ __launch_bounds__(256) void radix_total_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                          const uint32_t* __restrict__ hist,
-                                                          uint32_t* __restrict__ digit_total, int nb_max) {
-  const uint32_t n = dev_n(n_ptr, cap);
-  const int nb = (int)((n + RS_TILE - 1) / RS_TILE);
-  const uint32_t* row = hist + (size_t)blockIdx.x * nb_max;
-  uint32_t s = 0;
-  for (int b = threadIdx.x; b < nb; b += 256) s += row[b];
-  __shared__ uint32_t sh[256];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
-    if (threadIdx.x < (unsigned)k) sh[threadIdx.x] += sh[threadIdx.x + k];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) digit_total[blockIdx.x] = sh[0];
-}
-
 // ---- pass kernel 2: one workgroup per digit scans its row of the histogram --------------------
 __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                          uint32_t* __restrict__ hist,
-                                                         const uint32_t* __restrict__ digit_total, int nb_max) {
+                                                         uint32_t* __restrict__ digit_total, int nb_max) {
   const uint32_t n = dev_n(n_ptr, cap);
   const int nb = (int)((n + RS_TILE - 1) / RS_TILE);
   const int d = blockIdx.x;
   __shared__ uint32_t sh[256];
   __shared__ uint32_t carry;
-  // base = number of items with a smaller digit
-  sh[threadIdx.x] = (threadIdx.x < (unsigned)d) ? digit_total[threadIdx.x] : 0u;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < (unsigned)s) sh[threadIdx.x] += sh[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) carry = sh[0];
+  // exclusive scan of the row over the workgroups; the row total (= number of items with this digit) goes to
+  // digit_total, whose scan over the digits is done by the scatter workgroups themselves
+  if (threadIdx.x == 0) carry = 0u;
   __syncthreads();
   uint32_t* row = hist + (size_t)d * nb_max;
   for (int b0 = 0; b0 < nb; b0 += 256) {
@@ -119,6 +93,7 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
     if (threadIdx.x == 255) carry = c0 + incl;
     __syncthreads();
   }
+  if (threadIdx.x == 0) digit_total[d] = carry;
 }
 
 // ---- pass kernel 3: stable scatter -------------------------------------------------------------
@@ -130,7 +105,7 @@ template <bool IOTA>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
-    const uint32_t* __restrict__ hist, int nb_max) {
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total, int nb_max) {
   const uint32_t n = dev_n(n_ptr, cap);
   const uint32_t base = blockIdx.x * RS_TILE;
   if (base >= n) return;
@@ -174,7 +149,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   // Block-local layout: items are first placed in LDS in their sorted order inside the block (digit-major, then
   // wave, then rank), then written out by consecutive threads -- a digit's run inside the block is contiguous in
   // the output too, so the stores are coalesced runs instead of 4-byte writes scattered over the whole array.
-  __shared__ uint32_t gbase[256], lstart[256], scan_tmp[256];
+  __shared__ uint32_t gbase[256], lstart[256], scan_tmp[256], scan_dig[256];
   __shared__ uint32_t st_k[RS_TILE], st_v[RS_TILE];
   {
     const int d = threadIdx.x;
@@ -184,20 +159,24 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       wbase[w][d] = tot;                           // items of digit d in earlier waves of this block
       tot += wcount[w][d];
     }
-    gbase[d] = hist[(size_t)d * nb_max + blockIdx.x];
     scan_tmp[d] = tot;
+    scan_dig[d] = digit_total[d];
   }
   __syncthreads();
-  {                                                // exclusive scan of the block's digit counts (Hillis-Steele)
+  {   // two exclusive scans over the digits at once (Hillis-Steele): this block's counts -> LDS layout, the global
+      // digit totals -> number of items with a smaller digit
     const int d = threadIdx.x;
-    const uint32_t mine = scan_tmp[d];
+    const uint32_t mine = scan_tmp[d], mine_g = scan_dig[d];
     for (int sft = 1; sft < 256; sft <<= 1) {
       const uint32_t add = (d >= sft) ? scan_tmp[d - sft] : 0u;
+      const uint32_t add_g = (d >= sft) ? scan_dig[d - sft] : 0u;
       __syncthreads();
       scan_tmp[d] += add;
+      scan_dig[d] += add_g;
       __syncthreads();
     }
     lstart[d] = scan_tmp[d] - mine;
+    gbase[d] = (scan_dig[d] - mine_g) + hist[(size_t)d * nb_max + blockIdx.x];
   }
   __syncthreads();
 #pragma unroll
@@ -244,7 +223,6 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
     TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
     {
       ProfScope ps("radix_scan", c.stream);
-      hipLaunchKernelGGL(radix_total_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
       hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_scan", c.stream, c.debug);
@@ -252,10 +230,10 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
       ProfScope ps("radix_scatter", c.stream);
       if (vals_are_iota && p == 0)
         hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
-                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, t.nb_max);
+                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, dt, t.nb_max);
       else
         hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
-                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, t.nb_max);
+                           t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_scatter", c.stream, c.debug);
     cur ^= 1;
