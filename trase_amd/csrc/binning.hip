@@ -74,25 +74,23 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) carry = 0u;
   __syncthreads();
   uint32_t* row = hist + (size_t)d * nb_max;
-  for (int b0 = 0; b0 < nb; b0 += 256) {
-    const int b = b0 + threadIdx.x;
-    const uint32_t v = (b < nb) ? row[b] : 0u;
-    // inclusive Hillis-Steele scan in LDS
-    sh[threadIdx.x] = v;
+  // every thread owns a contiguous piece of the row: serial sum, one block-wide scan of the 256 sums, serial rewrite
+  const int per = (nb + 255) / 256;
+  const int b_lo = threadIdx.x * per, b_hi = min(b_lo + per, nb);
+  uint32_t mine = 0;
+  for (int b = b_lo; b < b_hi; ++b) mine += row[b];
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int s = 1; s < 256; s <<= 1) {
+    const uint32_t add = (threadIdx.x >= (unsigned)s) ? sh[threadIdx.x - s] : 0u;
     __syncthreads();
-    for (int s = 1; s < 256; s <<= 1) {
-      const uint32_t add = (threadIdx.x >= (unsigned)s) ? sh[threadIdx.x - s] : 0u;
-      __syncthreads();
-      sh[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const uint32_t incl = sh[threadIdx.x];
-    const uint32_t c0 = carry;
-    if (b < nb) row[b] = c0 + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry = c0 + incl;
+    sh[threadIdx.x] += add;
     __syncthreads();
   }
+  uint32_t run = sh[threadIdx.x] - mine;
+  for (int b = b_lo; b < b_hi; ++b) { const uint32_t v = row[b]; row[b] = run; run += v; }
+  if (threadIdx.x == 255) carry = sh[255];
+  __syncthreads();
   if (threadIdx.x == 0) digit_total[d] = carry;
 }
 
