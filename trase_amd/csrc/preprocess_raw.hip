@@ -60,8 +60,18 @@ __device__ __forceinline__ void load_sh_split(const RawFwdArgs& a, int i, float 
   const float* dc = a.f_dc + 3 * (size_t)i;
   const float* rest = a.f_rest + 45 * (size_t)i;
   shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
+  // 45 consecutive floats per Gaussian, 4-byte aligned: eleven 16-byte loads + one instead of 45 dword loads (a
+  // wave-wide dword load of a 180-byte-strided array touches 64 lines per instruction either way)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  float r[48];
 #pragma unroll
-  for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? rest[k - 3] : 0.f;
+  for (int k4 = 0; k4 < 11; ++k4) {
+    const f4u v = *reinterpret_cast<const f4u*>(rest + 4 * k4);
+    r[4 * k4] = v[0]; r[4 * k4 + 1] = v[1]; r[4 * k4 + 2] = v[2]; r[4 * k4 + 3] = v[3];
+  }
+  r[44] = rest[44];
+#pragma unroll
+  for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? r[k - 3] : 0.f;
 }
 
 template <int F>
@@ -213,8 +223,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_raw_kernel(RawFwdArgs a, c
   if (o.d_f_dc) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
   if (o.d_f_rest) {
     float* dst = o.d_f_rest + 45 * (size_t)i;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 180-byte rows: 4-byte aligned 16-byte stores
 #pragma unroll
-    for (int k = 0; k < 45; ++k) dst[k] = dsh[3 + k];
+    for (int k4 = 0; k4 < 11; ++k4)
+      *reinterpret_cast<f4u*>(dst + 4 * k4) = f4u{dsh[3 + 4 * k4], dsh[4 + 4 * k4], dsh[5 + 4 * k4], dsh[6 + 4 * k4]};
+    dst[44] = dsh[47];
   }
 }
 
