@@ -60,6 +60,25 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
   hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = h[threadIdx.x];
 }
 
+// inclusive scan over the 256 threads of a workgroup: a DPP scan inside every wave, then the three lower waves'
+// totals through LDS (two barriers instead of the sixteen of a Hillis-Steele scan in LDS)
+__device__ __forceinline__ uint32_t block256_incl_scan(uint32_t v, uint32_t* part /* [4] in LDS */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) part[wave] = x;
+  __syncthreads();
+  uint32_t add = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) add += (w < wave) ? part[w] : 0u;
+  __syncthreads();
+  return x + add;
+}
+
 // ---- pass kernel 2: one workgroup per digit scans its row of the histogram --------------------
 __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                          uint32_t* __restrict__ hist,
@@ -79,17 +98,10 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
   const int b_lo = threadIdx.x * per, b_hi = min(b_lo + per, nb);
   uint32_t mine = 0;
   for (int b = b_lo; b < b_hi; ++b) mine += row[b];
-  sh[threadIdx.x] = mine;
-  __syncthreads();
-  for (int s = 1; s < 256; s <<= 1) {
-    const uint32_t add = (threadIdx.x >= (unsigned)s) ? sh[threadIdx.x - s] : 0u;
-    __syncthreads();
-    sh[threadIdx.x] += add;
-    __syncthreads();
-  }
-  uint32_t run = sh[threadIdx.x] - mine;
+  const uint32_t incl = block256_incl_scan(mine, sh);
+  uint32_t run = incl - mine;
   for (int b = b_lo; b < b_hi; ++b) { const uint32_t v = row[b]; row[b] = run; run += v; }
-  if (threadIdx.x == 255) carry = sh[255];
+  if (threadIdx.x == 255) carry = incl;
   __syncthreads();
   if (threadIdx.x == 0) digit_total[d] = carry;
 }
@@ -161,20 +173,15 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     scan_dig[d] = digit_total[d];
   }
   __syncthreads();
-  {   // two exclusive scans over the digits at once (Hillis-Steele): this block's counts -> LDS layout, the global
-      // digit totals -> number of items with a smaller digit
+  {   // two exclusive scans over the digits: this block's counts -> LDS layout, the global digit totals -> number of
+      // items with a smaller digit
     const int d = threadIdx.x;
     const uint32_t mine = scan_tmp[d], mine_g = scan_dig[d];
-    for (int sft = 1; sft < 256; sft <<= 1) {
-      const uint32_t add = (d >= sft) ? scan_tmp[d - sft] : 0u;
-      const uint32_t add_g = (d >= sft) ? scan_dig[d - sft] : 0u;
-      __syncthreads();
-      scan_tmp[d] += add;
-      scan_dig[d] += add_g;
-      __syncthreads();
-    }
-    lstart[d] = scan_tmp[d] - mine;
-    gbase[d] = (scan_dig[d] - mine_g) + hist[(size_t)d * nb_max + blockIdx.x];
+    __shared__ uint32_t part_a[4], part_b[4];
+    const uint32_t ia = block256_incl_scan(mine, part_a);
+    const uint32_t ig = block256_incl_scan(mine_g, part_b);
+    lstart[d] = ia - mine;
+    gbase[d] = (ig - mine_g) + hist[(size_t)d * nb_max + blockIdx.x];
   }
   __syncthreads();
 #pragma unroll
