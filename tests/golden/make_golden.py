@@ -10,6 +10,7 @@ Fixtures:
   G3 camera.npz         utils/graphics_utils.py:45-77 getWorld2View2/getProjectionMatrix + scene/cameras.py:76-79
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
+  G6 contrastive.npz    utils/loss_utils.py:304-349 soft hard-positive / soft negative pixel-pair losses
 """
 import math
 import os
@@ -143,6 +144,23 @@ def main():
     total.backward()
     np.savez_compressed(os.path.join(HERE, "losses.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=ss.item(),
                         total=total.item(), grad_a=a.grad.numpy())
+    # ---- G6: contrastive pixel-pair losses, 'soft' mode (arguments/__init__.py:131), utils/loss_utils.py:304-349
+    from utils.loss_utils import positive_pixel_pair_loss, negative_pixel_pair_loss
+    torch.manual_seed(6)
+    S, nm = 192, 9
+    memb = (torch.rand(nm, S) < 0.25).float()              # pixel-mask correspondence vectors (utils/feature_utils.py:46-55)
+    C = torch.einsum("nh,nj->hj", memb, memb)
+    C[C != 0] = 1
+    f = torch.nn.functional.normalize(torch.randn(S, 32) + 1.5 * memb.t() @ torch.randn(nm, 32), dim=-1)
+    f.requires_grad_(True)
+    CF = torch.einsum("hc,jc->hj", f, f)
+    CF.retain_grad()
+    wts = 1.0 + 9.0 * torch.rand(S, S)
+    lp = positive_pixel_pair_loss["soft"](C=C, C_F=CF, positive_th=0.75, weights=wts)
+    ln = negative_pixel_pair_loss["soft"](C=C, C_F=CF, negative_th=0.5, weights=wts)
+    (lp + ln).backward()
+    np.savez_compressed(os.path.join(HERE, "contrastive.npz"), C=C.numpy(), CF=CF.detach().numpy(), weights=wts.numpy(),
+                        loss_pos=float(lp), loss_neg=float(ln), grad_CF=CF.grad.numpy())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -416,6 +416,72 @@ def test_fused_l1_ssim_matches_reference_golden_and_torch():
         del xi, li, si
 
 
+def _ref_soft_losses(C, C_F, pth, nth, w):
+    """utils/loss_utils.py:304-349 restated (soft hard-positive + soft negative), PyTorch."""
+    n = C_F.shape[0]
+    diag = torch.eye(n, dtype=torch.bool, device=C_F.device)
+    out = []
+    for neg in (False, True):
+        cond = torch.logical_and(C_F > nth, C == 0) if neg else torch.logical_and(C_F < pth, C == 1)
+        m = torch.triu(torch.logical_and(torch.any(cond, dim=0), ~diag), diagonal=0)
+        npair = torch.nonzero(m).shape[0]
+        m = torch.logical_and(m, C == (0 if neg else 1))
+        if m.sum() == 0:
+            out.append(torch.zeros((), device=C_F.device))
+        elif neg:
+            out.append((w[m] * torch.relu(C_F[m])).sum() / npair)
+        else:
+            out.append((-w[m] * C_F[m]).sum() / npair)
+    return out
+
+
+def test_fused_contrastive_soft_losses_match_reference_golden_and_torch():
+    """trase_contrastive_forward / _backward against (a) golden vectors from the imported reference
+    (tests/golden/contrastive.npz: positive_pixel_pair_loss['soft'] + negative_pixel_pair_loss['soft'],
+    utils/loss_utils.py:304-349, with weights) and (b) the PyTorch restatement at a ragged size (S = 1337, not a multiple
+    of the 64 x 256 tiles), without weights, plus the empty-selection case (loss 0, zero gradient).
+    Scalars to 1e-5 relative, gradients to 1e-5 of their scale; deterministic."""
+    import os
+    from trase_amd.losses import (pixel_mask_correspondence_loss_soft_hard_positive as soft_pos,
+                                  pixel_mask_correspondence_loss_soft_negative as soft_neg)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive.npz"))
+    C = torch.from_numpy(d["C"]).cuda()
+    CF = torch.from_numpy(d["CF"]).cuda().requires_grad_(True)
+    w = torch.from_numpy(d["weights"]).cuda()
+    lp = soft_pos(C=C, C_F=CF, positive_th=0.75, weights=w)
+    ln = soft_neg(C=C, C_F=CF, negative_th=0.5, weights=w)
+    assert abs(float(lp.detach()) - float(d["loss_pos"])) < 1e-5 * abs(float(d["loss_pos"]))
+    assert abs(float(ln.detach()) - float(d["loss_neg"])) < 1e-5 * abs(float(d["loss_neg"]))
+    (lp + ln).backward()
+    want = torch.from_numpy(d["grad_CF"]).cuda()
+    assert float((CF.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert int(((CF.grad != 0) != (want != 0)).sum()) == 0
+    # ragged size, no weights
+    torch.manual_seed(4)
+    S, nm = 1337, 23
+    memb = (torch.rand(nm, S, device="cuda") < 0.15).float()
+    C2 = (memb.t() @ memb != 0).float()
+    f = torch.nn.functional.normalize(torch.randn(S, 32, device="cuda") + 1.2 * memb.t() @ torch.randn(nm, 32, device="cuda"), dim=-1)
+    CFa = (f @ f.t()).requires_grad_(True)
+    ones = torch.ones(S, S, device="cuda")
+    rp, rn = _ref_soft_losses(C2, CFa, 0.75, 0.5, ones)
+    (rp + 2.0 * rn).backward()
+    CFb = CFa.detach().clone().requires_grad_(True)
+    gp, gn = soft_pos(C2, CFb, 0.75), soft_neg(C2, CFb, 0.5)
+    assert abs(float(gp.detach() - rp.detach())) < 1e-5 * abs(float(rp.detach())) + 1e-7
+    assert abs(float(gn.detach() - rn.detach())) < 1e-5 * abs(float(rn.detach())) + 1e-7
+    (gp + 2.0 * gn).backward()
+    assert float((CFb.grad - CFa.grad).abs().max()) < 1e-5 * float(CFa.grad.abs().max())
+    CFc = CFa.detach().clone().requires_grad_(True)
+    (soft_pos(C2, CFc, 0.75) + 2.0 * soft_neg(C2, CFc, 0.5)).backward()
+    assert torch.equal(CFc.grad, CFb.grad)
+    # nothing selected: every similarity of a positive pair is above the threshold
+    CFd = torch.ones(64, 64, device="cuda", requires_grad=True)
+    l0 = soft_pos(torch.ones(64, 64, device="cuda"), CFd, 0.75)
+    l0.backward()
+    assert float(l0.detach()) == 0.0 and float(CFd.grad.abs().max()) == 0.0
+
+
 def test_fused_adam_matches_torch_adam():
     """trase_adam_step (one launch over all tensors) against torch.optim.Adam with the reference's configuration:
     per-group learning rates, eps = 1e-15, lr changed between steps (update_learning_rate, train.py:388-389), a

@@ -89,3 +89,62 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     if window_size != 11 or not size_average:
         raise NotImplementedError("trase_amd.losses.ssim: only window_size=11, size_average=True is compiled in")
     return _fused(img1, img2)[1]
+
+
+# ---- contrastive pixel-pair losses, 'soft' mode (utils/loss_utils.py:304-349) ------------------------------------------
+class _ContrastiveSoft(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, C_F, Cm, weights, th, negative):
+        lib = _lib.load()
+        dev = C_F.device
+        S = C_F.shape[0]
+        cf = C_F.detach().float().contiguous()
+        cm = Cm.detach().float().contiguous()
+        wt = None if weights is None else weights.detach().float().contiguous()
+        nbytes = C.c_size_t()
+        _lib.check(lib.trase_contrastive_sizes(S, C.byref(nbytes)), "trase_contrastive_sizes")
+        ws = _bytes(nbytes.value, dev)
+        out2 = torch.empty(2, device=dev)
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_contrastive_forward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, float(th), int(negative),
+                                                 _lib.ptr(out2), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
+                   "trase_contrastive_forward")
+        ctx.save_for_backward(cf, cm, ws, out2, *(() if wt is None else (wt,)))
+        ctx.negative = int(negative)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        cf, cm, ws, out2, *rest = ctx.saved_tensors
+        wt = rest[0] if rest else None
+        dev = cf.device
+        S = cf.shape[0]
+        d_cf = torch.empty_like(cf)
+        gg = g.reshape(1).float().contiguous()
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_contrastive_backward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, ctx.negative, _lib.ptr(out2),
+                                                  _lib.ptr(gg), _lib.ptr(ws), ws.numel(), _lib.ptr(d_cf), d, _stream(dev)),
+                   "trase_contrastive_backward")
+        return d_cf, None, None, None, None
+
+
+def _contrastive(C_mat, C_F, th, weights, negative):
+    if C_F.device.type != "cuda":
+        raise RuntimeError("trase_amd.losses runs on the GPU only (there is no CPU path)")
+    if C_F.dim() != 2 or C_F.shape[0] != C_F.shape[1] or C_mat.shape != C_F.shape or (weights is not None and weights.shape != C_F.shape):
+        raise ValueError("expected square C, C_F (and weights) of equal shape")
+    return _ContrastiveSoft.apply(C_F, C_mat, weights, th, negative)
+
+
+def pixel_mask_correspondence_loss_soft_hard_positive(C, C_F, positive_th=0.75, weights=None, verbose=False, log_tb=False,
+                                                      tb_writer=None, iteration=None):
+    """utils/loss_utils.py:304-327 (``positive_pixel_pair_loss['soft']``).  Differences: no host synchronisation, so
+    the "[WARNING] no positive sample found" print is gone and an empty selection yields a zero TENSOR."""
+    return _contrastive(C, C_F, positive_th, weights, 0)
+
+
+def pixel_mask_correspondence_loss_soft_negative(C, C_F, negative_th=0.5, weights=None, verbose=False, log_tb=False,
+                                                 tb_writer=None, iteration=None):
+    """utils/loss_utils.py:329-349 (``negative_pixel_pair_loss['soft']``)."""
+    return _contrastive(C, C_F, negative_th, weights, 1)
