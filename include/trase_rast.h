@@ -280,20 +280,29 @@ int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int
 int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
                                 const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream);
 
-/* ---- contrastive pixel-pair losses, 'soft' mode (second half) -----------------------------
- * pixel_mask_correspondence_loss_soft_hard_positive / _soft_negative (utils/loss_utils.py:304-349), selected by
- * opt.contrastive_mode = 'soft' (arguments/__init__.py:131) and called at train.py:290-291 on the S x S matrices
- * C (0/1 pixel-mask correspondence), C_F (feature similarity) and weights (may be NULL).  negative = 0 / 1 picks the
- * loss.  out2 = {loss, number of candidate pairs N} (device floats); `ws` (trase_contrastive_sizes bytes) keeps the
- * column flags for the backward, which writes the dense dL/dC_F (S x S) for the upstream gradient g (device scalar).
- * Nothing synchronises (the reference calls torch.nonzero twice per loss). */
+/* ---- contrastive pixel-pair losses (second half) -------------------------------------------
+ * positive_pixel_pair_loss / negative_pixel_pair_loss (utils/loss_utils.py:396-406), selected by
+ * opt.contrastive_mode (arguments/__init__.py:131; default 'soft') and called at train.py:290-291 on the S x S matrices
+ * C (0/1 pixel-mask correspondence), C_F (feature similarity) and weights (may be NULL).
+ * kind = TRASE_PAIR_POSITIVE|NEGATIVE + TRASE_PAIR_SOFT|ALL|HARD:
+ *   soft: utils/loss_utils.py:304-349   all: :275-302 (threshold unused)   hard: :351-394.
+ * out2 = {loss, N} (device floats; N = number of candidate pairs, for 'hard' the selection size); `ws`
+ * (trase_contrastive_sizes bytes) keeps the column flags for the backward, which writes the dense dL/dC_F (S x S) for
+ * the upstream gradient g (device scalar).  Nothing synchronises (the reference calls torch.nonzero per loss).  An
+ * empty candidate set gives loss 0 with a zero gradient (the reference: python 0.0 / tensor(0.) for soft / hard, and
+ * 0/0 = nan for 'all'). */
+#define TRASE_PAIR_POSITIVE 0
+#define TRASE_PAIR_NEGATIVE 1
+#define TRASE_PAIR_SOFT 0
+#define TRASE_PAIR_ALL 2
+#define TRASE_PAIR_HARD 4
 int trase_contrastive_sizes(int32_t S, size_t* ws_bytes);
 int trase_contrastive_forward(const float* C, const float* C_F, const float* weights, int32_t S, float threshold,
-                              int32_t negative, float* out2, void* ws, size_t ws_bytes, int32_t device,
+                              int32_t kind, float* out2, void* ws, size_t ws_bytes, int32_t device,
                               trase_stream_t stream);
-int trase_contrastive_backward(const float* C, const float* C_F, const float* weights, int32_t S, int32_t negative,
-                               const float* out2, const float* g, const void* ws, size_t ws_bytes, float* dL_dC_F,
-                               int32_t device, trase_stream_t stream);
+int trase_contrastive_backward(const float* C, const float* C_F, const float* weights, int32_t S, float threshold,
+                               int32_t kind, const float* out2, const float* g, const void* ws, size_t ws_bytes,
+                               float* dL_dC_F, int32_t device, trase_stream_t stream);
 
 /* ---- multi-tensor Adam (first half) --------------------------------------------------------
  * One launch steps up to 16 parameter tensors with per-tensor learning rate and step count, in place

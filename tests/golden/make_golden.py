@@ -10,7 +10,7 @@ Fixtures:
   G3 camera.npz         utils/graphics_utils.py:45-77 getWorld2View2/getProjectionMatrix + scene/cameras.py:76-79
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
-  G6 contrastive.npz    utils/loss_utils.py:304-349 soft hard-positive / soft negative pixel-pair losses
+  G6 contrastive.npz    utils/loss_utils.py:275-406 pixel-pair losses, modes soft / all / hard
 """
 import math
 import os
@@ -159,8 +159,15 @@ def main():
     lp = positive_pixel_pair_loss["soft"](C=C, C_F=CF, positive_th=0.75, weights=wts)
     ln = negative_pixel_pair_loss["soft"](C=C, C_F=CF, negative_th=0.5, weights=wts)
     (lp + ln).backward()
+    extra = {}
+    for mode in ("all", "hard"):                           # utils/loss_utils.py:275-302 and :351-394
+        CFm = CF.detach().clone().requires_grad_(True)
+        mp = positive_pixel_pair_loss[mode](C=C, C_F=CFm, positive_th=0.75, weights=wts)
+        mn = negative_pixel_pair_loss[mode](C=C, C_F=CFm, negative_th=0.5, weights=wts)
+        (mp + mn).backward()
+        extra.update({f"loss_pos_{mode}": float(mp), f"loss_neg_{mode}": float(mn), f"grad_CF_{mode}": CFm.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, "contrastive.npz"), C=C.numpy(), CF=CF.detach().numpy(), weights=wts.numpy(),
-                        loss_pos=float(lp), loss_neg=float(ln), grad_CF=CF.grad.numpy())
+                        loss_pos=float(lp), loss_neg=float(ln), grad_CF=CF.grad.numpy(), **extra)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

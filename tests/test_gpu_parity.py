@@ -482,6 +482,76 @@ def test_fused_contrastive_soft_losses_match_reference_golden_and_torch():
     assert float(l0.detach()) == 0.0 and float(CFd.grad.abs().max()) == 0.0
 
 
+def _ref_mode_losses(C, C_F, pth, nth, w, mode):
+    """utils/loss_utils.py:275-302 ('all') and :351-394 ('hard') restated, PyTorch."""
+    n = C_F.shape[0]
+    diag = torch.eye(n, dtype=torch.bool, device=C_F.device)
+    out = []
+    for neg in (False, True):
+        cv = 0 if neg else 1
+        if mode == "all":
+            m = torch.triu(torch.logical_and(torch.any(C == cv, dim=0), ~diag), diagonal=0)
+            npair = torch.nonzero(m).shape[0]
+            m = torch.logical_and(m, C == cv)
+            v = w[m] * torch.relu(C_F[m]) if neg else -w[m] * C_F[m]
+            out.append(v.sum() / npair)
+        else:
+            m = torch.triu(((C_F > nth) if neg else (C_F < pth)) & (C == cv) & (~diag), diagonal=0)
+            idx = torch.nonzero(m, as_tuple=False)
+            if idx.shape[0] == 0:
+                out.append(torch.zeros((), device=C_F.device))
+                continue
+            i, j = idx[:, 0], idx[:, 1]
+            out.append((w[i, j] * torch.relu(C_F[i, j])).mean() if neg else (-w[i, j] * C_F[i, j]).mean())
+    return out
+
+
+@pytest.mark.parametrize("mode", ["all", "hard"])
+def test_fused_contrastive_all_and_hard_modes_match_reference_golden_and_torch(mode):
+    """The other two opt.contrastive_mode values (utils/loss_utils.py:396-406 tables): golden vectors from the imported
+    reference with weights (tests/golden/contrastive.npz, keys *_all / *_hard), then the PyTorch restatement at a
+    ragged size without weights, determinism, and the empty 'hard' selection.  Same tolerances as the 'soft' test."""
+    import os
+    from trase_amd.losses import positive_pixel_pair_loss, negative_pixel_pair_loss
+    pos, neg = positive_pixel_pair_loss[mode], negative_pixel_pair_loss[mode]
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive.npz"))
+    C = torch.from_numpy(d["C"]).cuda()
+    CF = torch.from_numpy(d["CF"]).cuda().requires_grad_(True)
+    w = torch.from_numpy(d["weights"]).cuda()
+    lp = pos(C=C, C_F=CF, positive_th=0.75, weights=w)
+    ln = neg(C=C, C_F=CF, negative_th=0.5, weights=w)
+    wp, wn = float(d[f"loss_pos_{mode}"]), float(d[f"loss_neg_{mode}"])
+    assert wp != 0.0 and wn != 0.0
+    assert abs(float(lp.detach()) - wp) < 1e-5 * abs(wp)
+    assert abs(float(ln.detach()) - wn) < 1e-5 * abs(wn)
+    (lp + ln).backward()
+    want = torch.from_numpy(d[f"grad_CF_{mode}"]).cuda()
+    assert float((CF.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert int(((CF.grad != 0) != (want != 0)).sum()) == 0
+    torch.manual_seed(5)
+    S, nm = 1337, 23
+    memb = (torch.rand(nm, S, device="cuda") < 0.15).float()
+    C2 = (memb.t() @ memb != 0).float()
+    f = torch.nn.functional.normalize(torch.randn(S, 32, device="cuda") + 1.2 * memb.t() @ torch.randn(nm, 32, device="cuda"), dim=-1)
+    CFa = (f @ f.t()).requires_grad_(True)
+    rp, rn = _ref_mode_losses(C2, CFa, 0.75, 0.5, torch.ones(S, S, device="cuda"), mode)
+    (rp + 2.0 * rn).backward()
+    CFb = CFa.detach().clone().requires_grad_(True)
+    gp, gn = pos(C2, CFb, 0.75), neg(C2, CFb, 0.5)
+    assert abs(float(gp.detach() - rp.detach())) < 1e-5 * abs(float(rp.detach())) + 1e-7
+    assert abs(float(gn.detach() - rn.detach())) < 1e-5 * abs(float(rn.detach())) + 1e-7
+    (gp + 2.0 * gn).backward()
+    assert float((CFb.grad - CFa.grad).abs().max()) < 1e-5 * float(CFa.grad.abs().max())
+    CFc = CFa.detach().clone().requires_grad_(True)
+    (pos(C2, CFc, 0.75) + 2.0 * neg(C2, CFc, 0.5)).backward()
+    assert torch.equal(CFc.grad, CFb.grad)
+    if mode == "hard":      # nothing below the threshold: tensor(0.) and a zero gradient
+        CFd = torch.ones(64, 64, device="cuda", requires_grad=True)
+        l0 = pos(torch.ones(64, 64, device="cuda"), CFd, 0.75)
+        l0.backward()
+        assert float(l0.detach()) == 0.0 and float(CFd.grad.abs().max()) == 0.0
+
+
 def test_fused_adam_matches_torch_adam():
     """trase_adam_step (one launch over all tensors) against torch.optim.Adam with the reference's configuration:
     per-group learning rates, eps = 1e-15, lr changed between steps (update_learning_rate, train.py:388-389), a

@@ -91,10 +91,13 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     return _fused(img1, img2)[1]
 
 
-# ---- contrastive pixel-pair losses, 'soft' mode (utils/loss_utils.py:304-349) ------------------------------------------
-class _ContrastiveSoft(torch.autograd.Function):
+# ---- contrastive pixel-pair losses (utils/loss_utils.py:275-406) --------------------------------------------------------
+PAIR_POSITIVE, PAIR_NEGATIVE, PAIR_SOFT, PAIR_ALL, PAIR_HARD = 0, 1, 0, 2, 4      # include/trase_rast.h TRASE_PAIR_*
+
+
+class _PixelPair(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, C_F, Cm, weights, th, negative):
+    def forward(ctx, C_F, Cm, weights, th, kind):
         lib = _lib.load()
         dev = C_F.device
         S = C_F.shape[0]
@@ -106,11 +109,11 @@ class _ContrastiveSoft(torch.autograd.Function):
         ws = _bytes(nbytes.value, dev)
         out2 = torch.empty(2, device=dev)
         d = dev.index if dev.index is not None else torch.cuda.current_device()
-        _lib.check(lib.trase_contrastive_forward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, float(th), int(negative),
+        _lib.check(lib.trase_contrastive_forward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, float(th), int(kind),
                                                  _lib.ptr(out2), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
                    "trase_contrastive_forward")
         ctx.save_for_backward(cf, cm, ws, out2, *(() if wt is None else (wt,)))
-        ctx.negative = int(negative)
+        ctx.kind, ctx.th = int(kind), float(th)
         return out2[0]
 
     @staticmethod
@@ -123,28 +126,68 @@ class _ContrastiveSoft(torch.autograd.Function):
         d_cf = torch.empty_like(cf)
         gg = g.reshape(1).float().contiguous()
         d = dev.index if dev.index is not None else torch.cuda.current_device()
-        _lib.check(lib.trase_contrastive_backward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, ctx.negative, _lib.ptr(out2),
-                                                  _lib.ptr(gg), _lib.ptr(ws), ws.numel(), _lib.ptr(d_cf), d, _stream(dev)),
+        _lib.check(lib.trase_contrastive_backward(_lib.ptr(cm), _lib.ptr(cf), _lib.ptr(wt), S, ctx.th, ctx.kind,
+                                                  _lib.ptr(out2), _lib.ptr(gg), _lib.ptr(ws), ws.numel(), _lib.ptr(d_cf), d,
+                                                  _stream(dev)),
                    "trase_contrastive_backward")
         return d_cf, None, None, None, None
 
 
-def _contrastive(C_mat, C_F, th, weights, negative):
+def _pixel_pair(C_mat, C_F, th, weights, kind):
     if C_F.device.type != "cuda":
         raise RuntimeError("trase_amd.losses runs on the GPU only (there is no CPU path)")
     if C_F.dim() != 2 or C_F.shape[0] != C_F.shape[1] or C_mat.shape != C_F.shape or (weights is not None and weights.shape != C_F.shape):
         raise ValueError("expected square C, C_F (and weights) of equal shape")
-    return _ContrastiveSoft.apply(C_F, C_mat, weights, th, negative)
+    return _PixelPair.apply(C_F, C_mat, weights, th, kind)
 
 
 def pixel_mask_correspondence_loss_soft_hard_positive(C, C_F, positive_th=0.75, weights=None, verbose=False, log_tb=False,
                                                       tb_writer=None, iteration=None):
     """utils/loss_utils.py:304-327 (``positive_pixel_pair_loss['soft']``).  Differences: no host synchronisation, so
     the "[WARNING] no positive sample found" print is gone and an empty selection yields a zero TENSOR."""
-    return _contrastive(C, C_F, positive_th, weights, 0)
+    return _pixel_pair(C, C_F, positive_th, weights, PAIR_POSITIVE | PAIR_SOFT)
 
 
 def pixel_mask_correspondence_loss_soft_negative(C, C_F, negative_th=0.5, weights=None, verbose=False, log_tb=False,
                                                  tb_writer=None, iteration=None):
     """utils/loss_utils.py:329-349 (``negative_pixel_pair_loss['soft']``)."""
-    return _contrastive(C, C_F, negative_th, weights, 1)
+    return _pixel_pair(C, C_F, negative_th, weights, PAIR_NEGATIVE | PAIR_SOFT)
+
+
+def pixel_mask_correspondence_loss_positive(C, C_F, positive_th=0.75, weights=None, verbose=False, log_tb=False,
+                                            tb_writer=None, iteration=None):
+    """utils/loss_utils.py:275-288 (``positive_pixel_pair_loss['all']``; the threshold is unused there as here).  With
+    no positive pair at all the reference divides 0 by 0 (nan); this returns 0."""
+    return _pixel_pair(C, C_F, positive_th, weights, PAIR_POSITIVE | PAIR_ALL)
+
+
+def pixel_mask_correspondence_loss_negative(C, C_F, negative_th=0.5, weights=None, verbose=False, log_tb=False,
+                                            tb_writer=None, iteration=None):
+    """utils/loss_utils.py:290-302 (``negative_pixel_pair_loss['all']``)."""
+    return _pixel_pair(C, C_F, negative_th, weights, PAIR_NEGATIVE | PAIR_ALL)
+
+
+def pixel_mask_correspondence_loss_hard_positive(C, C_F, positive_th=0.75, weights=None, verbose=False, log_tb=False,
+                                                 tb_writer=None, iteration=None):
+    """utils/loss_utils.py:351-372 (``positive_pixel_pair_loss['hard']``): mean of -w * C_F over the strictly upper
+    triangle pairs with C == 1 and C_F < th, without the nonzero() index list (and its host synchronisation)."""
+    return _pixel_pair(C, C_F, positive_th, weights, PAIR_POSITIVE | PAIR_HARD)
+
+
+def pixel_mask_correspondence_loss_hard_negative(C, C_F, negative_th=0.5, weights=None, verbose=False, log_tb=False,
+                                                 tb_writer=None, iteration=None):
+    """utils/loss_utils.py:374-394 (``negative_pixel_pair_loss['hard']``)."""
+    return _pixel_pair(C, C_F, negative_th, weights, PAIR_NEGATIVE | PAIR_HARD)
+
+
+# the reference's mode tables, utils/loss_utils.py:396-406 (train.py:290-291 indexes them with opt.contrastive_mode)
+positive_pixel_pair_loss = {
+    "hard": pixel_mask_correspondence_loss_hard_positive,
+    "all": pixel_mask_correspondence_loss_positive,
+    "soft": pixel_mask_correspondence_loss_soft_hard_positive,
+}
+negative_pixel_pair_loss = {
+    "hard": pixel_mask_correspondence_loss_hard_negative,
+    "all": pixel_mask_correspondence_loss_negative,
+    "soft": pixel_mask_correspondence_loss_soft_negative,
+}
