@@ -326,6 +326,38 @@ int trase_selftest(int32_t device, trase_stream_t stream, char* msg, size_t msg_
 const char* trase_last_error(void);
 const char* trase_version(void);
 
+/* ---- densification bookkeeping + densify / prune compaction (second half) -------------------
+ * trase_densify_stats: the per-iteration statistics of train.py:362-365 and scene/gaussian_model.py:637-639 in one
+ * launch, with visibility_filter = radii > 0 (gaussian_renderer/__init__.py:137):
+ *   max_radii2D = max(max_radii2D, radii);  xyz_gradient_accum += |viewspace_grad[:, :2]|;  denom += 1   on visible rows.
+ * viewspace_grad is the [P][3] gradient of the screen-space points (means2D.grad).
+ *
+ * trase_densify_plan + trase_densify_apply replace GaussianModel.densify_and_prune (scene/gaussian_model.py:617-635:
+ * densify_and_clone :594-615, densify_and_split :563-592, prune_points :491-509, optimizer surgery :472-489, :511-534).
+ * plan: decides clone / split / prune per row from the accumulated statistics and the RAW scaling [P][3] and opacity
+ *   [P] parameters, and builds the row map of the final model in `ws` (trase_densify_sizes bytes).
+ *   dense_extent = percent_dense * scene_extent; big_extent = 0.1 * scene_extent, applied only when use_screen_size != 0
+ *   (the reference's max_screen_size argument; its max_radii2D test is dead code there, see densify.hip).
+ *   counts (5 device ints) = {kept originals, kept clones, kept split children per sample, split-selected rows M,
+ *   clone-selected rows}; the new row count is counts[0] + counts[1] + 2 * counts[2].  The caller reads them (the one
+ *   synchronisation: it has to allocate the new tensors), draws 2M x 3 standard normals and calls
+ * apply: gathers `count` (<= 32 per call) row-major tensors of 4-byte elements through the map, dst[r] = src[map[r]],
+ *   writing zeros into rows that are not kept originals where zero_new[i] != 0 (the Adam moments), then -- when
+ *   normal_samples != NULL -- rewrites the children rows of new_xyz / new_scaling:
+ *   xyz' = R(rotation) (z * exp(scaling)) + xyz,  scaling' = log(exp(scaling) / 1.6).  With more than 32 tensors pass
+ *   normal_samples on the last call only (after xyz and scaling were gathered); it may be NULL only when M == 0. */
+int trase_densify_stats(const float* viewspace_grad, const int32_t* radii, float* xyz_gradient_accum, float* denom,
+                        float* max_radii2D, int32_t P, int32_t device, trase_stream_t stream);
+int trase_densify_sizes(int32_t P, size_t* ws_bytes);
+int trase_densify_plan(const float* xyz_gradient_accum, const float* denom, const float* scaling, const float* opacity,
+                       int32_t P, float grad_threshold, float dense_extent, float min_opacity, int32_t use_screen_size,
+                       float big_extent, int32_t* counts, void* ws, size_t ws_bytes, int32_t device,
+                       trase_stream_t stream);
+int trase_densify_apply(int32_t count, const void* const* src, void* const* dst, const int32_t* row_elems,
+                        const int32_t* zero_new, int32_t P, int32_t new_P, const float* xyz, const float* scaling,
+                        const float* rotation, const float* normal_samples, float* new_xyz, float* new_scaling,
+                        const void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,8 @@ Fixtures:
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
   G6 contrastive.npz    utils/loss_utils.py:275-406 pixel-pair losses, modes soft / all / hard
+  G7 densify.npz        scene/gaussian_model.py:617-635 GaussianModel.densify_and_prune (clone, split, prune, both Adam
+                        optimizers' state) on a CPU instance of the reference class, with and without max_screen_size
 """
 import math
 import os
@@ -168,6 +170,84 @@ def main():
         extra.update({f"loss_pos_{mode}": float(mp), f"loss_neg_{mode}": float(mn), f"grad_CF_{mode}": CFm.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, "contrastive.npz"), C=C.numpy(), CF=CF.detach().numpy(), weights=wts.numpy(),
                         loss_pos=float(lp), loss_neg=float(ln), grad_CF=CF.grad.numpy(), **extra)
+    # ---- G7: densify_and_prune of the reference's own GaussianModel (scene/gaussian_model.py:617-635), run on the CPU.
+    # The split samples are torch.normal(mean=0, std=stds) = standard normals * stds (checked below): the standard
+    # normals are recorded as an input, so the fixture pins everything except the generator itself.
+    from types import SimpleNamespace
+    from scene.gaussian_model import GaussianModel
+    targs = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                            position_lr_delay_mult=0.01, position_lr_max_steps=30_000, feature_lr=0.0025, opacity_lr=0.05,
+                            scaling_lr=0.005, rotation_lr=0.001)                        # arguments/__init__.py:100-113
+    extent = 3.7
+    g7 = {"extent": extent, "percent_dense": targs.percent_dense, "max_grad": 0.0002, "min_opacity": 0.005}
+    for tag, size_threshold in (("a", 20), ("b", None)):                                # train.py:369
+        torch.manual_seed(70 + (tag == "b"))
+        n7 = 1201
+        with no_cuda_kwarg():
+            gm = GaussianModel(3)
+            gm.spatial_lr_scale = 1.0
+            gm._xyz = torch.nn.Parameter(torch.randn(n7, 3) * 1.5)
+            gm._features_dc = torch.nn.Parameter(torch.randn(n7, 1, 3))
+            gm._features_rest = torch.nn.Parameter(torch.randn(n7, 15, 3) * 0.1)
+            # activated scales around percent_dense * extent = 0.037, a tail above 0.1 * extent = 0.37
+            gm._scaling = torch.nn.Parameter(torch.log(torch.tensor(0.037)) + torch.randn(n7, 3) * 1.2)
+            gm._rotation = torch.nn.Parameter(torch.randn(n7, 4))
+            gm._opacity = torch.nn.Parameter(torch.randn(n7, 1) * 3.0 - 2.0)           # some below sigmoid^-1(0.005) = -5.3
+            gm._gaussian_features = torch.nn.Parameter(torch.randn(n7, 1, 32))
+            gm.max_radii2D = torch.rand(n7) * 40.0
+            gm.training_setup(targs)
+            for _ in range(2):                                                          # non-trivial Adam moments
+                for mode in ("GAUSSIAN", "FEATURE"):
+                    for grp in gm.optimizer[mode].param_groups:
+                        grp["params"][0].grad = torch.randn_like(grp["params"][0]) * 0.01
+                    gm.optimizer[mode].step()
+            gm.denom = torch.randint(0, 4, (n7, 1)).float()                             # zeros -> nan -> 0 path
+            gm.xyz_gradient_accum = torch.rand(n7, 1) * 0.0006 * gm.denom
+            inp = {}
+            for mode in ("GAUSSIAN", "FEATURE"):
+                for grp in gm.optimizer[mode].param_groups:
+                    prm = grp["params"][0]
+                    st = gm.optimizer[mode].state[prm]
+                    inp[f"in_{grp['name']}"] = prm.detach().clone().numpy()
+                    inp[f"in_{grp['name']}_m"] = st["exp_avg"].clone().numpy()
+                    inp[f"in_{grp['name']}_v"] = st["exp_avg_sq"].clone().numpy()
+            inp["in_accum"], inp["in_denom"] = gm.xyz_gradient_accum.clone().numpy(), gm.denom.clone().numpy()
+            inp["in_max_radii2D"] = gm.max_radii2D.clone().numpy()
+            rec = {}
+            real_normal = torch.normal
+
+            def spy_normal(*a, **k):
+                state = torch.get_rng_state()
+                out_ = real_normal(*a, **k)
+                after = torch.get_rng_state()
+                torch.set_rng_state(state)
+                zz = torch.randn(out_.shape)
+                torch.set_rng_state(after)
+                assert torch.equal(zz * k["std"] + k["mean"], out_), "torch.normal(mean, std) != randn * std + mean"
+                rec["z"] = zz
+                return out_
+            torch.normal = spy_normal
+            real_empty_cache = torch.cuda.empty_cache
+            torch.cuda.empty_cache = lambda: None
+            try:
+                torch.manual_seed(700)
+                num_clone, num_split = gm.densify_and_prune(g7["max_grad"], g7["min_opacity"], extent, size_threshold)
+            finally:
+                torch.normal = real_normal
+                torch.cuda.empty_cache = real_empty_cache
+            out7 = {"z": rec["z"].numpy(), "num_clone": int(num_clone), "num_split": int(num_split)}
+            for mode in ("GAUSSIAN", "FEATURE"):
+                for grp in gm.optimizer[mode].param_groups:
+                    prm = grp["params"][0]
+                    st = gm.optimizer[mode].state[prm]
+                    out7[f"out_{grp['name']}"] = prm.detach().numpy()
+                    out7[f"out_{grp['name']}_m"] = st["exp_avg"].numpy()
+                    out7[f"out_{grp['name']}_v"] = st["exp_avg_sq"].numpy()
+            assert gm._xyz is gm.optimizer["GAUSSIAN"].param_groups[0]["params"][0]
+            assert float(gm.xyz_gradient_accum.abs().sum() + gm.denom.abs().sum() + gm.max_radii2D.abs().sum()) == 0.0
+            print("G7", tag, "rows", n7, "->", gm._xyz.shape[0], "clone", int(num_clone), "split", int(num_split))
+        g7.update({f"{tag}_{k}": v for k, v in {**inp, **out7}.items()})
+    np.savez_compressed(os.path.join(HERE, "densify.npz"), **g7)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -743,3 +743,149 @@ def test_fused_render_matches_unfused_composition(with_deform):
         rel_l2 = ((a - b).double().norm() / (b.double().norm() + 1e-30)).item()
         # a flipped borderline gate (see above) perturbs a few entries; the bulk must agree tightly
         assert err < 1e-2 * scale and rel_l2 < 2e-3, f"{name}: max {err:.3e} (scale {scale:.3e}), rel L2 {rel_l2:.3e}"
+
+
+# ---- densification bookkeeping + densify / prune compaction (second half) ----------------------
+_DN_NAMES = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "gaussian_feats"]
+_DN_ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+            "rotation": "_rotation", "gaussian_feats": "_gaussian_features"}
+
+
+def _densify_model(params, moments, accum, denom, max_radii, percent_dense, opt_cls):
+    """A GaussianModel-shaped object (scene/gaussian_model.py:56-75, :253-289): parameters, two Adam optimizers with one
+    parameter per named group and injected state, densification statistics."""
+    from types import SimpleNamespace
+    m = SimpleNamespace(percent_dense=percent_dense, feature_smooth_map="stale", mode="from_scratch")
+    for n in _DN_NAMES:
+        setattr(m, _DN_ATTR[n], torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(params[n])).cuda()))
+    grp = lambda names: [{"params": [getattr(m, _DN_ATTR[n])], "lr": 1e-3, "name": n} for n in names]
+    m.optimizer = {"GAUSSIAN": opt_cls(grp(_DN_NAMES[:6]), lr=0.0, eps=1e-15), "FEATURE": opt_cls(grp(_DN_NAMES[6:]), lr=0.0, eps=1e-15)}
+    for mode in m.optimizer:
+        for g in m.optimizer[mode].param_groups:
+            if g["name"] in moments:
+                ea, es = moments[g["name"]]
+                m.optimizer[mode].state[g["params"][0]] = {"step": torch.tensor(2.0), "exp_avg": torch.from_numpy(np.ascontiguousarray(ea)).cuda(),
+                                                           "exp_avg_sq": torch.from_numpy(np.ascontiguousarray(es)).cuda()}
+    m.xyz_gradient_accum = torch.from_numpy(np.ascontiguousarray(accum)).cuda()
+    m.denom = torch.from_numpy(np.ascontiguousarray(denom)).cuda()
+    m.max_radii2D = torch.from_numpy(np.ascontiguousarray(max_radii)).cuda()
+    return m
+
+
+def _densify_check(m, want_p, want_m, rtol=2e-6):
+    for mode in m.optimizer:
+        for g in m.optimizer[mode].param_groups:
+            n, p = g["name"], g["params"][0]
+            assert p is getattr(m, _DN_ATTR[n]) and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_leaf
+            got = p.detach().cpu().numpy()
+            assert got.shape == want_p[n].shape, (n, got.shape, want_p[n].shape)
+            if n in ("xyz", "scaling"):
+                np.testing.assert_allclose(got, want_p[n], rtol=rtol, atol=rtol)
+            else:
+                assert np.array_equal(got, want_p[n]), n
+            if n in want_m:
+                st = m.optimizer[mode].state[p]
+                assert float(st["step"]) == 2.0
+                assert np.array_equal(st["exp_avg"].cpu().numpy(), want_m[n][0]), n
+                assert np.array_equal(st["exp_avg_sq"].cpu().numpy(), want_m[n][1]), n
+            else:
+                assert p not in m.optimizer[mode].state
+            assert len(m.optimizer[mode].state) == sum(1 for gg in m.optimizer[mode].param_groups if gg["name"] in want_m)
+    P = want_p["xyz"].shape[0]
+    assert m.xyz_gradient_accum.shape == (P, 1) and m.denom.shape == (P, 1) and m.max_radii2D.shape == (P,)
+    assert float(m.xyz_gradient_accum.abs().sum() + m.denom.abs().sum() + m.max_radii2D.abs().sum()) == 0.0
+    assert m.feature_smooth_map is None
+
+
+@pytest.mark.parametrize("tag,size_threshold", [("a", 20), ("b", None)])
+def test_densify_and_prune_matches_reference_golden(tag, size_threshold):
+    """trase_densify_plan / _apply against the reference's own GaussianModel.densify_and_prune
+    (tests/golden/densify.npz: scene/gaussian_model.py:617-635 run on the CPU with recorded split samples): row count,
+    row order, every parameter and both Adam moments bit-exact, except the children rows of xyz / scaling, which carry
+    float arithmetic (rotation product, exp / log): 2e-6."""
+    import os
+    from trase_amd.densify import densify_and_prune
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "densify.npz"))
+    params = {n: d[f"{tag}_in_{n}"] for n in _DN_NAMES}
+    moments = {n: (d[f"{tag}_in_{n}_m"], d[f"{tag}_in_{n}_v"]) for n in _DN_NAMES}
+    m = _densify_model(params, moments, d[f"{tag}_in_accum"], d[f"{tag}_in_denom"], d[f"{tag}_in_max_radii2D"],
+                       float(d["percent_dense"]), torch.optim.Adam)
+    nc, ns = densify_and_prune(m, float(d["max_grad"]), float(d["min_opacity"]), float(d["extent"]), size_threshold,
+                               normal_samples=torch.from_numpy(d[f"{tag}_z"]).cuda())
+    assert nc == int(d[f"{tag}_num_clone"]) and ns == int(d[f"{tag}_num_split"])
+    _densify_check(m, {n: d[f"{tag}_out_{n}"] for n in _DN_NAMES},
+                   {n: (d[f"{tag}_out_{n}_m"], d[f"{tag}_out_{n}_v"]) for n in _DN_NAMES})
+
+
+def test_densify_and_prune_large_ragged_and_edge_cases_match_oracle():
+    """P = 200 003 (not a multiple of the 256-row workgroups, ~780 workgroups through the scan) with FusedAdam and a
+    FEATURE optimizer that has no state yet, against the pinned numpy oracle; the generator path (seeded torch.randn)
+    equals passing the same samples explicitly; then: nothing selected and nothing pruned (identity), and everything
+    pruned (zero rows)."""
+    from oracle import densify_oracle as O
+    from trase_amd.densify import densify_and_prune
+    from trase_amd.optim import FusedAdam
+    rng = np.random.default_rng(11)
+    P, extent, pd = 200_003, 5.2, 0.01
+    f32 = np.float32
+    params = {"xyz": rng.normal(size=(P, 3)).astype(f32), "f_dc": rng.normal(size=(P, 1, 3)).astype(f32),
+              "f_rest": rng.normal(size=(P, 15, 3)).astype(f32), "opacity": (rng.normal(size=(P, 1)) * 3 - 2).astype(f32),
+              "scaling": (np.log(pd * extent) + rng.normal(size=(P, 3)) * 1.2).astype(f32),
+              "rotation": rng.normal(size=(P, 4)).astype(f32), "gaussian_feats": rng.normal(size=(P, 1, 32)).astype(f32)}
+    moments = {n: (rng.normal(size=params[n].shape).astype(f32), rng.random(size=params[n].shape).astype(f32)) for n in _DN_NAMES[:6]}
+    denom = rng.integers(0, 4, size=(P, 1)).astype(f32)
+    accum = (rng.random(size=(P, 1)) * 0.0006).astype(f32) * denom
+    mr = (rng.random(size=P) * 40).astype(f32)
+    m = _densify_model(params, moments, accum, denom, mr, pd, FusedAdam)
+    torch.manual_seed(123)
+    nc, ns = densify_and_prune(m, 0.0002, 0.005, extent, 20)
+    torch.manual_seed(123)
+    z = torch.randn((2 * ns, 3), device="cuda")
+    wp, wm, onc, ons = O.densify_and_prune(params, moments, accum, denom, pd, extent, 0.0002, 0.005, 20, z.cpu().numpy())
+    assert (nc, ns) == (onc, ons) and nc > 1000 and ns > 1000
+    _densify_check(m, wp, wm, rtol=3e-6)
+    m2 = _densify_model(params, moments, accum, denom, mr, pd, FusedAdam)
+    assert densify_and_prune(m2, 0.0002, 0.005, extent, 20, normal_samples=z) == (nc, ns)
+    for n in _DN_NAMES:
+        assert torch.equal(getattr(m2, _DN_ATTR[n]).data, getattr(m, _DN_ATTR[n]).data)
+    # identity: no gradient statistics, opaque, small
+    small = {k: v[:777].copy() for k, v in params.items()}
+    small["opacity"][:] = 2.0
+    small["scaling"][:] = np.log(0.01)
+    sm = {n: (moments[n][0][:777], moments[n][1][:777]) for n in moments}
+    m3 = _densify_model(small, sm, np.zeros((777, 1), f32), np.zeros((777, 1), f32), mr[:777], pd, FusedAdam)
+    assert densify_and_prune(m3, 0.0002, 0.005, extent, 20) == (0, 0)
+    _densify_check(m3, small, sm)
+    # everything pruned
+    small["opacity"][:] = -20.0
+    m4 = _densify_model(small, sm, np.zeros((777, 1), f32), np.zeros((777, 1), f32), mr[:777], pd, FusedAdam)
+    densify_and_prune(m4, 0.0002, 0.005, extent, None)
+    assert m4._xyz.shape == (0, 3) and m4._features_rest.shape == (0, 15, 3) and m4.denom.shape == (0, 1)
+
+
+def test_densification_stats_match_oracle_and_torch():
+    """trase_densify_stats against the numpy oracle and the reference's torch statements (train.py:362-365,
+    scene/gaussian_model.py:637-639): max_radii2D exact, the gradient norm to 1 ulp."""
+    from types import SimpleNamespace
+    from oracle import densify_oracle as O
+    from trase_amd.densify import add_densification_stats
+    torch.manual_seed(3)
+    P = 100_001
+    vp = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    vp.grad = torch.randn(P, 3, device="cuda") * 1e-3
+    radii = torch.randint(-1, 60, (P,), device="cuda", dtype=torch.int32) * (torch.rand(P, device="cuda") < 0.6).int()
+    acc0, den0, mr0 = torch.rand(P, 1, device="cuda") * 1e-3, torch.randint(0, 9, (P, 1), device="cuda").float(), torch.rand(P, device="cuda") * 50
+    m = SimpleNamespace(xyz_gradient_accum=acc0.clone(), denom=den0.clone(), max_radii2D=mr0.clone())
+    add_densification_stats(m, vp, radii)
+    vis = radii > 0
+    mr_t, acc_t, den_t = mr0.clone(), acc0.clone(), den0.clone()
+    mr_t[vis] = torch.max(mr_t[vis], radii[vis].float())
+    acc_t[vis] += torch.norm(vp.grad[vis, :2], dim=-1, keepdim=True)
+    den_t[vis] += 1
+    assert torch.equal(m.max_radii2D, mr_t) and torch.equal(m.denom, den_t)
+    assert float((m.xyz_gradient_accum - acc_t).abs().max()) <= 2.4e-7 * float(acc_t.abs().max())
+    a, dn, r = acc0.cpu().numpy(), den0.cpu().numpy(), mr0.cpu().numpy()
+    O.add_densification_stats(a, dn, r, vp.grad.cpu().numpy(), radii.cpu().numpy())
+    assert np.array_equal(r, m.max_radii2D.cpu().numpy()) and np.array_equal(dn, m.denom.cpu().numpy())
+    np.testing.assert_allclose(m.xyz_gradient_accum.cpu().numpy(), a, rtol=3e-7, atol=1e-10)
+    assert int(vis.sum()) > 1000 and int((~vis).sum()) > 1000
