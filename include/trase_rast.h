@@ -358,6 +358,37 @@ int trase_densify_apply(int32_t count, const void* const* src, void* const* dst,
                         const float* rotation, const float* normal_samples, float* new_xyz, float* new_scaling,
                         const void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
 
+/* ---- FEATURE-state loss head without S x S matrices (train.py:251-296) ------------------------
+ * trase_mask_stats: one pass over the N bool masks [N][HW] (1 byte each): cover_count[p] = number of masks covering pixel
+ *   p (the sampler's non_mask_region is cover_count == 0, utils/feature_utils.py:23) and mask_size[n] = sam_masks[n].sum()
+ *   (utils/feature_utils.py:30).
+ * trase_pairhead_forward: for the S sampled pixels pix[] (flat indices into HW, ascending = boolean-index order) evaluates
+ *   what train.py:272-296 computes through get_pixel_mask_correspondence_matrix (utils/feature_utils.py:40-49),
+ *   get_features_correspondence_matrix (:51-57), get_pixel_weights (:28-38), positive_/negative_pixel_pair_loss[mode]
+ *   (utils/loss_utils.py:275-406; mode 0 soft, 1 all, 2 hard) and the two mean similarities (train.py:295-296), from
+ *   per-pixel factors only: feats is the [F = 32][HW] feature image at mask resolution, sampled_mask the N 0/1 bytes of the
+ *   sampled masks (n_sampled_masks = an upper bound of their number, at most 256).
+ *   out8 = {loss_pos, N_pos, loss_neg, N_neg, pos_similarity, neg_similarity, S, sampled masks} (device floats).
+ *   use_weights = 0 evaluates the losses with weights = None.
+ * trase_pairhead_backward: dL/dfeats [F][HW] (zero-filled here, then the S sampled columns) for the upstream gradients
+ *   g2 = {dL/dloss_pos, dL/dloss_neg} (device floats), from the forward's workspace.
+ * trase_featnorm_*: the regulariser (1 - mean_p |feats[:, p]|_2)^2 of train.py:281-282; out2 = {value, mean norm}. */
+int trase_mask_stats(const uint8_t* sam_masks, int32_t N, int64_t HW, int32_t* cover_count, uint32_t* mask_size, int32_t device,
+                     trase_stream_t stream);
+int trase_pairhead_sizes(int32_t S, size_t* ws_bytes);
+int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint8_t* sam_masks, int32_t N,
+                           const uint8_t* sampled_mask, int32_t n_sampled_masks, const uint32_t* mask_size, const int32_t* pix,
+                           int32_t S, int32_t mode, float positive_th, float negative_th, int32_t use_weights, float* out8,
+                           void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S, int32_t mode, float positive_th,
+                            float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
+                            size_t ws_bytes, float* dL_dfeats, int32_t device, trase_stream_t stream);
+int trase_featnorm_sizes(int64_t HW, size_t* ws_bytes);
+int trase_featnorm_forward(const float* feats, int32_t F, int64_t HW, float* out2, void* ws, size_t ws_bytes, int32_t device,
+                           trase_stream_t stream);
+int trase_featnorm_backward(const float* feats, int32_t F, int64_t HW, const float* out2, const float* g, float* dL_dfeats,
+                            int32_t device, trase_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,8 @@ Fixtures:
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
   G6 contrastive.npz    utils/loss_utils.py:275-406 pixel-pair losses, modes soft / all / hard
+  G8 feature_head.npz   train.py:251-296 FEATURE-state head: utils/feature_utils.py:17-57 (sampler, C, C_F, weights) +
+                        utils/loss_utils.py:275-406 pair losses (3 modes) + similarities + feature-norm regulariser
   G7 densify.npz        scene/gaussian_model.py:617-635 GaussianModel.densify_and_prune (clone, split, prune, both Adam
                         optimizers' state) on a CPU instance of the reference class, with and without max_screen_size
 """
@@ -248,6 +250,54 @@ def main():
             print("G7", tag, "rows", n7, "->", gm._xyz.shape[0], "clone", int(num_clone), "split", int(num_split))
         g7.update({f"{tag}_{k}": v for k, v in {**inp, **out7}.items()})
     np.savez_compressed(os.path.join(HERE, "densify.npz"), **g7)
+    # ---- G8: the FEATURE-state head as train.py:251-296 composes it from the reference's helpers
+    from utils.feature_utils import (get_sample_pixel_and_mask, get_pixel_weights, get_pixel_mask_correspondence_matrix,
+                                     get_features_correspondence_matrix)
+    torch.manual_seed(8)
+    n8, h8, w8 = 14, 40, 56
+    yy, xx = torch.meshgrid(torch.arange(h8), torch.arange(w8), indexing="ij")
+    sam = torch.zeros(n8, h8, w8, dtype=torch.bool)
+    for k in range(n8):                                     # overlapping boxes and discs, some pixels uncovered
+        cy, cx = int(torch.randint(0, h8, (1,))), int(torch.randint(0, w8, (1,)))
+        ry, rx = int(torch.randint(3, 14, (1,))), int(torch.randint(3, 18, (1,)))
+        if k % 2:
+            sam[k] = ((yy - cy).abs() <= ry) & ((xx - cx).abs() <= rx)
+        else:
+            sam[k] = ((yy - cy).float() / ry) ** 2 + ((xx - cx).float() / rx) ** 2 <= 1.0
+    base = torch.randn(n8, 32)
+    feat = (sam.float().permute(1, 2, 0) @ base).permute(2, 0, 1) * 0.7 + 0.6 * torch.randn(32, h8, w8)
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self         # the sampler moves its CPU draws to the GPU; stay on the CPU
+    try:
+        torch.manual_seed(80)
+        sampled_pixel, sampled_mask = get_sample_pixel_and_mask(sam, 300, 7)
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    g8 = {"sam_masks": sam.numpy(), "features": feat.numpy(), "sampled_pixel": sampled_pixel.numpy(),
+          "sampled_mask": sampled_mask.numpy(), "sampler_seed": 80, "num_sampled_pixels": 300, "num_sampled_masks": 7,
+          "positive_th": 0.75, "negative_th": 0.5}
+    Cm = get_pixel_mask_correspondence_matrix(sam, sampled_pixel, sampled_mask)
+    Wm = get_pixel_weights(sam, sampled_pixel)
+    g8["C"], g8["weights"] = Cm.numpy(), Wm.numpy()
+    for mode, use_w in (("soft", True), ("all", True), ("hard", True), ("soft", False)):
+        fr = feat.clone().requires_grad_(True)
+        CFm = get_features_correspondence_matrix(fr, sampled_pixel)
+        lp = positive_pixel_pair_loss[mode](C=Cm, C_F=CFm, positive_th=0.75, weights=Wm if use_w else None)
+        ln = negative_pixel_pair_loss[mode](C=Cm, C_F=CFm, negative_th=0.5, weights=Wm if use_w else None)
+        (lp + ln).backward()
+        tag = mode + ("" if use_w else "_noweights")
+        g8[f"{tag}_loss_pos"], g8[f"{tag}_loss_neg"], g8[f"{tag}_grad"] = float(lp), float(ln), fr.grad.numpy()
+    with torch.no_grad():
+        g8["C_F"] = CFm.detach().numpy()
+        g8["pos_similarity"] = float(CFm[Cm == 1].mean())   # train.py:295-296
+        g8["neg_similarity"] = float(CFm[Cm == 0].mean())
+    fr = feat.clone().requires_grad_(True)
+    reg = (1 - fr.norm(dim=0, p=2).mean()) ** 2             # train.py:281-282
+    reg.backward()
+    g8["reg"], g8["reg_grad"] = float(reg), fr.grad.numpy()
+    print("G8 S =", int(sampled_pixel.sum()), "sampled masks =", int(sampled_mask.sum()),
+          {k: round(v, 5) for k, v in g8.items() if isinstance(v, float)})
+    np.savez_compressed(os.path.join(HERE, "feature_head.npz"), **g8)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -889,3 +889,104 @@ def test_densification_stats_match_oracle_and_torch():
     assert np.array_equal(r, m.max_radii2D.cpu().numpy()) and np.array_equal(dn, m.denom.cpu().numpy())
     np.testing.assert_allclose(m.xyz_gradient_accum.cpu().numpy(), a, rtol=3e-7, atol=1e-10)
     assert int(vis.sum()) > 1000 and int((~vis).sum()) > 1000
+
+
+# ---- FEATURE-state loss head without S x S matrices (train.py:251-296) -------------------------
+def test_mask_stats_and_sampler_match_reference_golden():
+    """trase_mask_stats against torch sums at a ragged size, and the sampler (utils/feature_utils.py:17-26) replayed with
+    the reference's CPU seed: identical sampled_pixel / sampled_mask as the golden run of the reference."""
+    import os
+    from trase_amd.feature_head import mask_stats, get_sample_pixel_and_mask
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_head.npz"))
+    sam = torch.from_numpy(d["sam_masks"]).cuda()
+    cover, size = mask_stats(sam)
+    assert torch.equal(cover.long(), sam.sum(dim=0)) and torch.equal(size.long(), sam.sum(-1).sum(-1))
+    torch.manual_seed(int(d["sampler_seed"]))
+    sp, sm = get_sample_pixel_and_mask(sam, int(d["num_sampled_pixels"]), int(d["num_sampled_masks"]))
+    assert np.array_equal(sp.cpu().numpy(), d["sampled_pixel"]) and np.array_equal(sm.cpu().numpy(), d["sampled_mask"])
+    g = torch.Generator(device="cuda").manual_seed(5)
+    big = torch.rand(37, 271, 483, device="cuda", generator=g) < 0.07          # H*W odd: the scalar tail path
+    cover, size = mask_stats(big)
+    assert torch.equal(cover.long(), big.sum(dim=0)) and torch.equal(size.long(), big.sum(-1).sum(-1))
+
+
+@pytest.mark.parametrize("mode,use_w", [("soft", True), ("all", True), ("hard", True), ("soft", False)])
+def test_contrastive_head_matches_reference_golden(mode, use_w):
+    """trase_pairhead_forward / _backward against the reference's own composition (tests/golden/feature_head.npz:
+    utils/feature_utils.py helpers + utils/loss_utils.py pair losses + train.py:295-296 similarities): losses and
+    similarities to 2e-6, the (32, H, W) feature gradient to 1e-5 of its scale with the same support."""
+    import os
+    from trase_amd.feature_head import contrastive_head
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_head.npz"))
+    sam = torch.from_numpy(d["sam_masks"]).cuda()
+    sp, sm = torch.from_numpy(d["sampled_pixel"]).cuda(), torch.from_numpy(d["sampled_mask"]).cuda()
+    f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
+    lp, ln, ps, ns = contrastive_head(f, sam, sp, sm, mode, float(d["positive_th"]), float(d["negative_th"]), use_w)
+    tag = mode + ("" if use_w else "_noweights")
+    assert abs(float(lp.detach()) - float(d[f"{tag}_loss_pos"])) < 2e-6, (float(lp.detach()), float(d[f"{tag}_loss_pos"]))
+    assert abs(float(ln.detach()) - float(d[f"{tag}_loss_neg"])) < 2e-6, (float(ln.detach()), float(d[f"{tag}_loss_neg"]))
+    assert abs(float(ps) - float(d["pos_similarity"])) < 2e-6 and abs(float(ns) - float(d["neg_similarity"])) < 2e-6
+    (lp + ln).backward()
+    want = torch.from_numpy(d[f"{tag}_grad"]).cuda()
+    assert float((f.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert torch.equal(f.grad[:, ~sp], torch.zeros_like(f.grad[:, ~sp]))
+
+
+@pytest.mark.parametrize("mode", ["soft", "hard"])
+def test_contrastive_head_large_matches_float64_oracle(mode):
+    """S ~ 3000 sampled pixels of a 270 x 480 mask stack with 90 masks (~ 45 sampled: two membership words), against the
+    pinned oracle evaluated in float64 on the GPU: losses 1e-5 relative, similarities 1e-6, gradient 1e-4 of its scale;
+    deterministic; and the head composed with the regulariser in one backward."""
+    from oracle import feature_head_oracle as O
+    from trase_amd.feature_head import contrastive_head, feature_norm_reg, mask_stats
+    g = torch.Generator(device="cuda").manual_seed(9)
+    N, H, W = 90, 270, 480
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    cy, cx = torch.randint(0, H, (N,), device="cuda", generator=g), torch.randint(0, W, (N,), device="cuda", generator=g)
+    ry, rx = torch.randint(8, 90, (N,), device="cuda", generator=g), torch.randint(8, 120, (N,), device="cuda", generator=g)
+    sam = ((yy[None] - cy[:, None, None]).abs() <= ry[:, None, None]) & ((xx[None] - cx[:, None, None]).abs() <= rx[:, None, None])
+    base = torch.randn(N, 32, device="cuda", generator=g)
+    feat = (sam.float().permute(1, 2, 0) @ base).permute(2, 0, 1) * 0.5 + 0.8 * torch.randn(32, H, W, device="cuda", generator=g)
+    cover, size = mask_stats(sam)
+    sp = (torch.rand(H, W, device="cuda", generator=g) < 3000 / (H * W)) & (cover != 0)
+    sm = torch.rand(N, device="cuda", generator=g) < 0.5
+    assert 2000 < int(sp.sum()) < 4000 and 32 < int(sm.sum()) < 64
+    fa = feat.clone().requires_grad_(True)
+    rp, rn, rps, rns = O.head(fa, sam, sp, sm, mode, 0.75, 0.5, True, dtype=torch.float64)
+    (rp + 0.5 * rn).backward()
+    fb = feat.clone().requires_grad_(True)
+    lp, ln, ps, ns = contrastive_head(fb, sam, sp, sm, mode, 0.75, 0.5, mask_size=size)
+    assert abs(float(lp.detach()) - float(rp.detach())) < 1e-5 * abs(float(rp.detach()))
+    assert abs(float(ln.detach()) - float(rn.detach())) < 1e-5 * abs(float(rn.detach()))
+    assert abs(float(ps) - float(rps)) < 1e-6 and abs(float(ns) - float(rns)) < 1e-6
+    (lp + 0.5 * ln).backward()
+    assert float((fb.grad - fa.grad).abs().max()) < 1e-4 * float(fa.grad.abs().max())
+    fc = feat.clone().requires_grad_(True)
+    lp2, ln2, _, _ = contrastive_head(fc, sam, sp, sm, mode, 0.75, 0.5)
+    (lp2 + 0.5 * ln2 + 0.3 * feature_norm_reg(fc)).backward()
+    fd = feat.clone().requires_grad_(True)
+    (0.3 * O.feature_norm_reg(fd)).backward()
+    assert torch.equal(lp2.detach(), lp.detach()) and torch.equal(ln2.detach(), ln.detach())
+    assert float((fc.grad - (fb.grad + fd.grad)).abs().max()) < 1e-6 * float(fc.grad.abs().max()) + 1e-12
+
+
+def test_feature_norm_reg_matches_reference_golden_and_torch():
+    import os
+    from trase_amd.feature_head import feature_norm_reg
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_head.npz"))
+    f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
+    r = feature_norm_reg(f)
+    (2.0 * r).backward()
+    assert abs(float(r.detach()) - float(d["reg"])) < 1e-5 * float(d["reg"])
+    want = 2.0 * torch.from_numpy(d["reg_grad"]).cuda()
+    assert float((f.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+    x = torch.randn(32, 333, 517, device="cuda")
+    x[:, 5, 7] = 0.0                                                            # zero norm: zero subgradient
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ra = (1 - a.norm(dim=0, p=2).mean()) ** 2
+    ra.backward()
+    rb = feature_norm_reg(b)
+    rb.backward()
+    assert abs(float(ra.detach()) - float(rb.detach())) < 1e-5 * float(ra.detach())
+    assert float((a.grad - b.grad).abs().max()) < 1e-5 * float(a.grad.abs().max())
+    assert float(b.grad[:, 5, 7].abs().max()) == 0.0
