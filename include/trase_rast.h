@@ -371,7 +371,8 @@ int trase_densify_apply(int32_t count, const void* const* src, void* const* dst,
  *   out8 = {loss_pos, N_pos, loss_neg, N_neg, pos_similarity, neg_similarity, S, sampled masks} (device floats).
  *   use_weights = 0 evaluates the losses with weights = None.
  * trase_pairhead_backward: dL/dfeats [F][HW] (zero-filled here, then the S sampled columns) for the upstream gradients
- *   g2 = {dL/dloss_pos, dL/dloss_neg} (device floats), from the forward's workspace.
+ *   g2 = {dL/dloss_pos, dL/dloss_neg} (device floats), from the forward's workspace.  accumulate != 0 adds the S columns
+ *   into an image that already holds a gradient (the regulariser's, trase_featnorm_backward) instead of zero-filling.
  * trase_featnorm_*: the regulariser (1 - mean_p |feats[:, p]|_2)^2 of train.py:281-282; out2 = {value, mean norm}. */
 int trase_mask_stats(const uint8_t* sam_masks, int32_t N, int64_t HW, int32_t* cover_count, uint32_t* mask_size, int32_t device,
                      trase_stream_t stream);
@@ -382,7 +383,7 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
                            void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
 int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S, int32_t mode, float positive_th,
                             float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
-                            size_t ws_bytes, float* dL_dfeats, int32_t device, trase_stream_t stream);
+                            size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream);
 int trase_featnorm_sizes(int64_t HW, size_t* ws_bytes);
 int trase_featnorm_forward(const float* feats, int32_t F, int64_t HW, float* out2, void* ws, size_t ws_bytes, int32_t device,
                            trase_stream_t stream);

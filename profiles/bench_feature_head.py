@@ -88,8 +88,8 @@ def main():
         feat.grad = None
         cover, size = mask_stats(sam)
         sp_, sm_ = get_sample_pixel_and_mask(sam, 5000, 50, cover_count=cover, rng=rng)
-        lp, ln, ps, ns = contrastive_head(feat, sam, sp_, sm_, "soft", 0.75, 0.5, mask_size=size)
-        (lp + ln + feature_norm_reg(feat)).backward()
+        lp, ln, ps, ns, reg = contrastive_head(feat, sam, sp_, sm_, "soft", 0.75, 0.5, mask_size=size, with_norm_reg=True)
+        (lp + ln + reg).backward()
 
     out["torch_head_ms"] = timed(ref_iter)
     out["hip_head_cpu_rng_ms"] = timed(lambda: hip_iter("cpu"))

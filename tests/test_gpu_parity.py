@@ -968,6 +968,12 @@ def test_contrastive_head_large_matches_float64_oracle(mode):
     (0.3 * O.feature_norm_reg(fd)).backward()
     assert torch.equal(lp2.detach(), lp.detach()) and torch.equal(ln2.detach(), ln.detach())
     assert float((fc.grad - (fb.grad + fd.grad)).abs().max()) < 1e-6 * float(fc.grad.abs().max()) + 1e-12
+    # the combined form (regulariser of the same image inside the head: one dense gradient pass) gives the same numbers
+    fe = feat.clone().requires_grad_(True)
+    lp3, ln3, ps3, ns3, reg3 = contrastive_head(fe, sam, sp, sm, mode, 0.75, 0.5, mask_size=size, with_norm_reg=True)
+    (lp3 + 0.5 * ln3 + 0.3 * reg3).backward()
+    assert torch.equal(lp3.detach(), lp.detach()) and torch.equal(ps3, ps) and torch.equal(reg3.detach(), feature_norm_reg(feat).detach())
+    assert float((fe.grad - fc.grad).abs().max()) < 1e-6 * float(fc.grad.abs().max()) + 1e-12
 
 
 def test_feature_norm_reg_matches_reference_golden_and_torch():

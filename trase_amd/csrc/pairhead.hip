@@ -28,6 +28,7 @@ constexpr int PH_F = 32;        // rendered feature channels (scene/gaussian_mod
 constexpr int PH_ROWS = 64;     // rows per workgroup in the pair passes
 constexpr int PH_CHUNKS = 32;   // u-chunks of the backward
 constexpr int PH_MAXW = 8;      // 32-bit membership words: up to 256 sampled masks
+constexpr int PH_MAXN = 8192;   // masks per view
 
 struct PairWs {
   float* fn;        // [S][32] normalised sampled features
@@ -38,6 +39,7 @@ struct PairWs {
   float* consts;    // [8]: ptp_max, w_max, number of sampled masks
   double* partial;  // [nblk][8]
   float* dpart;     // [PH_CHUNKS][S][32]
+  int* rank;        // [PH_MAXN] bit position of a sampled mask (-1: not sampled)
   int nblk;
 };
 
@@ -48,12 +50,12 @@ static size_t pair_ws_carve(int S, PairWs* w, void* base) {
   const size_t o_fn = take(sizeof(float) * PH_F * (size_t)S), o_r = take(sizeof(float) * (size_t)S), o_a = take(sizeof(float) * (size_t)S),
                o_b = take(sizeof(uint32_t) * PH_MAXW * (size_t)S), o_cp = take(sizeof(int) * (size_t)S), o_cn = take(sizeof(int) * (size_t)S),
                o_c = take(sizeof(float) * 8), o_p = take(sizeof(double) * 8 * (size_t)bx * by),
-               o_d = take(sizeof(float) * PH_F * (size_t)S * PH_CHUNKS);
+               o_d = take(sizeof(float) * PH_F * (size_t)S * PH_CHUNKS), o_k = take(sizeof(int) * PH_MAXN);
   if (w && base) {
     char* b = (char*)base;
     w->fn = (float*)(b + o_fn); w->rinv = (float*)(b + o_r); w->a = (float*)(b + o_a); w->bits = (uint32_t*)(b + o_b);
     w->colP = (int*)(b + o_cp); w->colN = (int*)(b + o_cn); w->consts = (float*)(b + o_c); w->partial = (double*)(b + o_p);
-    w->dpart = (float*)(b + o_d); w->nblk = bx * by;
+    w->dpart = (float*)(b + o_d); w->rank = (int*)(b + o_k); w->nblk = bx * by;
   }
   return off;
 }
@@ -93,46 +95,84 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restri
 }
 
 // ---- per sampled pixel ---------------------------------------------------------------------------------------------------
+// bit position of every sampled mask = its rank among the sampled ones (the row order of sam_masks[sampled_mask])
+__global__ __launch_bounds__(256) void ph_rank_kernel(const uint8_t* __restrict__ sampled_mask, int N, int* __restrict__ rank,
+                                                      float* __restrict__ consts) {
+  __shared__ int carry;
+  __shared__ int wsum[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 256) {
+    const int n = base + threadIdx.x;
+    const int v = (n < N && sampled_mask[n]) ? 1 : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if ((int)(threadIdx.x & 63) >= o) x += y; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int add = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) add += wsum[w];
+    if (n < N) rank[n] = v ? add + x - 1 : -1;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = add + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) consts[2] = (float)carry;
+}
+
+// eight lanes per sampled pixel: lane l walks the masks n = l, l + 8, ... (scattered one-byte reads), the partial
+// membership words / size sums are combined with shuffles; four channels of the feature column per lane
 __global__ __launch_bounds__(256) void ph_gather_kernel(const float* __restrict__ feats, long long HW,
-                                                        const uint8_t* __restrict__ masks, int N,
-                                                        const uint8_t* __restrict__ sampled_mask,
+                                                        const uint8_t* __restrict__ masks, int N, const int* __restrict__ rank,
                                                         const uint32_t* __restrict__ mask_size, const int32_t* __restrict__ pix,
                                                         int S, float* __restrict__ fn, float* __restrict__ rinv,
-                                                        float* __restrict__ a, uint32_t* __restrict__ bits,
-                                                        float* __restrict__ consts) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= S) return;
-  const long long p = pix[s];
-  float x[PH_F];
+                                                        float* __restrict__ a, uint32_t* __restrict__ bits) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int s = gid >> 3, l = gid & 7;
+  const long long p = pix[min(s, S - 1)];
+  float x[4];
   float ss = 0.f;
 #pragma unroll
-  for (int c = 0; c < PH_F; ++c) { x[c] = feats[(size_t)c * HW + p]; ss = fmaf(x[c], x[c], ss); }
-  const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                       // F.normalize(p=2, eps=1e-12)
-#pragma unroll
-  for (int c = 0; c < PH_F; ++c) fn[(size_t)s * PH_F + c] = x[c] * r;
-  rinv[s] = r;
+  for (int e = 0; e < 4; ++e) { x[e] = feats[(size_t)(4 * l + e) * HW + p]; ss = fmaf(x[e], x[e], ss); }
   uint32_t b[PH_MAXW];
 #pragma unroll
   for (int k = 0; k < PH_MAXW; ++k) b[k] = 0u;
   unsigned long long tot = 0ull;
   uint32_t cnt = 0u;
-  int k = 0;
-  for (int n = 0; n < N; ++n) {
-    const bool in = masks[(size_t)n * HW + p] != 0;
-    if (in) { tot += mask_size[n]; ++cnt; }
-    if (sampled_mask[n]) {                                                 // wave-uniform
-      if (in) {
+  for (int n0 = l; n0 < N; n0 += 32) {
+    uint8_t in4[4];
 #pragma unroll
-        for (int q = 0; q < PH_MAXW; ++q) if (q == (k >> 5)) b[q] |= 1u << (k & 31);
+    for (int e = 0; e < 4; ++e) in4[e] = (n0 + 8 * e < N) ? masks[(size_t)(n0 + 8 * e) * HW + p] : (uint8_t)0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + 8 * e;
+      if (n < N && in4[e]) {
+        tot += mask_size[n]; ++cnt;
+        const int k = rank[n];
+        if (k >= 0) {
+#pragma unroll
+          for (int q = 0; q < PH_MAXW; ++q) if (q == (k >> 5)) b[q] |= 1u << (k & 31);
+        }
       }
-      ++k;
     }
   }
 #pragma unroll
-  for (int q = 0; q < PH_MAXW; ++q) bits[(size_t)s * PH_MAXW + q] = b[q];
-  // per_pixel_mean_mask_size = sum(size of covering masks) / (cover count + 1e-9)   (utils/feature_utils.py:30-31)
-  a[s] = (float)(long long)tot / ((float)cnt + 1e-9f);
-  if (s == 0) consts[2] = (float)k;
+  for (int o = 4; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o);
+    tot += __shfl_xor(tot, o);
+    cnt += __shfl_xor((int)cnt, o);
+#pragma unroll
+    for (int q = 0; q < PH_MAXW; ++q) b[q] |= (uint32_t)__shfl_xor((int)b[q], o);
+  }
+  if (s >= S) return;
+  const float r = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                       // F.normalize(p=2, eps=1e-12)
+  *reinterpret_cast<float4*>(fn + (size_t)s * PH_F + 4 * l) = make_float4(x[0] * r, x[1] * r, x[2] * r, x[3] * r);
+  bits[(size_t)s * PH_MAXW + l] = b[l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 2 : l == 3 ? 3 : l == 4 ? 4 : l == 5 ? 5 : l == 6 ? 6 : 7];
+  if (l == 0) {
+    rinv[s] = r;
+    // per_pixel_mean_mask_size = sum(size of covering masks) / (cover count + 1e-9)   (utils/feature_utils.py:30-31)
+    a[s] = (float)(long long)tot / ((float)cnt + 1e-9f);
+  }
 }
 
 // ptp_max = (max a)^2; w_max = max(1, ptp_max / (min non-zero a)^2); the matrix minimum of the clamped ratio is exactly 1
@@ -163,18 +203,25 @@ __device__ __forceinline__ float pair_weight(float ai, float aj, float P, float 
   return (w - 1.0f) / (wmax - 1.0f) * 9.0f + 1.0f;        // (w - w.min()) / (w.max() - w.min()) * 9. + 1.
 }
 
-__device__ __forceinline__ bool share_mask(const uint32_t* bj, const uint32_t* __restrict__ bi) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const f32x2 cfloat2;      // constant address space: wave-uniform rows come through
+typedef __attribute__((address_space(4))) const uint32_t cuint;     // the scalar cache (s_load) and feed the VALU as SGPR pairs
+
+__device__ __forceinline__ bool share_mask(const uint32_t* bj, const uint32_t* bi_) {
+  cuint* bi = (cuint*)bi_;
   uint32_t x = 0u;
 #pragma unroll
   for (int q = 0; q < PH_MAXW; ++q) x |= bj[q] & bi[q];
   return x != 0u;
 }
 
-__device__ __forceinline__ float dot32(const float* fj, const float* __restrict__ fi) {
-  float d = 0.f;
+// <f_i, f_j> with channel pairs on v_pk_fma_f32 (two partial sums, added at the end)
+__device__ __forceinline__ float dot32(const f32x2* fj, const float* fi_) {
+  cfloat2* fi = (cfloat2*)fi_;
+  f32x2 d = {0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < PH_F; ++c) d = fmaf(fi[c], fj[c], d);
-  return d;
+  for (int c = 0; c < PH_F / 2; ++c) d = __builtin_elementwise_fma(fi[c], fj[c], d);
+  return d.x + d.y;
 }
 
 // kind: bit 1-2 = mode (0 soft, 1 all, 2 hard)
@@ -184,10 +231,10 @@ __global__ __launch_bounds__(256) void ph_flags_kernel(const float* __restrict__
   __shared__ double red[4][4];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * PH_ROWS, i1 = min(i0 + PH_ROWS, S);
-  float fj[PH_F]; uint32_t bj[PH_MAXW];
+  f32x2 fj[PH_F / 2]; uint32_t bj[PH_MAXW];
   const int jj = min(j, S - 1);
 #pragma unroll
-  for (int c = 0; c < PH_F; ++c) fj[c] = fn[(size_t)jj * PH_F + c];
+  for (int c = 0; c < PH_F / 2; ++c) fj[c] = *reinterpret_cast<const f32x2*>(fn + (size_t)jj * PH_F + 2 * c);
 #pragma unroll
   for (int q = 0; q < PH_MAXW; ++q) bj[q] = bits[(size_t)jj * PH_MAXW + q];
   bool anyP = false, anyN = false;
@@ -221,10 +268,14 @@ __global__ __launch_bounds__(256) void ph_sum_kernel(const float* __restrict__ f
   __shared__ double red[4][4];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * PH_ROWS, i1 = min(i0 + PH_ROWS, S);
+  if (i0 >= min(S, (int)(blockIdx.x * 256 + 256))) {        // the whole tile is on or below the diagonal: nothing to add
+    if (threadIdx.x < 4) partial[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + threadIdx.x] = 0.0;
+    return;
+  }
   const int jj = min(j, S - 1);
-  float fj[PH_F]; uint32_t bj[PH_MAXW];
+  f32x2 fj[PH_F / 2]; uint32_t bj[PH_MAXW];
 #pragma unroll
-  for (int c = 0; c < PH_F; ++c) fj[c] = fn[(size_t)jj * PH_F + c];
+  for (int c = 0; c < PH_F / 2; ++c) fj[c] = *reinterpret_cast<const f32x2*>(fn + (size_t)jj * PH_F + 2 * c);
 #pragma unroll
   for (int q = 0; q < PH_MAXW; ++q) bj[q] = bits[(size_t)jj * PH_MAXW + q];
   const float aj = a[jj], P = consts[0], wmax = consts[1];
@@ -296,9 +347,9 @@ __global__ __launch_bounds__(256) void ph_bwd_kernel(const float* __restrict__ f
   const int per = (S + PH_CHUNKS - 1) / PH_CHUNKS;
   const int u0 = blockIdx.y * per, u1 = min(u0 + per, S);
   const int tt = min(t, S - 1);
-  float ft[PH_F], acc[PH_F]; uint32_t bt[PH_MAXW];
+  f32x2 ft[PH_F / 2], acc[PH_F / 2]; uint32_t bt[PH_MAXW];
 #pragma unroll
-  for (int c = 0; c < PH_F; ++c) { ft[c] = fn[(size_t)tt * PH_F + c]; acc[c] = 0.f; }
+  for (int c = 0; c < PH_F / 2; ++c) { ft[c] = *reinterpret_cast<const f32x2*>(fn + (size_t)tt * PH_F + 2 * c); acc[c] = f32x2{0.f, 0.f}; }
 #pragma unroll
   for (int q = 0; q < PH_MAXW; ++q) bt[q] = bits[(size_t)tt * PH_MAXW + q];
   const float at = a[tt], P = consts[0], wmax = consts[1];
@@ -318,40 +369,38 @@ __global__ __launch_bounds__(256) void ph_bwd_kernel(const float* __restrict__ f
     else if (cn && f > 0.f && (!hard || f > nth)) d = kn;
     if (d != 0.f) {
       d *= pair_weight(a[u], at, P, wmax, use_w);
+      const f32x2 d2 = {d, d};
+      cfloat2* fu2 = (cfloat2*)fu;
 #pragma unroll
-      for (int c2 = 0; c2 < PH_F; ++c2) acc[c2] = fmaf(d, fu[c2], acc[c2]);
+      for (int c2 = 0; c2 < PH_F / 2; ++c2) acc[c2] = __builtin_elementwise_fma(d2, fu2[c2], acc[c2]);
     }
   }
   if (t < S) {
     float* o = dpart + ((size_t)blockIdx.y * S + t) * PH_F;
 #pragma unroll
-    for (int c = 0; c < PH_F; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    for (int c = 0; c < PH_F / 2; c += 2) *reinterpret_cast<float4*>(o + 2 * c) = make_float4(acc[c].x, acc[c].y, acc[c + 1].x, acc[c + 1].y);
   }
 }
 
-// reduce the chunks in order, back through x -> x / max(|x|, eps), scatter into the (zero-filled) gradient image
+// reduce the chunks in order, back through x -> x / max(|x|, eps), scatter into the gradient image.
+// One thread per (sampled pixel, channel): a 32-lane half wave owns a pixel and reduces <fn, d> with shuffles.
 __global__ __launch_bounds__(256) void ph_scatter_kernel(const float* __restrict__ dpart, const float* __restrict__ fn,
                                                          const float* __restrict__ rinv, const int32_t* __restrict__ pix, int S,
-                                                         long long HW, float* __restrict__ dfeats) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+                                                         long long HW, int accumulate, float* __restrict__ dfeats) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int s = gid >> 5, c = gid & 31;
+  const int ss = min(s, S - 1);
+  float d = 0.f;
+  for (int k = 0; k < PH_CHUNKS; ++k) d += dpart[((size_t)k * S + ss) * PH_F + c];
+  const float r = rinv[ss], f = fn[(size_t)ss * PH_F + c];
+  float proj = f * d;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) proj += __shfl_xor(proj, o);
+  if (!(r < 1e12f)) proj = 0.f;                             // |x| <= eps: the clamp is active, d x = r d
   if (s >= S) return;
-  float d[PH_F];
-#pragma unroll
-  for (int c = 0; c < PH_F; ++c) d[c] = 0.f;
-  for (int k = 0; k < PH_CHUNKS; ++k) {
-    const float* o = dpart + ((size_t)k * S + s) * PH_F;
-#pragma unroll
-    for (int c = 0; c < PH_F; ++c) d[c] += o[c];
-  }
-  const float r = rinv[s];
-  float proj = 0.f;
-  if (r < 1e12f) {                                          // |x| > eps: d x = r (d - fn <fn, d>); else the clamp is active
-#pragma unroll
-    for (int c = 0; c < PH_F; ++c) proj = fmaf(fn[(size_t)s * PH_F + c], d[c], proj);
-  }
-  const long long p = pix[s];
-#pragma unroll
-  for (int c = 0; c < PH_F; ++c) dfeats[(size_t)c * HW + p] = r * (d[c] - fn[(size_t)s * PH_F + c] * proj);
+  const float v = r * (d - f * proj);
+  float* o = dfeats + (size_t)c * HW + pix[ss];            // sampled pixels are distinct: no atomics
+  *o = accumulate ? *o + v : v;
 }
 
 // ---- feature-norm regulariser ----------------------------------------------------------------------------------------------
@@ -361,7 +410,15 @@ __global__ __launch_bounds__(256) void featnorm_fwd_kernel(const float* __restri
   double acc = 0.0;
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
     float ss = 0.f;
-    for (int c = 0; c < F; ++c) { const float x = feats[(size_t)c * HW + p]; ss = fmaf(x, x, ss); }
+    int c = 0;
+    for (; c + 8 <= F; c += 8) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = feats[(size_t)(c + e) * HW + p];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+    }
+    for (; c < F; ++c) { const float x = feats[(size_t)c * HW + p]; ss = fmaf(x, x, ss); }
     acc += (double)sqrtf(ss);
   }
 #pragma unroll
@@ -392,10 +449,24 @@ __global__ __launch_bounds__(256) void featnorm_bwd_kernel(const float* __restri
                                                            float* __restrict__ dfeats) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
+  const float coef = g[0] * (-2.0f * (1.0f - out2[1])) / (float)HW;
+  if (F == PH_F) {                                          // the rendered 32-d features: one read, held in registers
+    float x[PH_F];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < PH_F; ++c) x[c] = feats[(size_t)c * HW + p];
+#pragma unroll
+    for (int c = 0; c < PH_F; ++c) ss = fmaf(x[c], x[c], ss);
+    const float n = sqrtf(ss);
+    const float k = (n > 0.f) ? coef / n : 0.f;
+#pragma unroll
+    for (int c = 0; c < PH_F; ++c) dfeats[(size_t)c * HW + p] = k * x[c];
+    return;
+  }
   float ss = 0.f;
   for (int c = 0; c < F; ++c) { const float x = feats[(size_t)c * HW + p]; ss = fmaf(x, x, ss); }
   const float n = sqrtf(ss);
-  const float k = (n > 0.f) ? (g[0] * (-2.0f * (1.0f - out2[1])) / (float)HW) / n : 0.f;
+  const float k = (n > 0.f) ? coef / n : 0.f;
   for (int c = 0; c < F; ++c) dfeats[(size_t)c * HW + p] = k * feats[(size_t)c * HW + p];
 }
 
@@ -430,7 +501,7 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
                            const uint8_t* sampled_mask, int32_t n_sampled_masks, const uint32_t* mask_size, const int32_t* pix,
                            int32_t S, int32_t mode, float positive_th, float negative_th, int32_t use_weights, float* out8,
                            void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
-  if (!feats || !sam_masks || !sampled_mask || !mask_size || !pix || !out8 || S < 1 || N < 1 || HW < 1 || mode < 0 || mode > 2) {
+  if (!feats || !sam_masks || !sampled_mask || !mask_size || !pix || !out8 || S < 1 || N < 1 || N > PH_MAXN || HW < 1 || mode < 0 || mode > 2) {
     set_error("trase_pairhead_forward: bad arguments"); return TRASE_ERR_INVALID;
   }
   if (F != PH_F) { set_error("trase_pairhead_forward: %d feature channels (compiled for %d)", F, PH_F); return TRASE_ERR_INVALID; }
@@ -446,8 +517,9 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
   const dim3 grid((S + 255) / 256, (S + PH_ROWS - 1) / PH_ROWS);
   {
     ProfScope ps("pairhead_fwd", stream);
-    hipLaunchKernelGGL(ph_gather_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, feats, (long long)HW, sam_masks, N, sampled_mask,
-                       mask_size, pix, S, w.fn, w.rinv, w.a, w.bits, w.consts);
+    hipLaunchKernelGGL(ph_rank_kernel, dim3(1), dim3(256), 0, stream, sampled_mask, N, w.rank, w.consts);
+    hipLaunchKernelGGL(ph_gather_kernel, dim3((S * 8 + 255) / 256), dim3(256), 0, stream, feats, (long long)HW, sam_masks, N, w.rank,
+                       mask_size, pix, S, w.fn, w.rinv, w.a, w.bits);
     hipLaunchKernelGGL(ph_consts_kernel, dim3(1), dim3(256), 0, stream, w.a, S, w.consts);
     hipLaunchKernelGGL(ph_flags_kernel, grid, dim3(256), 0, stream, w.fn, w.bits, S, positive_th, negative_th, mode, w.colP, w.colN,
                        w.partial);
@@ -461,7 +533,7 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
 
 int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S, int32_t mode, float positive_th,
                             float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
-                            size_t ws_bytes, float* dL_dfeats, int32_t device, trase_stream_t stream_) {
+                            size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream_) {
   if (!pix || !out8 || !g2 || !dL_dfeats || S < 1 || HW < 1 || mode < 0 || mode > 2 || F != PH_F) {
     set_error("trase_pairhead_backward: bad arguments"); return TRASE_ERR_INVALID;
   }
@@ -469,13 +541,13 @@ int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S
   if (!ws || ws_bytes < pair_ws_carve(S, &w, const_cast<void*>(ws))) { set_error("trase_pairhead_backward: workspace too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
-  TRASE_CHECK(hipMemsetAsync(dL_dfeats, 0, sizeof(float) * (size_t)F * (size_t)HW, stream));
+  if (!accumulate) TRASE_CHECK(hipMemsetAsync(dL_dfeats, 0, sizeof(float) * (size_t)F * (size_t)HW, stream));
   {
     ProfScope ps("pairhead_bwd", stream);
     hipLaunchKernelGGL(ph_bwd_kernel, dim3((S + 255) / 256, PH_CHUNKS), dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, positive_th,
                        negative_th, mode, use_weights, w.colP, w.colN, out8, g2, w.dpart);
-    hipLaunchKernelGGL(ph_scatter_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, w.dpart, w.fn, w.rinv, pix, S, (long long)HW,
-                       dL_dfeats);
+    hipLaunchKernelGGL(ph_scatter_kernel, dim3((S * PH_F + 255) / 256), dim3(256), 0, stream, w.dpart, w.fn, w.rinv, pix, S, (long long)HW,
+                       accumulate, dL_dfeats);
   }
   TRASE_POST_LAUNCH("pairhead_bwd", stream, 0);
   return TRASE_OK;

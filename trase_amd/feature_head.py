@@ -78,7 +78,7 @@ def get_sample_pixel_and_mask(sam_masks, num_sampled_pixels, num_sampled_masks, 
 
 class _PairHead(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, masks_u8, sampled_mask_u8, n_sampled, mask_size, pix, mode, pth, nth, use_w):
+    def forward(ctx, feats, masks_u8, sampled_mask_u8, n_sampled, mask_size, pix, mode, pth, nth, use_w, with_reg):
         lib = _lib.load()
         dev = feats.device
         F, H, W = feats.shape
@@ -93,33 +93,52 @@ class _PairHead(torch.autograd.Function):
                                               int(n_sampled), _lib.ptr(mask_size), _lib.ptr(pix), S, int(mode), float(pth), float(nth),
                                               int(use_w), _lib.ptr(out8), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
                    "trase_pairhead_forward")
-        ctx.save_for_backward(ws, out8, pix)
-        ctx.cfg = (F, H, W, S, int(mode), float(pth), float(nth), int(use_w))
         sims = out8[4:6].clone()
         ctx.mark_non_differentiable(sims)
-        return out8[0], out8[2], sims
+        ctx.cfg = (F, H, W, S, int(mode), float(pth), float(nth), int(use_w), bool(with_reg))
+        if not with_reg:
+            ctx.save_for_backward(ws, out8, pix)
+            return out8[0], out8[2], sims
+        # the regulariser of train.py:281-282 on the same image: its dense gradient is written first in the backward and
+        # the S sampled columns are added into it (no zero-fill, no separate accumulation pass)
+        _lib.check(lib.trase_featnorm_sizes(H * W, C.byref(nbytes)), "trase_featnorm_sizes")
+        ws_r = _bytes(nbytes.value, dev)
+        out2 = torch.empty(2, device=dev)
+        _lib.check(lib.trase_featnorm_forward(_lib.ptr(f), F, H * W, _lib.ptr(out2), _lib.ptr(ws_r), ws_r.numel(), d, _stream(dev)),
+                   "trase_featnorm_forward")
+        ctx.save_for_backward(ws, out8, pix, f, out2)
+        return out8[0], out8[2], sims, out2[0]
 
     @staticmethod
-    def backward(ctx, g_pos, g_neg, _g_sims):
+    def backward(ctx, g_pos, g_neg, _g_sims, g_reg=None):
         lib = _lib.load()
-        ws, out8, pix = ctx.saved_tensors
-        F, H, W, S, mode, pth, nth, use_w = ctx.cfg
+        F, H, W, S, mode, pth, nth, use_w, with_reg = ctx.cfg
+        ws, out8, pix = ctx.saved_tensors[:3]
         dev = ws.device
+        d, st = _dev_index(dev), _stream(dev)
         g2 = torch.stack([g_pos.reshape(()), g_neg.reshape(())]).float().contiguous()
         d_feats = torch.empty((F, H, W), device=dev)
+        if with_reg:
+            f, out2 = ctx.saved_tensors[3:]
+            gg = g_reg.reshape(1).float().contiguous()
+            _lib.check(lib.trase_featnorm_backward(_lib.ptr(f), F, H * W, _lib.ptr(out2), _lib.ptr(gg), _lib.ptr(d_feats), d, st),
+                       "trase_featnorm_backward")
         _lib.check(lib.trase_pairhead_backward(F, H * W, _lib.ptr(pix), S, mode, pth, nth, use_w, _lib.ptr(out8), _lib.ptr(g2),
-                                               _lib.ptr(ws), ws.numel(), _lib.ptr(d_feats), _dev_index(dev), _stream(dev)),
+                                               _lib.ptr(ws), ws.numel(), 1 if with_reg else 0, _lib.ptr(d_feats), d, st),
                    "trase_pairhead_backward")
-        return (d_feats,) + (None,) * 9
+        return (d_feats,) + (None,) * 10
 
 
 def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, mode="soft", positive_th=0.75, negative_th=0.5,
-                     use_weights=True, mask_size=None):
-    """(loss_pos, loss_neg, pos_similarity, neg_similarity) of train.py:272-296:
+                     use_weights=True, mask_size=None, with_norm_reg=False):
+    """(loss_pos, loss_neg, pos_similarity, neg_similarity[, norm_reg]) of train.py:272-296:
     ``positive_pixel_pair_loss[mode](C, C_F, positive_th, weights)``, ``negative_pixel_pair_loss[mode](...)``,
     ``C_F[C == 1].mean()``, ``C_F[C == 0].mean()`` for the matrices the reference derives from ``sam_masks``,
     ``sampled_pixel``, ``sampled_mask`` and the (32, H, W) features.  One synchronisation (the number of sampled pixels;
-    the reference synchronises at every boolean index)."""
+    the reference synchronises at every boolean index).  ``with_norm_reg=True`` also returns the regulariser
+    ``(1 - rendered_features.norm(dim=0).mean()) ** 2`` (train.py:281-282) of the same image -- valid when the rendered
+    features already have the mask resolution, so that train.py:284's ``interpolate`` is the identity -- and shares one
+    dense gradient pass with the pair losses."""
     if mode not in _MODES:
         raise ValueError(f"contrastive mode {mode!r} (expected one of {sorted(_MODES)})")
     m = _masks_u8(sam_masks)
@@ -141,10 +160,11 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
     if pix.numel() == 0:
         z = rendered_features.sum() * 0.0
         nan = torch.full((), float("nan"), device=dev)
-        return z, z, nan, nan
-    lp, ln, sims = _PairHead.apply(rendered_features, m, sm, n_sampled, mask_size.contiguous(), pix, _MODES[mode], positive_th,
-                                   negative_th, 1 if use_weights else 0)
-    return lp, ln, sims[0], sims[1]
+        return (z, z, nan, nan, feature_norm_reg(rendered_features)) if with_norm_reg else (z, z, nan, nan)
+    res = _PairHead.apply(rendered_features, m, sm, n_sampled, mask_size.contiguous(), pix, _MODES[mode], positive_th, negative_th,
+                          1 if use_weights else 0, bool(with_norm_reg))
+    lp, ln, sims = res[:3]
+    return (lp, ln, sims[0], sims[1], res[3]) if with_norm_reg else (lp, ln, sims[0], sims[1])
 
 
 class _FeatNorm(torch.autograd.Function):
