@@ -209,12 +209,14 @@ typedef struct TraseMlpWeights {
   int32_t D;             /* hidden layers (8) */
   int32_t W;             /* hidden width (256) */
   int32_t xyz_multires;  /* 10 -> 63 input channels */
-  int32_t t_multires;    /* 10 -> 21 input channels */
-  int32_t is_blender;    /* must be 0 */
+  int32_t t_multires;    /* 10 -> 21 input channels; 6 with is_blender */
+  int32_t is_blender;    /* 0: cat(PE(x), PE(t)), 84 inputs.  1 (D-NeRF, utils/time_utils.py:74-86): cat(PE(x),
+                          * timenet(PE(t))), 93 inputs -- the caller evaluates the tiny timenet and passes its 30 outputs
+                          * as `t` with t_stride 0 (train.py:190-202 feeds the same time to every row when is_blender) */
   int32_t is_6dof;       /* must be 0 */
   int32_t variant;       /* 0 = default kernel; bit 0 = first-generation kernel (A/B) */
   int32_t reserved;
-  const float* weight[8];/* linear.{i}.weight: (256, 84) / (256, 256) / (256, 340) for the skip layer i = 5 */
+  const float* weight[8];/* linear.{i}.weight: (256, 84|93) / (256, 256) / (256, 340|349) for the skip layer i = 5 */
   const float* bias[8];  /* linear.{i}.bias  : (256,) */
   const float* w_warp;     const float* b_warp;      /* gaussian_warp     (3,256), (3,) */
   const float* w_rotation; const float* b_rotation;  /* gaussian_rotation (4,256), (4,) */
@@ -223,7 +225,7 @@ typedef struct TraseMlpWeights {
 
 int trase_mlp_sizes(size_t* ws_bytes);
 /* x (N,3); t: one float per row at stride t_stride floats (0 = the same scalar for every row, as the
- * reference's expand() produces at train.py:196); outputs d_xyz (N,3), d_rotation (N,4), d_scaling (N,3). */
+ * reference's expand() produces at train.py:196; is_blender: the 30 timenet outputs, t_stride 0); outputs d_xyz (N,3), d_rotation (N,4), d_scaling (N,3). */
 int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
                       float* d_xyz, float* d_rotation, float* d_scaling, void* ws, size_t ws_bytes, int32_t device,
                       trase_stream_t stream);

@@ -9,6 +9,7 @@ Fixtures:
   G2 cov3d.npz          utils/general_utils.py:122-154 build_scaling_rotation + strip_symmetric (scene/gaussian_model.py:37-41)
   G3 camera.npz         utils/graphics_utils.py:45-77 getWorld2View2/getProjectionMatrix + scene/cameras.py:76-79
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
+     deform_mlp_blender.npz   the same for is_blender=True (t_multires 6 + timenet)
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
   G6 contrastive.npz    utils/loss_utils.py:275-406 pixel-pair losses, modes soft / all / hard
   G8 feature_head.npz   train.py:251-296 FEATURE-state head: utils/feature_utils.py:17-57 (sampler, C, C_F, weights) +
@@ -136,6 +137,20 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deform_mlp.npz"), x=x.numpy(), t=t.numpy(), d_xyz=d_xyz.detach().numpy(),
                         d_rotation=d_rot.detach().numpy(), d_scaling=d_scale.detach().numpy(), gx=gx.numpy(),
                         gr=gr.numpy(), gs=gs.numpy(), **{"w_" + k: v for k, v in sd.items()}, **grads)
+
+    # ---- G4b: the is_blender variant (D-NeRF: t_multires = 6 + timenet, utils/time_utils.py:74-86), same cotangents
+    rng_state = torch.get_rng_state()                      # G5 continues G4's random stream
+    torch.manual_seed(11)
+    netb = DeformNetwork(D=8, W=256, multires=10, is_blender=True, is_6dof=False)
+    tb = torch.full((m, 1), 0.37)
+    bx, br, bs = netb(x, tb)
+    ((bx * gx).sum() + (br * gr).sum() + (bs * gs).sum()).backward()
+    sdb = {k: v.detach().numpy() for k, v in netb.state_dict().items()}
+    gradsb = {"grad_" + k: p.grad.detach().numpy() for k, p in netb.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "deform_mlp_blender.npz"), x=x.numpy(), t=tb.numpy(), d_xyz=bx.detach().numpy(),
+                        d_rotation=br.detach().numpy(), d_scaling=bs.detach().numpy(), gx=gx.numpy(), gr=gr.numpy(),
+                        gs=gs.numpy(), **{"w_" + k: v for k, v in sdb.items()}, **gradsb)
+    torch.set_rng_state(rng_state)
 
     # ---- G5
     from utils.loss_utils import l1_loss, ssim

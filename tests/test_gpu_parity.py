@@ -640,7 +640,10 @@ def _bf16_evaluated_net(net, x, t):
 
     def rb(v):
         return v + (v.to(torch.bfloat16).float() - v).detach()
-    e = rb(torch.cat([net.embed(x, 10), net.embed(t, 10)], -1))
+    # is_blender: the time block of the (identical) rows is evaluated once, as the kernel path does -- a batched GEMM
+    # could round one of the 30 values to the neighbouring bf16
+    tb = net.time_block(t[0:1]).expand(x.shape[0], -1) if getattr(net, "is_blender", False) else net.time_block(t)
+    e = rb(torch.cat([net.embed(x, 10), tb], -1))
     h = e
     for i, l in enumerate(net.linear):
         h = rb(torch.relu(Fn.linear(h, rb(l.weight)) + l.bias))
@@ -682,6 +685,61 @@ def test_deform_mlp_training_step_matches_bf16_evaluated_autograd(n):
             err = float((p.grad - want[k]).abs().max())
             rel = float((p.grad - want[k]).norm() / want[k].norm())
             assert rel < 5e-2 and err < 1e-1 * scale + 1e-6, f"{use} grad {k}: rel L2 {rel:.3e}, max abs {err:.3e} vs scale {scale:.3e}"
+
+
+def test_deform_mlp_blender_variant_matches_reference_golden_and_bf16_autograd():
+    """is_blender DeformNetwork (D-NeRF scenes: t_multires = 6 and a timenet whose 30 outputs replace PE(t),
+    utils/time_utils.py:74-86, :107-109).  (a) Forward against golden vectors from the imported reference
+    (tests/golden/deform_mlp_blender.npz), 2e-2 of the output scale like the default variant; fp32 golden gradients of
+    the heads to the same loose bounds.  (b) Training step against PyTorch autograd of the bf16-evaluated network,
+    INCLUDING the four timenet parameters, whose gradient is assembled from the two bias gradients (every row shares
+    the time block): 5e-2 relative L2.  (c) Non-uniform times are refused."""
+    import os
+    from trase_amd.deform import deform_forward, DeformNetworkHIP
+    from trase_amd.synthetic import SynthDeformNetwork
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "deform_mlp_blender.npz"))
+    params = {k[2:]: torch.from_numpy(d[k]).cuda() for k in d.files if k.startswith("w_")}
+    assert params["linear.0.weight"].shape == (256, 93) and params["linear.5.weight"].shape == (256, 349)
+    x, t = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["t"]).cuda()
+    with torch.no_grad():
+        out = deform_forward(params, x, t, is_blender=True)
+        out0 = deform_forward(params, x, torch.tensor([[0.37]], device="cuda").expand(x.shape[0], -1), is_blender=True)
+    for name, got, got0 in zip(("d_xyz", "d_rotation", "d_scaling"), out, out0):
+        want = d[name]
+        assert np.abs(got.cpu().numpy() - want).max() < 2e-2 * np.abs(want).max() + 1e-4, name
+        assert torch.equal(got, got0), name
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    og = deform_forward(leaf, x, t, is_blender=True)
+    assert all(torch.equal(a, b) for a, b in zip(og, out))
+    torch.autograd.backward(og, tuple(torch.from_numpy(d[k]).cuda() for k in ("gx", "gr", "gs")))
+    for k, p in leaf.items():
+        want = torch.from_numpy(d["grad_" + k]).cuda()
+        assert p.grad is not None and p.grad.shape == want.shape, k
+        rel = float((p.grad - want).norm() / want.norm())
+        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else 0.25)
+        assert rel < tol, f"grad {k}: relative L2 distance to the fp32 golden gradient {rel:.3e}"
+    # (b) bf16-evaluated autograd, many rows
+    torch.manual_seed(5)
+    net = SynthDeformNetwork(is_blender=True).cuda()
+    n = 20_011
+    xx = (torch.rand(n, 3, device="cuda") * 2 - 1) * 1.3
+    tt = torch.tensor([[0.61]], device="cuda").expand(n, -1)
+    wx, wr, ws = torch.randn(n, 3, device="cuda"), torch.randn(n, 4, device="cuda"), torch.randn(n, 3, device="cuda")
+    a = _bf16_evaluated_net(net, xx, tt.contiguous())
+    sum((v * w).sum() for v, w in zip(a, (wx, wr, ws))).backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad()
+    b = DeformNetworkHIP(net)(xx, tt)
+    for u, v in zip(a, b):      # bf16 activations: a unit whose pre-activation sits on a rounding boundary moves an output by ~2e-4
+        assert float((u - v).detach().abs().max()) < 5e-3 * float(u.detach().abs().max()) + 1e-5
+    sum((v * w).sum() for v, w in zip(b, (wx, wr, ws))).backward()
+    assert any(k.startswith("timenet") for k in want)
+    for k, p in net.named_parameters():
+        rel = float((p.grad - want[k]).norm() / want[k].norm())
+        assert rel < 5e-2, f"grad {k}: rel L2 {rel:.3e}"
+    # (c)
+    with pytest.raises(NotImplementedError):
+        DeformNetworkHIP(net)(xx[:8], torch.rand(8, 1, device="cuda"))
 
 
 @pytest.mark.parametrize("with_deform", [False, True])

@@ -21,7 +21,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MW = 256;          // hidden width
 constexpr int MD = 8;            // hidden layers
-constexpr int EMB = 84;          // 63 + 21
+constexpr int EMB_T = 84;        // default network: PE(x) 63 + PE(t) 21 (t_multires = 10)
+constexpr int EMB_B = 93;        // is_blender (D-NeRF): PE(x) 63 + timenet output 30 (utils/time_utils.py:74-86)
 constexpr int EMBP = 96;         // padded to a multiple of 16
 constexpr int SKIP = 5;          // layer whose input is cat(PE, h)
 constexpr int MROWS = 32;        // rows per wave
@@ -33,6 +34,7 @@ struct MlpNet {
   const float* b[MD];
   const __bf16* w_head;  // [256/16][32][16]: rows 0-2 warp, 3-6 rotation, 7-9 scaling, rest 0
   const float* b_head;   // [32]
+  const float* temb;     // is_blender: the 30 timenet outputs shared by all rows (columns 63..92); else nullptr
 };
 
 __device__ __forceinline__ int mlp_kp(int l) { return l == 0 ? EMBP : (l == SKIP ? EMBP + MW : MW); }
@@ -42,6 +44,7 @@ struct MlpPackArgs {
   const float* w[MD]; const float* b[MD];
   const float* w_warp; const float* b_warp; const float* w_rot; const float* b_rot; const float* w_scale; const float* b_scale;
   __bf16* out_w[MD]; float* out_b[MD]; __bf16* out_wh; float* out_bh;
+  int emb;               // input columns of layer 0: EMB_T or EMB_B
 };
 
 __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackArgs a) {
@@ -49,6 +52,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (l < MD) {
     const int kp = l == 0 ? EMBP : (l == SKIP ? EMBP + MW : MW);
+    const int EMB = a.emb;
     const int kin = l == 0 ? EMB : (l == SKIP ? EMB + MW : MW);
     if (idx < MW * kp) {
       const int n = idx / kp, k = idx % kp;
@@ -80,15 +84,17 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackArgs a) {
 // ---- positional encoding, generated straight into an MFMA A fragment ---------------------------------
 // column order of cat(PE(x), PE(t)) as built by Embedder.embed (utils/time_utils.py:26-57):
 //   x(3), then per frequency 2^f: sin(x 2^f)(3), cos(x 2^f)(3);  t, then per frequency: sin(t 2^f), cos(t 2^f)
-__device__ __forceinline__ float pe_value(int c, float x0, float x1, float x2, float t) {
+//   is_blender: the time block is the timenet output instead (30 columns, the same for every row)
+__device__ __forceinline__ float pe_value(int c, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
   if (c < 3) return c == 0 ? x0 : (c == 1 ? x1 : x2);
   if (c < 63) {
     const int q = c - 3, f = q / 6, r = q % 6, d = r % 3;
     const float v = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * (float)(1 << f);
     return r < 3 ? __sinf(v) : __cosf(v);
   }
+  if (temb) return c < EMB_B ? temb[c - 63] : 0.f;
   if (c == 63) return t;
-  if (c < EMB) {
+  if (c < EMB_T) {
     const int q = c - 64, f = q >> 1;
     const float v = t * (float)(1 << f);
     return (q & 1) ? __cosf(v) : __sinf(v);
@@ -96,10 +102,10 @@ __device__ __forceinline__ float pe_value(int c, float x0, float x1, float x2, f
   return 0.f;
 }
 
-__device__ __forceinline__ bf16x8 pe_fragment(int c0, float x0, float x1, float x2, float t) {
+__device__ __forceinline__ bf16x8 pe_fragment(int c0, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
   bf16x8 a;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = (__bf16)pe_value(c0 + j, x0, x1, x2, t);
+  for (int j = 0; j < 8; ++j) a[j] = (__bf16)pe_value(c0 + j, x0, x1, x2, t, temb);
   return a;
 }
 
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel(MlpNet net, const
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
     for (int ks = 0; ks < steps; ++ks) {
       bf16x8 a;
-      if (ks < emb_steps) a = pe_fragment(ks * 16 + 8 * h, x0, x1, x2, tt);
+      if (ks < emb_steps) a = pe_fragment(ks * 16 + 8 * h, x0, x1, x2, tt, net.temb);
       else a = *reinterpret_cast<const bf16x8*>(act + act_off(m, (ks - emb_steps) * 16 + 8 * h));
       const __bf16* wk = W + ((size_t)ks * MW + m) * 16 + 8 * h;    // column n = nb*32 + m of this N block
 #pragma unroll
@@ -198,15 +204,16 @@ __global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel(MlpNet net, const
 //  * the positional encoding is generated branch-free (both lane halves' columns are compile-time constants).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float pe_const(int c, float x0, float x1, float x2, float t) {   // c is a compile-time constant
+__device__ __forceinline__ float pe_const(int c, float x0, float x1, float x2, float t, const float* __restrict__ temb) {   // c is a compile-time constant
   if (c < 3) return c == 0 ? x0 : (c == 1 ? x1 : x2);
   if (c < 63) {
     const int q = c - 3, f = q / 6, r = q % 6, d = r % 3;
     const float v = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * (float)(1 << f);
     return r < 3 ? __sinf(v) : __cosf(v);
   }
+  if (temb) return c < EMB_B ? temb[c - 63] : 0.f;       // wave-uniform pointer and address: scalar loads
   if (c == 63) return t;
-  if (c < EMB) {
+  if (c < EMB_T) {
     const int q = c - 64, f = q >> 1;
     const float v = t * (float)(1 << f);
     return (q & 1) ? __cosf(v) : __sinf(v);
@@ -215,12 +222,12 @@ __device__ __forceinline__ float pe_const(int c, float x0, float x1, float x2, f
 }
 
 template <int KS>
-__device__ __forceinline__ bf16x8 pe_fragment_ct(int h, float x0, float x1, float x2, float t) {
+__device__ __forceinline__ bf16x8 pe_fragment_ct(int h, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
   bf16x8 a;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float lo = pe_const(KS * 16 + j, x0, x1, x2, t);
-    const float hi = pe_const(KS * 16 + 8 + j, x0, x1, x2, t);
+    const float lo = pe_const(KS * 16 + j, x0, x1, x2, t, temb);
+    const float hi = pe_const(KS * 16 + 8 + j, x0, x1, x2, t, temb);
     a[j] = (__bf16)(h ? hi : lo);
   }
   return a;
@@ -255,10 +262,11 @@ __device__ __forceinline__ void emb_steps(f32x16 (&acc)[4], const __bf16* __rest
 }
 
 template <int KS>
-__device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0, float x1, float x2, float tt) {
+__device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0, float x1, float x2, float tt,
+                                        const float* __restrict__ temb) {
   if constexpr (KS < EMBP / 16) {
-    pe[KS] = pe_fragment_ct<KS>(h, x0, x1, x2, tt);
-    pe_fill<KS + 1>(pe, h, x0, x1, x2, tt);
+    pe[KS] = pe_fragment_ct<KS>(h, x0, x1, x2, tt, temb);
+    pe_fill<KS + 1>(pe, h, x0, x1, x2, tt, temb);
   }
 }
 
@@ -307,7 +315,7 @@ __device__ __forceinline__ void mlp_fwd_body(__bf16 (*s_act)[MROWS * MW], const 
   const float tt = t[(size_t)gm * t_stride];
   __bf16* act = s_act[wave];
   bf16x8 pe[EMBP / 16];
-  pe_fill<0>(pe, h, x0, x1, x2, tt);
+  pe_fill<0>(pe, h, x0, x1, x2, tt, net.temb);
   for (int l = 0; l < MD; ++l) {
     const bool has_emb = (l == 0 || l == SKIP);
     const int hid_steps = (l == 0) ? 0 : MW / 16;
@@ -433,6 +441,7 @@ struct MlpPackTArgs {
   const float* w[MD];
   const float* w_warp; const float* w_rot; const float* w_scale;
   __bf16* out_wt[MD]; __bf16* out_wth;
+  int emb;
 };
 
 __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
   if (l >= 1) {
     if (idx < MW * MW) {
       const int f = idx / MW, j = idx % MW;
-      const int kin = l == SKIP ? EMB + MW : MW, off = l == SKIP ? EMB : 0;
+      const int kin = l == SKIP ? a.emb + MW : MW, off = l == SKIP ? a.emb : 0;
       a.out_wt[l][((size_t)(f >> 4) * MW + j) * 16 + (f & 15)] = (__bf16)a.w[l][f * kin + off + j];
     }
   } else if (idx < MW * 16) {
@@ -457,14 +466,14 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
 // transposed image of the bf16 positional encoding, [tile][96][32] (columns 84..95 and padding rows zero):
 // the GEMM input of layers 0 and 5
 __global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
-                                                     int N, __bf16* __restrict__ peT) {
+                                                     const float* __restrict__ temb, int N, __bf16* __restrict__ peT) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)((N + 31) >> 5) * EMBP * 32;
   if (idx >= total) return;
   const int r = (int)(idx & 31), c = (int)((idx >> 5) % EMBP);
   const int row = (int)(idx / (EMBP * 32)) * 32 + r;
   float v = 0.f;
-  if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride]);
+  if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride], temb);
   peT[idx] = (__bf16)v;
 }
 
@@ -744,9 +753,9 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
 
 static int mlp_check_weights(const TraseMlpWeights* w, const char* who) {
   if (!w) { set_error("%s: null weights", who); return TRASE_ERR_INVALID; }
-  if (w->D != MD || w->W != MW || w->xyz_multires != 10 || w->t_multires != 10 || w->is_blender || w->is_6dof) {
-    set_error("%s: only the default DeformNetwork (D=8, W=256, multires=10, t_multires=10, "
-              "not blender, not 6dof) is compiled in", who);
+  if (w->D != MD || w->W != MW || w->xyz_multires != 10 || w->is_6dof || (w->is_blender ? w->t_multires != 6 : w->t_multires != 10)) {
+    set_error("%s: only DeformNetwork(D=8, W=256, multires=10, not 6dof) with t_multires=10 (default) or "
+              "is_blender (t_multires=6, timenet) is compiled in", who);
     return TRASE_ERR_UNSUPPORTED;
   }
   for (int l = 0; l < MD; ++l)
@@ -771,6 +780,8 @@ static int mlp_pack_forward(const TraseMlpWeights* w, void* ws, MlpNet& net, hip
   pa.out_bh = (float*)c; net.b_head = (const float*)c;
   pa.w_warp = w->w_warp; pa.b_warp = w->b_warp; pa.w_rot = w->w_rotation; pa.b_rot = w->b_rotation;
   pa.w_scale = w->w_scaling; pa.b_scale = w->b_scaling;
+  pa.emb = w->is_blender ? EMB_B : EMB_T;
+  net.temb = nullptr;
   {
     ProfScope ps("mlp_pack", stream);
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((MW * (EMBP + MW) + 255) / 256, MD + 1), dim3(256), 0, stream, pa);
@@ -811,6 +822,10 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
   TRASE_CHECK(hipSetDevice(device));
   MlpNet net;
   if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
+  if (w->is_blender) {                                     // t = the 30 timenet outputs shared by all rows
+    if (t_stride != 0) { set_error("trase_mlp_forward: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
+    net.temb = t;
+  }
   const int rows_per_block = MWAVES * MROWS;
   {
     ProfScope ps("mlp_fwd", stream);
@@ -838,10 +853,14 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
   TRASE_CHECK(hipSetDevice(device));
   MlpNet net;
   if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
+  if (w->is_blender) {
+    if (t_stride != 0) { set_error("trase_mlp_forward_train: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
+    net.temb = t;
+  }
   {
     ProfScope ps("mlp_pe", stream);
     const size_t n = (size_t)((N + 31) / 32) * EMBP * 32;
-    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, N, sv.peT);
+    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT);
   }
   TRASE_POST_LAUNCH("mlp_pe", stream, 0);
   const int rows_per_block = MWAVES * MROWS;
@@ -874,6 +893,8 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
   for (int l = 1; l < MD; ++l) { pa.w[l] = w->weight[l]; pa.out_wt[l] = bp.wt[l]; net.wt[l] = bp.wt[l]; }
   pa.out_wth = bp.wt_head; net.wt_head = bp.wt_head;
   pa.w_warp = w->w_warp; pa.w_rot = w->w_rotation; pa.w_scale = w->w_scaling;
+  const int EMB = w->is_blender ? EMB_B : EMB_T;           // input columns of the encoding block
+  pa.emb = EMB;
   {
     ProfScope ps("mlp_pack_t", stream);
     hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(MW * MW / 256, MD), dim3(256), 0, stream, pa);

@@ -31,10 +31,11 @@ from .rasterizer import _bytes, _stream
 PARAM_KEYS = tuple(k for i in range(8) for k in (f"linear.{i}.weight", f"linear.{i}.bias")) + (
     "gaussian_warp.weight", "gaussian_warp.bias", "gaussian_rotation.weight", "gaussian_rotation.bias",
     "gaussian_scaling.weight", "gaussian_scaling.bias")
-_EMB = 84
+TIMENET_KEYS = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias")   # is_blender only
 
 
 def _fill_weights(tensors, dev, keep, is_blender=False, is_6dof=False) -> "_lib.MlpWeights":
+    _EMB = 93 if is_blender else 84           # 63 + timenet output 30 | 63 + PE(t) 21  (utils/time_utils.py:70-97)
     def P(i):
         v = tensors[i].detach()
         if v.device != dev or v.dtype != torch.float32 or not v.is_contiguous():
@@ -43,7 +44,7 @@ def _fill_weights(tensors, dev, keep, is_blender=False, is_6dof=False) -> "_lib.
         return v
 
     w = _lib.MlpWeights()
-    w.D, w.W, w.xyz_multires, w.t_multires = 8, 256, 10, 10
+    w.D, w.W, w.xyz_multires, w.t_multires = 8, 256, 10, (6 if is_blender else 10)
     w.is_blender, w.is_6dof = int(is_blender), int(is_6dof)
     w.variant = int(os.environ.get("TRASE_MLP_VARIANT", "0"), 0)
     for i in range(8):
@@ -75,15 +76,38 @@ def _dev_index(dev):
     return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
+def _time_embedding(params, t, n):
+    """is_blender: ``timenet(embed_time_fn(t))`` (utils/time_utils.py:74-80, :107-109) evaluated ONCE -- the reference
+    feeds the same time to every row when is_blender (train.py:190-198: ``fid.unsqueeze(0).expand(N, -1)``, no
+    ``ast_noise``) and runs the two small Linear layers on all N identical rows.  Returns the (30,) output with autograd
+    history to the timenet parameters."""
+    if t.dim() == 2 and t.shape[0] == n and t.stride(0) == 0:
+        row = t[0:1]
+    else:
+        tt = t.reshape(n, -1)
+        if n > 1 and not bool((tt == tt[0:1]).all()):
+            raise NotImplementedError("trase_amd.deform: is_blender expects one time for all rows (train.py:190-198)")
+        row = tt[0:1]
+    row = row.reshape(1, 1).float()
+    freqs = 2.0 ** torch.arange(6, device=row.device, dtype=torch.float32)               # get_embedder(6, 1)
+    ang = row * freqs                                                                   # (1, 6)
+    emb = torch.cat([row, torch.stack([torch.sin(ang), torch.cos(ang)], dim=-1).reshape(1, 12)], dim=-1)   # t, sin, cos, ...
+    h = torch.relu(torch.nn.functional.linear(emb, params["timenet.0.weight"], params["timenet.0.bias"]))
+    return torch.nn.functional.linear(h, params["timenet.2.weight"], params["timenet.2.bias"]).reshape(30)
+
+
 class _DeformMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, t, *params):
+    def forward(ctx, x, t, is_blender, *params):
         lib = _lib.load()
         dev = x.device
         n = x.shape[0]
         keep = []
-        w = _fill_weights(params, dev, keep)
-        xs, tt, t_stride = _prep_xt(x, t)
+        w = _fill_weights(params, dev, keep, is_blender)
+        if is_blender:                      # t = the (30,) timenet output, shared by all rows
+            xs, tt, t_stride = x.detach().float().contiguous(), t.detach().float().contiguous(), 0
+        else:
+            xs, tt, t_stride = _prep_xt(x, t)
         d_xyz = torch.empty(n, 3, device=dev)
         d_rot = torch.empty(n, 4, device=dev)
         d_scale = torch.empty(n, 3, device=dev)
@@ -98,6 +122,7 @@ class _DeformMLP(torch.autograd.Function):
         ctx.save_for_backward(saved, *params)
         ctx.n = n
         ctx.bwd_bytes = bwd_b.value
+        ctx.is_blender = bool(is_blender)
         return d_xyz, d_rot, d_scale
 
     @staticmethod
@@ -106,11 +131,15 @@ class _DeformMLP(torch.autograd.Function):
         saved, *params = ctx.saved_tensors
         dev = saved.device
         n = ctx.n
-        need = ctx.needs_input_grad[2:]
+        need = list(ctx.needs_input_grad[3:])
+        need_t = ctx.is_blender and ctx.needs_input_grad[1]
         if n == 0:
-            return (None, None, *[torch.zeros_like(p) if nd else None for p, nd in zip(params, need)])
+            return (None, torch.zeros(30, device=dev) if need_t else None, None,
+                    *[torch.zeros_like(p) if nd else None for p, nd in zip(params, need)])
+        if need_t:                          # the time block's gradient is assembled from the bias gradients of its two layers
+            need[1] = need[11] = True
         keep = []
-        w = _fill_weights(params, dev, keep)
+        w = _fill_weights(params, dev, keep, ctx.is_blender)
         g_xyz, g_rot, g_scale = (None if g is None else g.float().contiguous() for g in (g_xyz, g_rot, g_scale))
         out = [torch.empty(p.shape, dtype=torch.float32, device=dev) if nd else None for p, nd in zip(params, need)]
         gr = _lib.MlpGrads()
@@ -123,27 +152,39 @@ class _DeformMLP(torch.autograd.Function):
         _lib.check(lib.trase_mlp_backward(C.byref(w), n, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(g_scale),
                                           _lib.ptr(saved), saved.numel(), C.byref(gr), _lib.ptr(ws), ws.numel(),
                                           _dev_index(dev), _stream(dev)), "trase_mlp_backward")
-        return (None, None, *out)
+        g_t = None
+        if need_t:
+            # every row sees the same 30 inputs at columns 63..92 of layer 0 and of the skip layer, so
+            # dL/dtemb = sum_rows dZ_0 W_0[:, 63:93] + sum_rows dZ_5 W_5[:, 63:93] = db_0 W_0[:, 63:93] + db_5 W_5[:, 63:93]
+            g_t = out[1] @ params[0].detach()[:, 63:93] + out[11] @ params[10].detach()[:, 63:93]
+        real = ctx.needs_input_grad[3:]
+        return (None, g_t, None, *[o if nd else None for o, nd in zip(out, real)])
 
 
 def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
                    is_blender: bool = False, is_6dof: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     if x.device.type != "cuda":
         raise RuntimeError("deform_forward runs on the GPU only (there is no CPU path)")
+    if is_6dof:
+        raise NotImplementedError("trase_amd.deform: the is_6dof head (exp_se3, utils/time_utils.py:111-118) is not compiled in")
     tensors = [params[k] for k in PARAM_KEYS]
-    if torch.is_grad_enabled() and any(p.requires_grad for p in tensors):
-        if is_blender or is_6dof:
-            raise NotImplementedError("trase_amd.deform: only the default DeformNetwork variant is compiled in")
+    n = x.shape[0]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in tensors + ([params[k] for k in TIMENET_KEYS] if is_blender else [])):
         if x.requires_grad or t.requires_grad:
             raise NotImplementedError("trase_amd.deform: x and t are detached inputs in the reference "
                                       "(scene/deform_model.py:34-35 called at train.py:202-204); no gradient is produced for them")
-        return _DeformMLP.apply(x, t, *tensors)
+        tin = _time_embedding(params, t.detach(), n) if is_blender else t
+        return _DeformMLP.apply(x, tin, bool(is_blender), *tensors)
     lib = _lib.load()
     dev = x.device
-    n = x.shape[0]
     keep = []
     w = _fill_weights(tensors, dev, keep, is_blender, is_6dof)
-    xs, tt, t_stride = _prep_xt(x, t)
+    if is_blender:
+        with torch.no_grad():
+            tt = _time_embedding(params, t, n).float().contiguous()
+        xs, t_stride = x.detach().float().contiguous(), 0
+    else:
+        xs, tt, t_stride = _prep_xt(x, t)
     d_xyz = torch.empty(n, 3, device=dev)
     d_rot = torch.empty(n, 4, device=dev)
     d_scale = torch.empty(n, 3, device=dev)
@@ -166,4 +207,5 @@ class DeformNetworkHIP(torch.nn.Module):
 
     def forward(self, x, t):
         params = dict(self.net.named_parameters())
-        return deform_forward(params, x, t)
+        return deform_forward(params, x, t, is_blender=bool(getattr(self.net, "is_blender", False)),
+                              is_6dof=bool(getattr(self.net, "is_6dof", False)))

@@ -201,10 +201,15 @@ class SynthDeformNetwork(torch.nn.Module):
     output).  A parameter holder for benches and tests; its eager fp32 ``forward`` is the "what the reference
     runs" comparison leg, never the product path (that is ``trase_amd.deform.deform_forward``)."""
 
-    def __init__(self):
+    def __init__(self, is_blender: bool = False):
         super().__init__()
+        self.is_blender, self.is_6dof = bool(is_blender), False
+        emb = 84
+        if is_blender:                      # utils/time_utils.py:74-86: t_multires = 6, timenet 13 -> 256 -> 30
+            emb = 93
+            self.timenet = torch.nn.Sequential(torch.nn.Linear(13, 256), torch.nn.ReLU(inplace=True), torch.nn.Linear(256, 30))
         self.linear = torch.nn.ModuleList(
-            [torch.nn.Linear(84, 256)] + [torch.nn.Linear(340 if i == 4 else 256, 256) for i in range(7)])
+            [torch.nn.Linear(emb, 256)] + [torch.nn.Linear(emb + 256 if i == 4 else 256, 256) for i in range(7)])
         self.gaussian_warp = torch.nn.Linear(256, 3)
         self.gaussian_rotation = torch.nn.Linear(256, 4)
         self.gaussian_scaling = torch.nn.Linear(256, 3)
@@ -216,8 +221,11 @@ class SynthDeformNetwork(torch.nn.Module):
             out += [torch.sin(v * 2.0 ** f), torch.cos(v * 2.0 ** f)]
         return torch.cat(out, -1)
 
+    def time_block(self, t):
+        return self.timenet(self.embed(t, 6)) if self.is_blender else self.embed(t, 10)
+
     def forward(self, x, t):
-        e = torch.cat([self.embed(x, 10), self.embed(t, 10)], -1)
+        e = torch.cat([self.embed(x, 10), self.time_block(t)], -1)
         h = e
         for i, l in enumerate(self.linear):
             h = torch.relu(l(h))
