@@ -13,6 +13,8 @@ from trase_amd import rasterizer as R
 from trase_amd.synthetic import make_scene, orbit_camera, SynthGaussianModel, SynthPipe, SynthDeformNetwork
 from trase_amd.deform import DeformNetworkHIP
 from trase_amd.losses import l1_ssim
+from trase_amd.optim import FusedAdam
+from trase_amd.densify import add_densification_stats
 from trase_amd.renderer import render
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
@@ -47,6 +49,15 @@ def main():
         for p in params:
             p.grad = None
 
+    # the rest of the iteration (train.py:361-389): densification statistics + the two optimizer steps
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 2.5e-3]
+    groups = lambda: [{"params": [p], "lr": lr, "name": str(k)} for k, (p, lr) in enumerate(zip(pc.parameters(), lrs))]
+    opt_hip = [FusedAdam(groups(), lr=0.0, eps=1e-15), FusedAdam(list(net.parameters()), lr=8e-4, eps=1e-15)]
+    opt_ref = [torch.optim.Adam(groups(), lr=0.0, eps=1e-15), torch.optim.Adam(list(net.parameters()), lr=8e-4, eps=1e-15)]
+    from types import SimpleNamespace
+    stats = SimpleNamespace(xyz_gradient_accum=torch.zeros(N, 1, device=dev), denom=torch.zeros(N, 1, device=dev),
+                            max_radii2D=torch.zeros(N, device=dev))
+
     def all_hip(i):
         zero()
         cam = cams[i % 8]
@@ -55,6 +66,13 @@ def main():
         out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)
         l1, ss = l1_ssim(out["render"], gts[i % 2])
         (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+        return out["viewspace_points"], out["radii"]
+
+    def all_hip_full(i):
+        vp, radii = all_hip(i)
+        add_densification_stats(stats, vp, radii)
+        for o in opt_hip:
+            o.step()
 
     def ref_comp(i):
         zero()
@@ -73,6 +91,16 @@ def main():
             opacities=pc.get_opacity, scales=pc.get_scaling + d_scale, rotations=pc.get_rotation + d_rot, cov3D_precomp=None)
         gt = gts[i % 2]
         (0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - ref_ssim(img, gt, win))).backward()
+        return m2d, radii
+
+    def ref_comp_full(i):
+        vp, radii = ref_comp(i)
+        vis = radii > 0                                                                   # train.py:362-365
+        stats.max_radii2D[vis] = torch.max(stats.max_radii2D[vis], radii[vis])
+        stats.xyz_gradient_accum[vis] += torch.norm(vp.grad[vis, :2], dim=-1, keepdim=True)
+        stats.denom[vis] += 1
+        for o in opt_ref:
+            o.step()
 
     # capacity for sync-free steps
     R.set_sync(True)
@@ -92,9 +120,13 @@ def main():
 
     t_hip = timed(all_hip)
     t_ref = timed(ref_comp)
-    print(json.dumps({"workload": "GAUSSIAN-state iteration without optimizer step, 300k Gaussians, 1920x1080, F=32",
+    t_hip_full = timed(all_hip_full)
+    t_ref_full = timed(ref_comp_full)
+    print(json.dumps({"workload": "GAUSSIAN-state iteration, 300k Gaussians, 1920x1080, F=32",
                       "all_hip_ms": round(t_hip, 3), "ref_composition_around_hip_rasterizer_ms": round(t_ref, 3),
-                      "iterations_per_s_all_hip": round(1e3 / t_hip, 1)}))
+                      "iterations_per_s_all_hip": round(1e3 / t_hip, 1),
+                      "with_stats_and_optimizer_steps": {"all_hip_ms": round(t_hip_full, 3), "ref_composition_ms": round(t_ref_full, 3),
+                                                         "iterations_per_s_all_hip": round(1e3 / t_hip_full, 1)}}))
 
 
 if __name__ == "__main__":
