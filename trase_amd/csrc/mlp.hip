@@ -412,6 +412,205 @@ void mlp_fwd_kernel_v3(MlpNet net, const float* __restrict__ x, const float* __r
   mlp_fwd_body<false>(s_act, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
 }
 
+// ---- inference forward, block-GEMM organisation ---------------------------------------------------------------------
+// The 32-row chain kernel makes every wave stream every weight slab from L2 on its own (16 MAC per byte through the vector
+// memory path) and hides the round trip with a single K-step of lookahead; PMC shows the matrix pipe busy 36 %.  Here
+// the WORKGROUP owns 128 rows and stages each 256 x 16 weight slab (8 KiB, contiguous in the K-slice-major packing) in
+// LDS exactly once, double-buffered, one workgroup barrier per K-step.  Wave (wr, wc) owns rows wr*64.. (two 32-row
+// groups) x output columns wc*128.. : 8 MFMAs per K-step from 4 weight + 2 activation fragments out of LDS, 128
+// accumulator registers, two workgroups per CU (80 KiB of LDS each: 64 KiB activations shared by the four waves + two
+// slabs).  Slab layout in LDS: [k/8][n][k%8] (two 4 KiB planes): the fragment reads of a lane half are 16-byte-contiguous
+// (conflict-free), as are the staging writes.  No `held` half: the tile is rewritten after the K loop, behind a barrier.
+constexpr int BRG = 2;                       // 32-row groups per wave
+constexpr int BROWS = 2 * BRG * MROWS;       // rows per workgroup (128)
+
+// encoding fragment of K-step KS for the block kernel: the time block is selected between PE(t) and the (pre-loaded,
+// wave-uniform) timenet outputs without branches
+template <int KS>
+__device__ __forceinline__ bf16x8 blk_pe_fragment(int h, const float (&p)[4], bool blender, const float (&tb)[32]) {
+  bf16x8 a;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = KS * 16 + 8 * hh + j;
+      if (c < 63) v[hh] = pe_const(c, p[0], p[1], p[2], p[3], nullptr);
+      else {
+        const float pv = pe_const(c, p[0], p[1], p[2], p[3], nullptr);
+        const float tv = (c < EMB_B) ? tb[c - 63] : 0.f;
+        v[hh] = blender ? tv : pv;
+      }
+    }
+    a[j] = (__bf16)(h ? v[1] : v[0]);
+  }
+  return a;
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() is a release/acquire fence and drains vmcnt too, which
+// would force the slab loads that are deliberately in flight across the barrier to complete at every K-step
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0); vmcnt and expcnt left at their maxima
+  __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                        float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // [buffer][k half][n][8]: 16 KiB
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int lrow0 = wr * (BRG * MROWS);        // first row of this wave inside the tile
+  const int row0 = blockIdx.x * BROWS + lrow0;
+  float px[BRG][4];                            // x, y, z, t of this lane's row in each group: the encoding is generated
+#pragma unroll                                 // on the fly in the six encoding K-steps of layers 0 and 5
+  for (int g = 0; g < BRG; ++g) {
+    const int gm = min(row0 + 32 * g + m, N - 1);
+    px[g][0] = x[3 * gm]; px[g][1] = x[3 * gm + 1]; px[g][2] = x[3 * gm + 2]; px[g][3] = t[(size_t)gm * t_stride];
+  }
+  const bool blender = net.temb != nullptr;
+  float tb[32];                                // is_blender: the 30 shared timenet outputs (scalar loads); else unused zeros
+  {
+    const float* tp = blender ? net.temb : net.b_head;     // always a valid address: the loads need no branch
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tb[i] = (i < EMB_B - 63) ? tp[i] : 0.f;
+  }
+  const int sn = threadIdx.x;                  // thread i stages output column n = i of a slab (two 16-byte pieces)
+  uint4 sa0, sa1, sb0, sb1;                    // slab registers -- sa: odd slabs, sb: even slabs (plain scalars: registers)
+  {                                            // slabs 0 and 1 of the first layer; later layers get theirs from the
+    const __bf16* src = net.w[0] + (size_t)sn * 16;          // last K-step pair of the layer before
+    sb0 = *reinterpret_cast<const uint4*>(src); sb1 = *reinterpret_cast<const uint4*>(src + 8);
+    sa0 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16); sa1 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16 + 8);
+  }
+  for (int l = 0; l < MD; ++l) {
+    const bool has_emb = (l == 0 || l == SKIP);
+    const int emb_k = has_emb ? EMBP / 16 : 0;
+    const int steps = emb_k + ((l == 0) ? 0 : MW / 16);
+    const __bf16* __restrict__ W = net.w[l];
+    const __bf16* __restrict__ Wn = net.w[min(l + 1, MD - 1)];
+    const float* __restrict__ B = net.b[l];
+    f32x16 acc[BRG][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bias = *reinterpret_cast<const float4*>(B + wc * 128 + nb * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int g = 0; g < BRG; ++g) {
+          acc[g][nb][4 * q + 0] = bias.x; acc[g][nb][4 * q + 1] = bias.y; acc[g][nb][4 * q + 2] = bias.z; acc[g][nb][4 * q + 3] = bias.w;
+        }
+      }
+    // slab pipeline: slab ks is in LDS buffer ks&1 during K-step ks; its global loads were issued TWO K-steps earlier
+    // (registers sa / sb alternate), it was parked in LDS at the end of K-step ks-1, behind that step's barrier
+    // slab ks of this layer; past the end: slabs 0 / 1 of the next layer (every layer has an even number of K-steps)
+    auto slab_load = [&](int ks, uint4& r0, uint4& r1) {
+      const __bf16* src = (ks < steps ? W + (size_t)ks * MW * 16 : Wn + (size_t)(ks - steps) * MW * 16) + (size_t)sn * 16;
+      r0 = *reinterpret_cast<const uint4*>(src); r1 = *reinterpret_cast<const uint4*>(src + 8);
+    };
+    auto slab_park = [&](int buf, const uint4& r0, const uint4& r1) {
+      *reinterpret_cast<uint4*>(&s_w[buf][0][sn * 8]) = r0;
+      *reinterpret_cast<uint4*>(&s_w[buf][1][sn * 8]) = r1;
+    };
+    slab_park(0, sb0, sb1);                                  // slab 0 (requested during the previous layer's last K-steps)
+    lds_barrier();
+    auto mma = [&](int buf, const bf16x8 (&a)[BRG]) {
+      const __bf16* wl = &s_w[buf][h][(wc * 128) * 8];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wl + (nb * 32 + m) * 8);
+#pragma unroll
+        for (int g = 0; g < BRG; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a[g], acc[g][nb], 0, 0, 0);
+      }
+    };
+    // a pair of K-steps (ks even): the loop is written two steps at a time so that sa / sb are static registers
+    auto kpair = [&](int ks, const bf16x8 (&a0)[BRG], const bf16x8 (&a1)[BRG]) {
+      slab_load(ks + 2, sb0, sb1);
+      mma(0, a0);
+      slab_park(1, sa0, sa1);                                // slab ks+1
+      lds_barrier();
+      slab_load(ks + 3, sa0, sa1);
+      mma(1, a1);
+      if (ks + 2 < steps) slab_park(0, sb0, sb1);            // slab ks+2
+      lds_barrier();
+    };
+    auto pe_frag = [&](int ks, int g) -> bf16x8 {
+      switch (ks) {                                          // folds after unrolling: the columns are compile-time constants
+        case 0: return blk_pe_fragment<0>(h, px[g], blender, tb);
+        case 1: return blk_pe_fragment<1>(h, px[g], blender, tb);
+        case 2: return blk_pe_fragment<2>(h, px[g], blender, tb);
+        case 3: return blk_pe_fragment<3>(h, px[g], blender, tb);
+        case 4: return blk_pe_fragment<4>(h, px[g], blender, tb);
+        default: return blk_pe_fragment<5>(h, px[g], blender, tb);
+      }
+    };
+    if (has_emb) {
+      // opaque to loop-invariant code motion: otherwise the 2 x 96 encoding values of layers 0 and 5 are computed once
+      // before the layer loop and kept (= spilled) across the hidden layers
+#pragma unroll
+      for (int g = 0; g < BRG; ++g) asm volatile("" : "+v"(px[g][0]), "+v"(px[g][1]), "+v"(px[g][2]), "+v"(px[g][3]));
+#pragma unroll
+      for (int ks = 0; ks < EMBP / 16; ks += 2) {
+        const bf16x8 a0[BRG] = {pe_frag(ks, 0), pe_frag(ks, 1)}, a1[BRG] = {pe_frag(ks + 1, 0), pe_frag(ks + 1, 1)};
+        kpair(ks, a0, a1);
+      }
+    }
+    for (int ks = emb_k; ks < steps; ks += 2) {
+      bf16x8 a0[BRG], a1[BRG];
+#pragma unroll
+      for (int g = 0; g < BRG; ++g) {
+        a0[g] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, (ks - emb_k) * 16 + 8 * h));
+        a1[g] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, (ks + 1 - emb_k) * 16 + 8 * h));
+      }
+      kpair(ks, a0, a1);
+    }
+    // epilogue: ReLU, bf16, this wave's 64 x 128 block of the tile (all reads of the old tile are behind the last barrier)
+#pragma unroll
+    for (int g = 0; g < BRG; ++g)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = bf16_bits(fmaxf(acc[g][nb][4 * q + e], 0.f));
+          *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * g + m, wc * 128 + nb * 32 + 8 * q + 4 * h)) = pk;
+        }
+    __syncthreads();
+  }
+  if (wc != 0) return;                                       // heads: one wave per 64 rows
+  f32x16 hacc[BRG];
+#pragma unroll
+  for (int g = 0; g < BRG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[g][r] = 0.f;
+  for (int ks = 0; ks < MW / 16; ++ks) {
+    const bf16x8 w = *reinterpret_cast<const bf16x8*>(net.w_head + ((size_t)ks * HEADP + m) * 16 + 8 * h);
+#pragma unroll
+    for (int g = 0; g < BRG; ++g) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, ks * 16 + 8 * h));
+      hacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, hacc[g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < BRG; ++g) {
+    const int grow = row0 + 32 * g + m;
+    if (grow < N) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int o = 8 * (r >> 2) + 4 * h + (r & 3);
+        if (o < 10) {
+          const float v = hacc[g][r] + net.b_head[o];
+          if (o < 3) d_xyz[(size_t)grow * 3 + o] = v;
+          else if (o < 7) d_rot[(size_t)grow * 4 + (o - 3)] = v;
+          else d_scale[(size_t)grow * 3 + (o - 7)] = v;
+        }
+      }
+    }
+  }
+}
+
 // the training forward spends a third of its time draining the saved-state stores (vmcnt is shared by loads and
 // stores, so a wave waiting for its next weight fragment also waits for its stores): two waves per SIMD let one
 // wave compute while the other drains
@@ -832,6 +1031,9 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
     const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
     if (w->variant & 1)       // v1: first-generation kernel (kept for A/B)
       hipLaunchKernelGGL(mlp_fwd_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
+    else if (w->variant & 2)  // block-GEMM organisation
+      hipLaunchKernelGGL(mlp_fwd_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N, d_xyz,
+                         d_rotation, d_scaling);
     else
       hipLaunchKernelGGL(mlp_fwd_kernel_v3, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
   }
