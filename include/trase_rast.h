@@ -214,7 +214,8 @@ typedef struct TraseMlpWeights {
                           * timenet(PE(t))), 93 inputs -- the caller evaluates the tiny timenet and passes its 30 outputs
                           * as `t` with t_stride 0 (train.py:190-202 feeds the same time to every row when is_blender) */
   int32_t is_6dof;       /* must be 0 */
-  int32_t variant;       /* 0 = default kernel; bit 0 = first-generation kernel (A/B) */
+  int32_t variant;       /* 0 = default (block-GEMM inference kernel); bit 0 = first-generation kernel, bit 1 = per-wave
+                          * weight streaming (both kept for A/B) */
   int32_t reserved;
   const float* weight[8];/* linear.{i}.weight: (256, 84|93) / (256, 256) / (256, 340|349) for the skip layer i = 5 */
   const float* bias[8];  /* linear.{i}.bias  : (256,) */

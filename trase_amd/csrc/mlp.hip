@@ -1031,11 +1031,11 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
     const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
     if (w->variant & 1)       // v1: first-generation kernel (kept for A/B)
       hipLaunchKernelGGL(mlp_fwd_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
-    else if (w->variant & 2)  // block-GEMM organisation
+    else if (w->variant & 2)  // v3: every wave streams the weights for its own 32 rows (kept for A/B)
+      hipLaunchKernelGGL(mlp_fwd_kernel_v3, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
+    else                      // block-GEMM organisation: weight slabs staged in LDS once per 128-row workgroup
       hipLaunchKernelGGL(mlp_fwd_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N, d_xyz,
                          d_rotation, d_scaling);
-    else
-      hipLaunchKernelGGL(mlp_fwd_kernel_v3, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
   }
   TRASE_POST_LAUNCH("mlp_fwd", stream, 0);
   return TRASE_OK;
