@@ -454,11 +454,14 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
-                        float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
-  __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
-  __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // [buffer][k half][n][8]: 16 KiB
+// SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations and the
+// ReLU gates (same saved-state layout as the chain kernel, so the backward does not care which forward produced it)
+template <bool SAVE>
+__device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf16 (*s_w)[2][MW * 8], const MlpNet& net,
+                                                 const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                                                 float* __restrict__ d_xyz, float* __restrict__ d_rot,
+                                                 float* __restrict__ d_scale, __bf16* __restrict__ actsT,
+                                                 uint32_t* __restrict__ gates) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int wr = wave & 1, wc = wave >> 1;
@@ -567,16 +570,28 @@ void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __
     }
     // epilogue: ReLU, bf16, this wave's 64 x 128 block of the tile (all reads of the old tile are behind the last barrier)
 #pragma unroll
-    for (int g = 0; g < BRG; ++g)
+    for (int g = 0; g < BRG; ++g) {
+      const int grow = row0 + 32 * g + m;
+      __bf16* const tileT = SAVE ? actsT + ((size_t)l * ((N + 31) >> 5) + ((row0 + 32 * g) >> 5)) * (MW * 32) : nullptr;
+      unsigned gate[2] = {0u, 0u};                           // SAVE: this lane's 64 ReLU gates of the layer
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const int f0 = wc * 128 + nb * 32 + 8 * q + 4 * h;
           s16x4 pk;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pk[e] = bf16_bits(fmaxf(acc[g][nb][4 * q + e], 0.f));
-          *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * g + m, wc * 128 + nb * 32 + 8 * q + 4 * h)) = pk;
+          *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * g + m, f0)) = pk;
+          if constexpr (SAVE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gate[nb >> 1] |= (pk[e] & 0x7fff) ? 1u << ((nb & 1) * 16 + q * 4 + e) : 0u;
+            if ((row0 + 32 * g) < N) store_transposed(tileT, f0, m, grow < N ? pk : s16x4{0, 0, 0, 0});   // padding rows: zeros
+          }
         }
+      if constexpr (SAVE)      // the row's 256 gate bits are two uint4 (h = 0 / 1); this wave owns words 2 wc, 2 wc + 1 of each
+        if (grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
+    }
     __syncthreads();
   }
   if (wc != 0) return;                                       // heads: one wave per 64 rows
@@ -609,6 +624,23 @@ void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __
       }
     }
   }
+}
+
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                        float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // [buffer][k half][n][8]: 16 KiB
+  mlp_fwd_blk_body<false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
+}
+
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_train_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                              float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
+                              __bf16* __restrict__ actsT, uint4* __restrict__ gates) {
+  __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];
+  mlp_fwd_blk_body<true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
 }
 
 // the training forward spends a third of its time draining the saved-state stores (vmcnt is shared by loads and
@@ -1069,8 +1101,12 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
   {
     ProfScope ps("mlp_fwd_train", stream);
     const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
-    hipLaunchKernelGGL(mlp_fwd_train_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation,
-                       d_scaling, sv.actsT, sv.gates);
+    if (w->variant & 2)       // per-wave weight streaming (kept for A/B)
+      hipLaunchKernelGGL(mlp_fwd_train_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation,
+                         d_scaling, sv.actsT, sv.gates);
+    else
+      hipLaunchKernelGGL(mlp_fwd_train_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N,
+                         d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates);
   }
   TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
   return TRASE_OK;
