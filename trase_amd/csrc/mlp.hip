@@ -592,7 +592,7 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
       if constexpr (SAVE)      // the row's 256 gate bits are two uint4 (h = 0 / 1); this wave owns words 2 wc, 2 wc + 1 of each
         if (grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
     }
-    __syncthreads();
+    lds_barrier();             // the tile is complete; the image stores and the next layer's slab loads stay in flight
   }
   if (wc != 0) return;                                       // heads: one wave per 64 rows
   f32x16 hacc[BRG];
@@ -706,6 +706,139 @@ __global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x
   float v = 0.f;
   if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride], temb);
   peT[idx] = (__bf16)v;
+}
+
+// backward data chain on the block-GEMM organisation of mlp_fwd_blk_body: the workgroup owns 128 rows and stages every
+// slab of the TRANSPOSED weights in LDS once; wave (wr, wc) owns rows wr*64.. x input columns wc*128..; the dZ tile lives in
+// the shared 64 KiB activation tile; every dZ_l leaves as a transposed image.  The head stage is a single K-step whose
+// four weight fragments each wave reads straight from L2.
+__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const float* __restrict__ g_rot,
+                             const float* __restrict__ g_scale, int N, const uint32_t* __restrict__ gates,
+                             __bf16* __restrict__ dzT, __bf16* __restrict__ gT) {
+  __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // 16 KiB
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int lrow0 = wr * (BRG * MROWS);
+  const int row0 = blockIdx.x * BROWS + lrow0;
+  const int tiles = (N + 31) >> 5;
+  const int sn = threadIdx.x;
+  // slabs 0 and 1 of the first hidden stage (l = MD - 1) are requested before the head stage
+  uint4 sa0, sa1, sb0, sb1;
+  {
+    const __bf16* src = net.wt[MD - 1] + (size_t)sn * 16;
+    sb0 = *reinterpret_cast<const uint4*>(src); sb1 = *reinterpret_cast<const uint4*>(src + 8);
+    sa0 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16); sa1 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16 + 8);
+  }
+  // cotangent of the ten head outputs as one 16-wide K-step: columns 0-2 d_xyz, 3-6 rotation, 7-9 scaling
+  bf16x8 g8[BRG];
+  bool live[BRG];
+  int gmr[BRG];
+#pragma unroll
+  for (int gi = 0; gi < BRG; ++gi) {
+    const int grow = row0 + 32 * gi + m;
+    const int gm = min(grow, N - 1);
+    live[gi] = grow < N; gmr[gi] = gm;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    if (live[gi]) {
+      if (h == 0) {
+        if (g_xyz) { g[0] = g_xyz[3 * (size_t)gm]; g[1] = g_xyz[3 * (size_t)gm + 1]; g[2] = g_xyz[3 * (size_t)gm + 2]; }
+        if (g_rot) { g[3] = g_rot[4 * (size_t)gm]; g[4] = g_rot[4 * (size_t)gm + 1]; g[5] = g_rot[4 * (size_t)gm + 2]; g[6] = g_rot[4 * (size_t)gm + 3]; }
+        if (g_scale) g[7] = g_scale[3 * (size_t)gm];
+      } else if (g_scale) { g[0] = g_scale[3 * (size_t)gm + 1]; g[1] = g_scale[3 * (size_t)gm + 2]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g8[gi][j] = (__bf16)g[j];
+    // transposed image of the cotangent, [tile][32 columns][32 rows] (columns 10..31 zero): operand of the head GEMM
+    if (wc == 0 && row0 + 32 * gi < N) {
+      __bf16* gt = gT + (size_t)((row0 + 32 * gi) >> 5) * (HEADP * 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gt[(8 * h + j) * 32 + m] = g8[gi][j];
+        gt[(16 + 8 * h + j) * 32 + m] = (__bf16)0.f;
+      }
+    }
+  }
+  for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
+    f32x16 acc[BRG][4];
+#pragma unroll
+    for (int gi = 0; gi < BRG; ++gi)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[gi][nb][r] = 0.f;
+    if (l == MD) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(net.wt_head + (size_t)(wc * 128 + nb * 32 + m) * 16 + 8 * h);
+#pragma unroll
+        for (int gi = 0; gi < BRG; ++gi) acc[gi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, g8[gi], acc[gi][nb], 0, 0, 0);
+      }
+    } else {
+      const __bf16* __restrict__ W = net.wt[l];
+      const __bf16* __restrict__ Wn = net.wt[max(l - 1, 1)];
+      constexpr int steps = MW / 16;
+      auto slab_load = [&](int ks, uint4& r0, uint4& r1) {   // past the end: slabs 0 / 1 of the next stage
+        const __bf16* src = (ks < steps ? W + (size_t)ks * MW * 16 : Wn + (size_t)(ks - steps) * MW * 16) + (size_t)sn * 16;
+        r0 = *reinterpret_cast<const uint4*>(src); r1 = *reinterpret_cast<const uint4*>(src + 8);
+      };
+      auto slab_park = [&](int buf, const uint4& r0, const uint4& r1) {
+        *reinterpret_cast<uint4*>(&s_w[buf][0][sn * 8]) = r0;
+        *reinterpret_cast<uint4*>(&s_w[buf][1][sn * 8]) = r1;
+      };
+      slab_park(0, sb0, sb1);
+      lds_barrier();
+      auto mma = [&](int buf, const bf16x8 (&a)[BRG]) {
+        const __bf16* wl = &s_w[buf][h][(wc * 128) * 8];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wl + (nb * 32 + m) * 8);
+#pragma unroll
+          for (int gi = 0; gi < BRG; ++gi) acc[gi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a[gi], acc[gi][nb], 0, 0, 0);
+        }
+      };
+      for (int ks = 0; ks < steps; ks += 2) {
+        bf16x8 a0[BRG], a1[BRG];
+#pragma unroll
+        for (int gi = 0; gi < BRG; ++gi) {
+          a0[gi] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * gi + m, ks * 16 + 8 * h));
+          a1[gi] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * gi + m, (ks + 1) * 16 + 8 * h));
+        }
+        slab_load(ks + 2, sb0, sb1);
+        mma(0, a0);
+        slab_park(1, sa0, sa1);
+        lds_barrier();
+        slab_load(ks + 3, sa0, sa1);
+        mma(1, a1);
+        if (ks + 2 < steps) slab_park(0, sb0, sb1);
+        lds_barrier();
+      }
+    }
+    // epilogue: ReLU gate recorded by the forward, bf16, LDS tile for the next stage + transposed image
+#pragma unroll
+    for (int gi = 0; gi < BRG; ++gi) {
+      const uint2 gv = *reinterpret_cast<const uint2*>(gates + (((size_t)(l - 1) * N + gmr[gi]) * 2 + h) * 4 + wc * 2);
+      const unsigned gate[2] = {gv.x, gv.y};
+      __bf16* const tileT = dzT + ((size_t)(l - 1) * tiles + ((row0 + 32 * gi) >> 5)) * (MW * 32);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = wc * 128 + nb * 32 + 8 * q + 4 * h;
+          const unsigned bits = live[gi] ? gate[nb >> 1] >> ((nb & 1) * 16 + q * 4) : 0u;
+          s16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (bits >> e & 1u) ? bf16_bits(acc[gi][nb][4 * q + e]) : (short)0;
+          *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * gi + m, f0)) = pk;
+          if (row0 + 32 * gi < N) store_transposed(tileT, f0, m, pk);
+        }
+    }
+    lds_barrier();
+  }
 }
 
 __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_bwd_data_kernel(MlpNetT net, const float* __restrict__ g_xyz,
@@ -1142,8 +1275,12 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
     ProfScope ps("mlp_bwd_data", stream);
     const int rows_per_block = MWAVES * MROWS;
     const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
-    hipLaunchKernelGGL(mlp_bwd_data_kernel, grid, block, 0, stream, net, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling, N,
-                       (const uint4*)sv.gates, bp.dzT, bp.gT);
+    if (w->variant & 2)       // per-wave weight streaming (kept for A/B)
+      hipLaunchKernelGGL(mlp_bwd_data_kernel, grid, block, 0, stream, net, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling, N,
+                         (const uint4*)sv.gates, bp.dzT, bp.gT);
+    else
+      hipLaunchKernelGGL(mlp_bwd_data_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, dL_dd_xyz, dL_dd_rotation,
+                         dL_dd_scaling, N, (const uint32_t*)sv.gates, bp.dzT, bp.gT);
   }
   TRASE_POST_LAUNCH("mlp_bwd_data", stream, 0);
   const size_t img = (size_t)tiles * MW * 32;              // one layer's transposed image, elements
