@@ -1054,3 +1054,50 @@ def test_feature_norm_reg_matches_reference_golden_and_torch():
     assert abs(float(ra.detach()) - float(rb.detach())) < 1e-5 * float(ra.detach())
     assert float((a.grad - b.grad).abs().max()) < 1e-5 * float(a.grad.abs().max())
     assert float(b.grad[:, 5, 7].abs().max()) == 0.0
+
+
+def test_contrastive_head_degenerate_inputs():
+    """Degenerate inputs of the FEATURE-state head: no sampled pixel (the reference's losses return 0.0, the similarity
+    means are nan), a single sampled pixel (no pair: both losses 0, zero gradient), masks given as uint8 / float instead of
+    bool, a sampled pixel whose features are all zero (F.normalize's eps clamp: finite gradient), and more sampled masks
+    than the 256 membership bits or a channel count other than 32 (refused loudly)."""
+    from trase_amd.feature_head import contrastive_head, mask_stats
+    torch.manual_seed(1)
+    N, H, W = 6, 24, 40
+    sam = torch.rand(N, H, W, device="cuda") < 0.3
+    sm = torch.ones(N, dtype=torch.bool, device="cuda")
+    f = torch.randn(32, H, W, device="cuda", requires_grad=True)
+    none = torch.zeros(H, W, dtype=torch.bool, device="cuda")
+    lp, ln, ps, ns = contrastive_head(f, sam, none, sm)
+    assert float(lp.detach()) == 0.0 and float(ln.detach()) == 0.0 and bool(torch.isnan(ps)) and bool(torch.isnan(ns))
+    (lp + ln).backward()
+    assert float(f.grad.abs().max()) == 0.0
+    one = none.clone(); one[3, 5] = True
+    f.grad = None
+    lp, ln, ps, ns = contrastive_head(f, sam, one, sm)
+    (lp + ln).backward()
+    assert float(lp.detach()) == 0.0 and float(ln.detach()) == 0.0 and float(f.grad.abs().max()) == 0.0
+    # dtype of the masks does not matter
+    sp = torch.rand(H, W, device="cuda") < 0.2
+    a = contrastive_head(f.detach(), sam, sp, sm)
+    b = contrastive_head(f.detach(), sam.to(torch.uint8) * 255, sp, sm)
+    c = contrastive_head(f.detach(), sam.float(), sp, sm.float())
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w)
+    cover, size = mask_stats(sam.to(torch.uint8) * 7)
+    assert torch.equal(cover.long(), sam.sum(0)) and torch.equal(size.long(), sam.sum((-1, -2)))
+    # an all-zero feature column: finite losses and gradient
+    fz = f.detach().clone()
+    ys, xs = torch.nonzero(sp)[0].tolist()
+    fz[:, ys, xs] = 0.0
+    fz.requires_grad_(True)
+    lp, ln, _, _ = contrastive_head(fz, sam, sp, sm)
+    (lp + ln).backward()
+    assert bool(torch.isfinite(lp.detach())) and bool(torch.isfinite(fz.grad).all())
+    many = torch.rand(300, 8, 8, device="cuda") < 0.5
+    with pytest.raises(ValueError):
+        contrastive_head(torch.randn(32, 8, 8, device="cuda"), many, torch.ones(8, 8, dtype=torch.bool, device="cuda"),
+                         torch.ones(300, dtype=torch.bool, device="cuda"))
+    with pytest.raises(ValueError):
+        contrastive_head(torch.randn(16, 8, 8, device="cuda"), many[:4], torch.ones(8, 8, dtype=torch.bool, device="cuda"),
+                         torch.ones(4, dtype=torch.bool, device="cuda"))
