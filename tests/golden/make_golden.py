@@ -10,6 +10,7 @@ Fixtures:
   G3 camera.npz         utils/graphics_utils.py:45-77 getWorld2View2/getProjectionMatrix + scene/cameras.py:76-79
   G4 deform_mlp.npz     utils/time_utils.py:60-131 DeformNetwork forward/backward, fixed state_dict
      deform_mlp_blender.npz   the same for is_blender=True (t_multires 6 + timenet)
+     deform_mlp_6dof.npz      forward of is_6dof=True (screw-axis heads + exp_se3)
   G5 losses.npz         utils/loss_utils.py:30-86 l1_loss, ssim
   G6 contrastive.npz    utils/loss_utils.py:275-406 pixel-pair losses, modes soft / all / hard
   G8 feature_head.npz   train.py:251-296 FEATURE-state head: utils/feature_utils.py:17-57 (sampler, C, C_F, weights) +
@@ -150,6 +151,14 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deform_mlp_blender.npz"), x=x.numpy(), t=tb.numpy(), d_xyz=bx.detach().numpy(),
                         d_rotation=br.detach().numpy(), d_scaling=bs.detach().numpy(), gx=gx.numpy(), gr=gr.numpy(),
                         gs=gs.numpy(), **{"w_" + k: v for k, v in sdb.items()}, **gradsb)
+    # ---- G4c: is_6dof (screw-axis heads + exp_se3, utils/time_utils.py:100-118, utils/rigid_utils.py:43-86); outputs only
+    torch.manual_seed(12)
+    net6 = DeformNetwork(D=8, W=256, multires=10, is_blender=False, is_6dof=True)
+    with torch.no_grad():
+        sx, sr, ss = net6(x, t)
+    np.savez_compressed(os.path.join(HERE, "deform_mlp_6dof.npz"), x=x.numpy(), t=t.numpy(), d_xyz=sx.numpy(),
+                        d_rotation=sr.numpy(), d_scaling=ss.numpy(),
+                        **{"w_" + k: v.detach().numpy() for k, v in net6.state_dict().items()})
     torch.set_rng_state(rng_state)
 
     # ---- G5

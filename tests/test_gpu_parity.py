@@ -742,6 +742,68 @@ def test_deform_mlp_blender_variant_matches_reference_golden_and_bf16_autograd()
         DeformNetworkHIP(net)(xx[:8], torch.rand(8, 1, device="cuda"))
 
 
+def test_deform_mlp_6dof_variant_matches_reference_golden_and_autograd():
+    """is_6dof DeformNetwork (screw-axis heads branch_w / branch_v + exp_se3, utils/time_utils.py:100-118,
+    utils/rigid_utils.py:43-86): (a) the (N, 4, 4) transforms, rotation and scaling against golden vectors from the
+    imported reference, 2e-2 of the output scale (bf16 network); (b) gradients of every parameter -- the two network
+    passes' contributions added by autograd -- against PyTorch autograd of the bf16-evaluated network, 5e-2; (c) render()
+    accepts the transforms (is_6dof path, gaussian_renderer/__init__.py:76-81)."""
+    import os
+    from trase_amd.deform import deform_forward, DeformNetworkHIP
+    from trase_amd.synthetic import SynthDeformNetwork
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "deform_mlp_6dof.npz"))
+    params = {k[2:]: torch.from_numpy(d[k]).cuda() for k in d.files if k.startswith("w_")}
+    assert "branch_w.weight" in params and "gaussian_warp.weight" not in params
+    x, t = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["t"]).cuda()
+    with torch.no_grad():
+        out = deform_forward(params, x, t, is_6dof=True)
+    assert out[0].shape == (x.shape[0], 4, 4)
+    for name, got in zip(("d_xyz", "d_rotation", "d_scaling"), out):
+        want = d[name]
+        assert np.abs(got.cpu().numpy() - want).max() < 2e-2 * np.abs(want).max() + 1e-4, name
+    torch.manual_seed(7)
+    net = SynthDeformNetwork(is_6dof=True).cuda()
+    n = 5003
+    xx = (torch.rand(n, 3, device="cuda") * 2 - 1) * 1.3
+    tt = torch.tensor([[0.3]], device="cuda").expand(n, -1)
+    wT, wr, ws = torch.randn(n, 4, 4, device="cuda"), torch.randn(n, 4, device="cuda"), torch.randn(n, 3, device="cuda")
+
+    def bf16_eval():
+        import torch.nn.functional as Fn
+        from trase_amd.deform import exp_se3
+        rb = lambda v: v + (v.to(torch.bfloat16).float() - v).detach()
+        e = rb(torch.cat([net.embed(xx, 10), net.embed(tt.contiguous(), 10)], -1))
+        h = e
+        for i, l in enumerate(net.linear):
+            h = rb(torch.relu(Fn.linear(h, rb(l.weight)) + l.bias))
+            if i == 4:
+                h = torch.cat([e, h], -1)
+        head = lambda m: Fn.linear(h, rb(m.weight)) + m.bias
+        w, v = head(net.branch_w), head(net.branch_v)
+        th = torch.norm(w, dim=-1, keepdim=True)
+        return exp_se3(torch.cat([w / th + 1e-5, v / th + 1e-5], -1), th), head(net.gaussian_rotation), head(net.gaussian_scaling)
+    a = bf16_eval()
+    sum((u * w).sum() for u, w in zip(a, (wT, wr, ws))).backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad()
+    b = DeformNetworkHIP(net)(xx, tt)
+    for u, v in zip(a, b):
+        assert float((u - v).detach().abs().max()) < 5e-3 * float(u.detach().abs().max()) + 1e-5
+    sum((u * w).sum() for u, w in zip(b, (wT, wr, ws))).backward()
+    for k, p in net.named_parameters():
+        rel = float((p.grad - want[k]).norm() / want[k].norm())
+        assert rel < 5e-2, f"grad {k}: rel L2 {rel:.3e}"
+    # (c) through render()
+    from gaussian_renderer import render
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    pc = SynthGaussianModel(make_scene(n, feat_dim=32, seed=3, scale_mult=0.8).to("cuda"))
+    with torch.no_grad():
+        T, dr, ds = DeformNetworkHIP(net)(pc.get_xyz.detach(), tt)
+    outr = render(orbit_camera(96, 64, angle=0.4).to("cuda"), pc, SynthPipe(), torch.zeros(3, device="cuda"), T, dr * 0.0, ds * 0.0,
+                  is_6dof=True)
+    assert torch.isfinite(outr["render"]).all()
+
+
 @pytest.mark.parametrize("with_deform", [False, True])
 def test_fused_render_matches_unfused_composition(with_deform):
     """gaussian_renderer.render() drop-in (A1 prep fused into the HIP kernels) vs the reference's own

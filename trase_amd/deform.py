@@ -31,6 +31,11 @@ from .rasterizer import _bytes, _stream
 PARAM_KEYS = tuple(k for i in range(8) for k in (f"linear.{i}.weight", f"linear.{i}.bias")) + (
     "gaussian_warp.weight", "gaussian_warp.bias", "gaussian_rotation.weight", "gaussian_rotation.bias",
     "gaussian_scaling.weight", "gaussian_scaling.bias")
+_HIDDEN_KEYS = tuple(k for i in range(8) for k in (f"linear.{i}.weight", f"linear.{i}.bias"))
+_TAIL_KEYS = ("gaussian_rotation.weight", "gaussian_rotation.bias", "gaussian_scaling.weight", "gaussian_scaling.bias")
+# is_6dof (utils/time_utils.py:100-102, :111-118): the translation head is replaced by two 3-vector heads
+KEYS_6DOF_W = _HIDDEN_KEYS + ("branch_w.weight", "branch_w.bias") + _TAIL_KEYS
+KEYS_6DOF_V = _HIDDEN_KEYS + ("branch_v.weight", "branch_v.bias") + _TAIL_KEYS
 TIMENET_KEYS = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias")   # is_blender only
 
 
@@ -161,12 +166,46 @@ class _DeformMLP(torch.autograd.Function):
         return (None, g_t, None, *[o if nd else None for o, nd in zip(out, real)])
 
 
+def _skew(w):
+    """utils/rigid_utils.py:6-23."""
+    z = torch.zeros_like(w[:, 0])
+    return torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], dim=-1).reshape(-1, 3, 3)
+
+
+def exp_se3(S: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """Screw axis (N, 6) and magnitude (N, 1) -> homogeneous transforms (N, 4, 4); utils/rigid_utils.py:43-86
+    (Rodrigues' formula, Modern Robotics 3.51 / 3.88), same operation order."""
+    w, v = S[:, :3], S[:, 3:]
+    W = _skew(w)
+    eye = torch.eye(3, device=S.device, dtype=S.dtype).unsqueeze(0).expand(W.shape[0], -1, -1)
+    W2 = torch.bmm(W, W)
+    th = theta.reshape(-1, 1, 1)
+    R = eye + torch.sin(th) * W + (1.0 - torch.cos(th)) * W2
+    p = torch.bmm(th * eye + (1.0 - torch.cos(th)) * W + (th - torch.sin(th)) * W2, v.unsqueeze(-1))
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=S.device, dtype=S.dtype).expand(R.shape[0], 1, 4)
+    return torch.cat([torch.cat([R, p], dim=-1), bottom], dim=1)
+
+
 def deform_forward(params: Mapping[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor,
                    is_blender: bool = False, is_6dof: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     if x.device.type != "cuda":
         raise RuntimeError("deform_forward runs on the GPU only (there is no CPU path)")
     if is_6dof:
-        raise NotImplementedError("trase_amd.deform: the is_6dof head (exp_se3, utils/time_utils.py:111-118) is not compiled in")
+        # utils/time_utils.py:111-118.  The fused kernels have one 3-vector head next to rotation and scaling, so the two
+        # screw-axis heads take two evaluations of the network (the second one's rotation / scaling outputs are unused and
+        # receive no cotangent); autograd adds the two passes' gradients of the shared layers.  Twice the cost of the
+        # default network -- is_6dof is an option of the reference (arguments: --is_6dof), off by default.
+        pw = {k2: params[k] for k, k2 in zip(KEYS_6DOF_W, PARAM_KEYS)}
+        pv = {k2: params[k] for k, k2 in zip(KEYS_6DOF_V, PARAM_KEYS)}
+        for k in TIMENET_KEYS:
+            if k in params:
+                pw[k] = pv[k] = params[k]
+        w, rotation, scaling = deform_forward(pw, x, t, is_blender, False)
+        v, _, _ = deform_forward(pv, x, t, is_blender, False)
+        theta = torch.norm(w, dim=-1, keepdim=True)
+        w = w / theta + 1e-5
+        v = v / theta + 1e-5
+        return exp_se3(torch.cat([w, v], dim=-1), theta), rotation, scaling
     tensors = [params[k] for k in PARAM_KEYS]
     n = x.shape[0]
     if torch.is_grad_enabled() and any(p.requires_grad for p in tensors + ([params[k] for k in TIMENET_KEYS] if is_blender else [])):

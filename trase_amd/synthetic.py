@@ -201,16 +201,20 @@ class SynthDeformNetwork(torch.nn.Module):
     output).  A parameter holder for benches and tests; its eager fp32 ``forward`` is the "what the reference
     runs" comparison leg, never the product path (that is ``trase_amd.deform.deform_forward``)."""
 
-    def __init__(self, is_blender: bool = False):
+    def __init__(self, is_blender: bool = False, is_6dof: bool = False):
         super().__init__()
-        self.is_blender, self.is_6dof = bool(is_blender), False
+        self.is_blender, self.is_6dof = bool(is_blender), bool(is_6dof)
         emb = 84
         if is_blender:                      # utils/time_utils.py:74-86: t_multires = 6, timenet 13 -> 256 -> 30
             emb = 93
             self.timenet = torch.nn.Sequential(torch.nn.Linear(13, 256), torch.nn.ReLU(inplace=True), torch.nn.Linear(256, 30))
         self.linear = torch.nn.ModuleList(
             [torch.nn.Linear(emb, 256)] + [torch.nn.Linear(emb + 256 if i == 4 else 256, 256) for i in range(7)])
-        self.gaussian_warp = torch.nn.Linear(256, 3)
+        if is_6dof:                         # utils/time_utils.py:100-102
+            self.branch_w = torch.nn.Linear(256, 3)
+            self.branch_v = torch.nn.Linear(256, 3)
+        else:
+            self.gaussian_warp = torch.nn.Linear(256, 3)
         self.gaussian_rotation = torch.nn.Linear(256, 4)
         self.gaussian_scaling = torch.nn.Linear(256, 3)
 
@@ -231,4 +235,11 @@ class SynthDeformNetwork(torch.nn.Module):
             h = torch.relu(l(h))
             if i == 4:
                 h = torch.cat([e, h], -1)
-        return self.gaussian_warp(h), self.gaussian_rotation(h), self.gaussian_scaling(h)
+        if self.is_6dof:                    # utils/time_utils.py:111-118
+            from .deform import exp_se3
+            w, v = self.branch_w(h), self.branch_v(h)
+            theta = torch.norm(w, dim=-1, keepdim=True)
+            d_xyz = exp_se3(torch.cat([w / theta + 1e-5, v / theta + 1e-5], dim=-1), theta)
+        else:
+            d_xyz = self.gaussian_warp(h)
+        return d_xyz, self.gaussian_rotation(h), self.gaussian_scaling(h)
