@@ -204,7 +204,8 @@ int trase_knn_points(const float* p1, int32_t N1, const float* p2, int32_t N2, i
 /* Deformation MLP (utils/time_utils.py:60-131 DeformNetwork.forward, reached through
  * scene/deform_model.py:34-35 DeformModel.step at train.py:202-204, render.py:195, gui.py:965).
  * Weights are the reference's nn.Linear parameters as they are (fp32, [out][in] row-major, device
- * pointers); they are re-packed to bf16 on every call.  Forward only (no_grad call sites). */
+ * pointers); they are re-packed to bf16 on every call.  trase_mlp_forward serves the no_grad call sites; the training pair is
+ * declared further down. */
 typedef struct TraseMlpWeights {
   int32_t D;             /* hidden layers (8) */
   int32_t W;             /* hidden width (256) */
