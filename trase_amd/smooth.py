@@ -10,8 +10,6 @@ materialises ``normed[idx[:, sel], 0, :]`` (N x S x 32) and back-propagates thro
 over a reverse adjacency that is built once per KNN map and cached next to it."""
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import _lib
