@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference's PyTorch prep ops around GaussianRasterizer instead of the fused render()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket", choices=["auto", "sink", "accumulate"], default="auto",
+                    help="gradient bucket of the N>1 exchange step; 'sink' / 'accumulate' force it on at N=1 (for timing the "
+                         "bucket handling alone: the all-reduce is a no-op there)")
     ap.add_argument("--cpu-tile-step", type=int, default=37)
     ap.add_argument("--cpu-budget-s", type=float, default=6.0, help="forward wall-time budget of the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16)")
@@ -124,7 +127,12 @@ def main():
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
     # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
-    bucket = FlatGradBucket(params) if world > 1 else None
+    bucket = FlatGradBucket(params) if (world > 1 or args.bucket != "auto") else None
+    use_sink = bucket is not None and not args.unfused and args.bucket != "accumulate"
+    if use_sink:
+        # the fused backward writes every gradient once, straight into the bucket: no zero-fill, no accumulation pass
+        from trase_amd.renderer import set_grad_sink
+        set_grad_sink(bucket.sink())
 
     n_views = 16
     cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
@@ -136,11 +144,11 @@ def main():
     g_feat = torch.randn(F, H, W, generator=g).to(device) / P
 
     def step(i):
-        if bucket is not None:
-            bucket.zero()
+        if bucket is not None and not use_sink:
+            bucket.zero()                 # autograd accumulates into the bucket views
         else:
             for p_ in params:
-                p_.grad = None
+                p_.grad = None            # autograd adopts the gradients (N > 1: views into the bucket, see above)
         if not args.unfused:
             # render() drop-in: the A1 prep (activations, SH concat, feature normalisation) is fused into the
             # per-Gaussian HIP kernels

@@ -1163,3 +1163,43 @@ def test_contrastive_head_degenerate_inputs():
     with pytest.raises(ValueError):
         contrastive_head(torch.randn(16, 8, 8, device="cuda"), many[:4], torch.ones(8, 8, dtype=torch.bool, device="cuda"),
                          torch.ones(4, dtype=torch.bool, device="cuda"))
+
+
+def test_grad_sink_writes_gradients_straight_into_the_allreduce_bucket():
+    """View-parallel DP: with ``set_grad_sink(bucket.sink())`` the fused backward writes every parameter gradient once,
+    in place, into the flat all-reduce bucket (autograd adopts the views as .grad: no zero-fill, no accumulation pass).
+    Same values as the ordinary path, .grad storage inside the bucket, bucket == concatenation of the gradients."""
+    from gaussian_renderer import render
+    from trase_amd.dp import FlatGradBucket
+    from trase_amd.renderer import set_grad_sink
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    dev = _dev()
+    pc = SynthGaussianModel(make_scene(4000, feat_dim=32, seed=9, scale_mult=0.8).to(dev))
+    cam = orbit_camera(160, 96, angle=0.7).to(dev)
+    bg = torch.zeros(3, device=dev)
+    gi, gf = torch.randn(3, 96, 160, device=dev), torch.randn(32, 96, 160, device=dev)
+    params = pc.parameters()
+
+    def run():
+        out = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0)
+        torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])
+    for p in params:
+        p.grad = None
+    run()
+    want = [p.grad.clone() for p in params]
+    bucket = FlatGradBucket(params)
+    bucket.flat.fill_(float("nan"))                      # nothing may rely on a zero-filled bucket
+    try:
+        set_grad_sink(bucket.sink())
+        for rep in range(2):
+            bucket.detach_grads()
+            run()
+            assert bucket.adopted()
+            for p, w in zip(params, want):
+                assert torch.equal(p.grad, w)
+            assert torch.equal(bucket.flat, torch.cat([w.reshape(-1) for w in want]))
+    finally:
+        set_grad_sink(None)
+    bucket.detach_grads()
+    run()
+    assert not bucket.adopted()

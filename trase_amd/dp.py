@@ -25,6 +25,26 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def sink(self):
+        """{param.data_ptr(): view of its slice} for ``trase_amd.renderer.set_grad_sink``: the fused backward writes
+        each gradient once, straight into the bucket.  Use with ``detach_grads()`` before every backward (autograd adopts a
+        gradient without copying only when ``.grad`` is None); parameters that receive no gradient in a step keep stale
+        bucket contents -- ``zero()`` first if that can happen."""
+        out, off = {}, 0
+        for p in self.params:
+            out[p.data_ptr()] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        return out
+
+    def detach_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def adopted(self) -> bool:
+        """True when every parameter's ``.grad`` lives inside the bucket (the sink path was taken)."""
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * self.flat.element_size()
+        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
+
     def allreduce(self, average: bool = False):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -20,6 +20,18 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Pol
                          _stream)
 
 
+_GRAD_SINK: dict = {}
+
+
+def set_grad_sink(sink=None) -> None:
+    """``sink``: {parameter.data_ptr(): preallocated gradient buffer of the parameter's shape} or None.  The fused
+    backward then writes the gradients of those parameters directly into the given buffers (and autograd adopts them as
+    ``.grad`` when ``.grad`` is None) instead of allocating fresh tensors -- used by ``trase_amd.dp.FlatGradBucket`` so
+    that the view-parallel all-reduce bucket is filled without a zero-fill and an accumulation pass."""
+    global _GRAD_SINK
+    _GRAD_SINK = dict(sink) if sink else {}
+
+
 class _RenderRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat, means2D,
@@ -125,16 +137,24 @@ class _RenderRaw(torch.autograd.Function):
         ws.capacity = ctx.capacity
         need = ctx.needs_input_grad   # xyz0 d_xyz1 f_dc2 f_rest3 opacity4 scaling5 d_scaling6 rotation7 d_rotation8 gfeat9 means2D10
 
-        def alloc(flag, like):
-            return torch.empty_like(like) if flag else None
+        def alloc(flag, like, sink=True):
+            if not flag:
+                return None
+            buf = _GRAD_SINK.get(like.data_ptr()) if (_GRAD_SINK and sink) else None
+            if buf is not None and buf.shape == like.shape and buf.device == like.device:
+                # a FRESH view object: autograd's AccumulateGrad then adopts it as .grad without a copy (it clones a
+                # gradient that somebody else still references), so the gradient is written once, in place, into the
+                # caller's buffer (trase_amd.dp.FlatGradBucket: the all-reduce bucket)
+                return buf.view(buf.shape)
+            return torch.empty_like(like)
 
-        g_xyz = torch.empty(P, 3, device=device)
-        g_dxyz = alloc(need[1] and has_dxyz, xyz)
+        g_xyz = alloc(True, xyz)
+        g_dxyz = alloc(need[1] and has_dxyz, xyz, sink=False)      # the deformation offsets are not bucket parameters
         g_m2d = torch.empty(P, 3, device=device)
         g_dc, g_rest = alloc(need[2], f_dc), alloc(need[3], f_rest)
         g_op, g_sc, g_rot = alloc(need[4], opacity), alloc(need[5], scaling), alloc(need[6 + 1], rotation)
-        g_dsc = alloc(need[6] and has_dscale, scaling)
-        g_drot = alloc(need[8] and has_drot, rotation)
+        g_dsc = alloc(need[6] and has_dscale, scaling, sink=False)
+        g_drot = alloc(need[8] and has_drot, rotation, sink=False)
         g_feat = alloc(need[9] and has_feat and F > 0, gfeat) if has_feat else None
         g = _lib.RastRawGrads()
         g.dL_dimage = _lib.ptr(_prep(grad_image, "grad_image", device))
