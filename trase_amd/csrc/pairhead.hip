@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restri
     }
     w = (w | (w >> 1) | (w >> 2) | (w >> 3) | (w >> 4) | (w >> 5) | (w >> 6) | (w >> 7)) & 0x01010101u;   // any non-zero byte -> 1
     c0 += w & 1u; c1 += (w >> 8) & 1u; c2 += (w >> 16) & 1u; c3 += w >> 24;
-    uint32_t cnt = __popc(w);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor((int)cnt, o);
+    // wave total of the four byte flags: four ballots + scalar popcounts instead of a six-step shuffle reduction
+    const uint32_t cnt = (uint32_t)(__popcll(__ballot(w & 1u)) + __popcll(__ballot(w & 0x100u)) + __popcll(__ballot(w & 0x10000u)) +
+                                    __popcll(__ballot(w & 0x1000000u)));
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&lsize[n], cnt);
   }
   if (p0 < HW) cover[p0] = (int32_t)c0;
