@@ -1203,3 +1203,38 @@ def test_grad_sink_writes_gradients_straight_into_the_allreduce_bucket():
     bucket.detach_grads()
     run()
     assert not bucket.adopted()
+
+
+def test_feature_only_backward_scope():
+    """``set_backward_scope("features")`` (FEATURE state after densification): the gradient of the Gaussian features is
+    bit-identical to the full backward's, every other gradient is zero; the default scope is restored afterwards."""
+    from gaussian_renderer import render
+    from trase_amd.renderer import set_backward_scope
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    dev = _dev()
+    pc = SynthGaussianModel(make_scene(6000, feat_dim=32, seed=5, scale_mult=0.8).to(dev))
+    cam = orbit_camera(192, 128, angle=1.1).to(dev)
+    bg = torch.zeros(3, device=dev)
+    gf = torch.randn(32, 128, 192, device=dev)
+    params = pc.parameters()
+
+    def run():
+        for p in params:
+            p.grad = None
+        out = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0, norm_gaussian_features=True)
+        out["render_gaussian_features"].backward(gf)
+        return [p.grad.clone() for p in params], out["viewspace_points"].grad.clone()
+    full, vp_full = run()
+    try:
+        set_backward_scope("features")
+        only, vp_only = run()
+    finally:
+        set_backward_scope("all")
+    again, _ = run()
+    for p, a, b, c in zip(params, full, only, again):
+        assert torch.equal(a, c)
+        if p is pc._gaussian_features:
+            assert torch.equal(a, b) and float(a.abs().max()) > 0
+        else:
+            assert float(b.abs().max()) == 0.0
+    assert float(vp_only.abs().max()) == 0.0 and float(vp_full.abs().max()) > 0

@@ -96,6 +96,10 @@ __device__ __forceinline__ bf16x8 gather_column(const __bf16* __restrict__ col) 
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// FEAT_ONLY: only dL/d(feature channels of the Gaussians) is produced (FEATURE state once densification has ended: nothing
+// else requires a gradient then, train.py:244-299 with scene/gaussian_model.py:303-315).  GEMM 1, the dL/dalpha scan and the
+// moments disappear; the weights alpha * T and GEMM 2 remain.  The rows keep their format with a zero tail.
+template <bool FEAT_ONLY>
 __global__ __launch_bounds__(MF_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void render_bwd_mf_kernel(BwdMfArgs a) {
   constexpr int F = 32, ROW = F + 12;
@@ -214,7 +218,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
     // pixel rows unrolled inside so that every register array index below is a compile-time constant
 #pragma unroll 1
     for (int mb = 0; mb < 2; ++mb) {
-      gemm1(mb);
+      if constexpr (!FEAT_ONLY) gemm1(mb);
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
       const int i = mb * 4 + ii;
@@ -248,6 +252,9 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           wave_scan_mul2_asm(Pa, Pb);
           const float Ta = pa.x * Pa, Tb = pb.x * Pb;     // transmittance in front of this Gaussian
           wa = ala * Ta; wb = alb * Tb;
+          if constexpr (FEAT_ONLY) {
+            if (lane == WAVE - 1) { s_pix[wave][p].x = Ta; s_pix[wave][p + 1].x = Tb; }   // carries for the next (nearer) chunk
+          } else {
           const float sa = (j < 4 ? Sx : Sy)[4 * ii + (j & 3)];
           const float sb = (j < 4 ? Sx : Sy)[4 * ii + ((j + 1) & 3)];
           const float wsa = wa * sa, wsb = wb * sb;
@@ -263,6 +270,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           R0 += qa + qb;
           R1 = fmaf(qb, (float)(j + 1), fmaf(qa, (float)j, R1));
           R2 = fmaf(qb, (float)((j + 1) * (j + 1)), fmaf(qa, (float)(j * j), R2));
+          }
         }
         {                                                // split the two weights, packed: w = hi + lo
           unsigned hb, lb;
@@ -292,13 +300,14 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
           Al[0] = __builtin_bit_cast(bf16x8, l0); Al[1] = __builtin_bit_cast(bf16x8, l1);
         }
         const int rowoff = ((i >> 1) * 16 + 8 * h) * MF_LD;    // first pixel row of this lane half in the K-step
+        constexpr int NBLK = FEAT_ONLY ? 1 : 2;            // channel block 1 = r g b depth
         bf16x8 Bh[2], Bl[2];
         Bh[0] = gather_column(ahi + rowoff + col0); Bl[0] = gather_column(alo + rowoff + col0);
-        Bh[1] = gather_column(ahi + rowoff + col1); Bl[1] = gather_column(alo + rowoff + col1);
+        if constexpr (!FEAT_ONLY) { Bh[1] = gather_column(ahi + rowoff + col1); Bl[1] = gather_column(alo + rowoff + col1); }
 #pragma unroll
         for (int gb = 0; gb < 2; ++gb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
+          for (int nb = 0; nb < NBLK; ++nb) {
             // rows = channels (cot^T fragment), columns = Gaussians (weight fragment): the result has lane = Gaussian
             D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bh[nb], Ah[gb], D[gb][nb], 0, 0, 0);
             D[gb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bl[nb], Ah[gb], D[gb][nb], 0, 0, 0);
@@ -368,7 +377,9 @@ int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   TRASE_POST_LAUNCH("split_channels", c.stream, c.debug);
   {
     ProfScope ps("render_bwd", c.stream);
-    hipLaunchKernelGGL(render_bwd_mf_kernel, dim3((a.ntiles + MF_WPB - 1) / MF_WPB), dim3(MF_WPB * WAVE), 0, c.stream, a);
+    const dim3 grid((a.ntiles + MF_WPB - 1) / MF_WPB), block(MF_WPB * WAVE);
+    if (c.variant & 0x400) hipLaunchKernelGGL(render_bwd_mf_kernel<true>, grid, block, 0, c.stream, a);   // feature gradients only
+    else hipLaunchKernelGGL(render_bwd_mf_kernel<false>, grid, block, 0, c.stream, a);
   }
   TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);
   return TRASE_OK;

@@ -20,6 +20,21 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Pol
                          _stream)
 
 
+def set_backward_scope(scope: str = "all") -> None:
+    """``"features"``: the backward produces only dL/d(gaussian features) -- everything else (positions, covariances,
+    opacities, colours, and the screen-space gradient the densifier reads) comes back as zeros.  For FEATURE-state
+    iterations once densification has ended (``iteration >= opt.densify_until_iter``): no other parameter requires a
+    gradient then (scene/gaussian_model.py:303-315) and ``viewspace_point_tensor.grad`` is no longer read
+    (train.py:361-366).  The blend-weight part of the backward (transmittance scan + the weights x cotangent GEMM) stays;
+    the channel contraction for dL/dalpha, its scan and the moment sums are skipped.  ``"all"`` (default) restores the
+    reference's behaviour."""
+    from . import rasterizer as _r
+    if scope not in ("all", "features"):
+        raise ValueError("scope must be 'all' or 'features'")
+    v = _r._Policy.variant & ~0x400
+    _r.set_variant(v | (0x400 if scope == "features" else 0))
+
+
 _GRAD_SINK: dict = {}
 
 
