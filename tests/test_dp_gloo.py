@@ -44,3 +44,55 @@ def test_flat_bucket_allreduce_equals_sum_of_view_grads():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+class _WritesIntoSink(torch.autograd.Function):
+    """Stands in for the fused render backward: returns gradients that are fresh views of caller-provided buffers."""
+
+    @staticmethod
+    def forward(ctx, sink, *params):
+        ctx.sink = sink
+        ctx.save_for_backward(*params)
+        return sum((p * p).sum() for p in params)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs = []
+        for p in ctx.saved_tensors:
+            buf = ctx.sink[p.data_ptr()]
+            buf.copy_(2 * p * g)                 # "the kernel writes the gradient once, in place"
+            outs.append(buf.view(buf.shape))     # a fresh view object: AccumulateGrad adopts it without a copy
+        return (None, *outs)
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket
+    torch.manual_seed(0)
+    params = [torch.randn(40, 3, requires_grad=True), torch.randn(40, 1, 32, requires_grad=True)]
+    bucket = FlatGradBucket(params)
+    bucket.flat.fill_(float("nan"))               # the sink path must not rely on a zero-filled bucket
+    sink = bucket.sink()
+    ok = True
+    for step in range(2):
+        bucket.detach_grads()
+        (_WritesIntoSink.apply(sink, *params) * float(rank + 1)).backward()
+        ok = ok and bucket.adopted()
+        bucket.allreduce()
+        want = [2 * p.detach() * sum(range(1, world + 1)) for p in params]
+        ok = ok and all(torch.allclose(p.grad, w) for p, w in zip(params, want))
+        ok = ok and torch.allclose(bucket.flat, torch.cat([w.reshape(-1) for w in want]))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_grad_sink_bucket_is_adopted_and_reduced_in_place():
+    """The N>1 exchange with the gradient sink (trase_amd.renderer.set_grad_sink / FlatGradBucket.sink): gradients written
+    straight into the bucket are adopted as .grad without a copy, and the single all-reduce acts on them in place."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sink_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
