@@ -137,6 +137,13 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
  * workspace (the reference's forward returns num_rendered the same way). */
 int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream);
 
+/* Byte offsets of the per-Gaussian arrays inside the geom workspace sized for P Gaussians (pure host
+ * arithmetic): off[0] header (64 u32: [0] lineage pair count, [1] overflow flag, [2] binned pair count),
+ * off[1] xy float2[P] (pixel centre), off[2] conic_opacity float4[P], off[3] rgb_depth float4[P] (.w = view-space
+ * depth, the blend-order key), off[4] tiles u32[P], off[5] clamp bits u32[P].  Introspection for parity tests and
+ * debugging -- the counterpart of reading the reference's geomBuffer; entries of culled Gaussians are undefined. */
+int trase_rast_geom_layout(int32_t P, int64_t off[6]);
+
 /* Stage 2: binning (tile lists in depth order) + alpha compositing. */
 int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                       const TraseRastWorkspace* ws, trase_stream_t stream);

@@ -56,6 +56,9 @@ class OracleOptions:
     # fragility margins (relative) used to flag pixels whose discrete decisions
     # may legitimately flip between float32 and float64 arithmetic
     frag_rel: float = 2e-5
+    # with the device's own float32 per-Gaussian state at hand (device_view incl. conic_opacity) only the device's
+    # *arithmetic* in the blend loop is unknown: exponent polynomial + exp2 in float32, ~2e-6 relative in alpha
+    frag_rel_arith: float = 5e-6
 
 
 def _f64(x):
@@ -232,12 +235,18 @@ def preprocess(settings, means3D, shs, colors_precomp, opacities, scales, rotati
                 frag_gauss=frag, cov3d=cov3d, ndc=ndc, frag_radius=frag_radius, frag_rect=frag_rect, r_real=rr)
 
 
-def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions):
+def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions, dev=None):
     """Appendix A 'Render fwd' for one tile.
 
     xy (G,2), conic (G,3), opac (G,), depth (G,), chans (G,Cc) already in blend
     order; pixx/pixy (P,) pixel coordinates.  Returns (out (P,Cc), T_final (P,),
-    n_contrib (P,), fragile (P,) bool)."""
+    n_contrib (P,), fragile (P,) bool, blended (G,P) bool).
+
+    dev: optional (xy_d (G,2), conic_d (G,3), opac_d (G,)) -- the DEVICE's float32 per-Gaussian state,
+    promoted to float64.  Used only for the fragility flags: a pixel is fragile when the same gates,
+    evaluated exactly on the device's rounded inputs, decide differently from the oracle's, or when the
+    device-input value lies within float32 *arithmetic* rounding of a threshold.  Without it the flags
+    fall back to a fixed relative margin around the oracle's own values."""
     G = xy.shape[0]
     P = pixx.shape[0]
     dx = xy[:, 0:1] - pixx[None, :]
@@ -264,12 +273,32 @@ def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions):
     # (before the pixel is done)
     rel = opt.frag_rel
     live_before = torch.cat([torch.ones(1, P, dtype=torch.bool), alive[:-1]], dim=0)
-    ad = alpha.detach()
-    f_alpha = (torch.abs(ad - opt.alpha_min) < 4 * rel * opt.alpha_min) & keep_p
-    f_pow = (torch.abs(power.detach()) < 1e-6) & (opac[:, None].detach() >= opt.alpha_min)
-    f_stop = (torch.abs(cp.detach() - opt.t_stop) < 8 * rel * opt.t_stop) & keep
-    f_clamp = torch.zeros_like(f_alpha)  # clamp at 0.99 is continuous in value; not fragile
-    fragile = ((f_alpha | f_pow | f_stop | f_clamp) & live_before).any(dim=0)
+    if dev is None:
+        ad = alpha.detach()
+        f_alpha = (torch.abs(ad - opt.alpha_min) < 4 * rel * opt.alpha_min) & keep_p
+        f_pow = (torch.abs(power.detach()) < 1e-6) & (opac[:, None].detach() >= opt.alpha_min)
+        f_stop = (torch.abs(cp.detach() - opt.t_stop) < 8 * rel * opt.t_stop) & keep
+        fragile = ((f_alpha | f_pow | f_stop) & live_before).any(dim=0)
+    else:
+        with torch.no_grad():
+            xy_d, conic_d, opac_d = dev
+            dxd = xy_d[:, 0:1] - pixx[None, :]
+            dyd = xy_d[:, 1:2] - pixy[None, :]
+            power_d = -0.5 * (conic_d[:, 0:1] * dxd * dxd + conic_d[:, 2:3] * dyd * dyd) - conic_d[:, 1:2] * dxd * dyd
+            keep_pd = power_d <= 0
+            alpha_d = torch.clamp_max(opac_d[:, None] * torch.exp(torch.where(keep_pd, power_d, torch.zeros_like(power_d))),
+                                      opt.alpha_max)
+            keep_d = keep_pd & (alpha_d >= opt.alpha_min)
+            cp_d = torch.cumprod(1.0 - torch.where(keep_d, alpha_d, torch.zeros_like(alpha_d)), dim=0)
+            alive_d = cp_d >= opt.t_stop
+            live_before_d = torch.cat([torch.ones(1, P, dtype=torch.bool), alive_d[:-1]], dim=0)
+            lb = live_before | live_before_d
+            m_a = opt.frag_rel_arith
+            f_alpha = (torch.abs(alpha_d - opt.alpha_min) < 4 * m_a * opt.alpha_min) & keep_pd
+            f_pow = (torch.abs(power_d) < 1e-6) & (opac_d[:, None] >= opt.alpha_min)
+            f_stop = (torch.abs(cp_d - opt.t_stop) < 8 * rel * opt.t_stop) & keep_d
+            flip = (keep != keep_d) | (alive != alive_d)
+            fragile = ((f_alpha | f_pow | f_stop | flip) & lb).any(dim=0)
     return out, T_final, n_contrib, fragile, (alive & keep)
 
 
@@ -286,13 +315,16 @@ class OracleOut:
     final_T: torch.Tensor    # (H,W)
     n_contrib: torch.Tensor  # (H,W)
     pairs_done: int = 0      # (tile,Gaussian) pairs actually composited (== num_rendered unless sampled)
+    tile_mask: torch.Tensor = None   # (H,W) bool: pixels of the tiles that were composited (all, unless sampled)
+    frag_stats: dict = None          # fragile-pixel counts by cause: gate / order / gauss
 
 
 def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_precomp=None,
               opacities=None, scales=None, rotations=None, cov3D_precomp=None,
               opt: OracleOptions = OracleOptions(), sort_depth: Optional[torch.Tensor] = None,
               radii_override: Optional[torch.Tensor] = None, tile_step: int = 1,
-              max_seconds: Optional[float] = None) -> OracleOut:
+              max_seconds: Optional[float] = None, device_view: Optional[dict] = None,
+              tiles: Optional[list] = None) -> OracleOut:
     """Full forward.  All float inputs are promoted to float64 (gradients flow
     back to the caller's leaves through the promotion).
 
@@ -304,7 +336,15 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     tile_step: render only every tile_step-th tile (bounded sample for bench.py's
     cpu_baseline timing); skipped tiles keep the background.
     max_seconds: stop compositing further tiles once this much wall time has been
-    spent in the tile loop (bounded sample); OracleOut.pairs_done says how far it got."""
+    spent in the tile loop (bounded sample); OracleOut.pairs_done says how far it got.
+    device_view: optional {"radii": (N,) int, "xy": (N,2) float32, "depth": (N,) float32[, "conic_opacity":
+    (N,4) float32]} -- the device's own per-Gaussian forward state.  Used ONLY to settle decisions that are legitimately
+    ambiguous between float32 and float64 evaluation: the blend order (float32 depth keys), and --
+    for Gaussians this oracle marks borderline -- the ceil() of the radius, the truncated tile-rect
+    edges and the near cull, each adopted only when it is one of the admissible neighbours of the
+    oracle's own value.  Every value that is compared (maps, gradients) is still the oracle's.
+    tiles: optional explicit list of (tx, ty) 16x16 tiles to composite (others keep the background);
+    OracleOut.tile_mask marks their pixels."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -322,6 +362,13 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
                    cov3D_precomp, means2D, opt)
     if radii_override is not None and bool(g.frag_radius.any()):
         g = _apply_radii_override(g, radii_override, W, H)
+    if device_view is not None:
+        g = _apply_device_view(g, device_view, W, H, opt)
+        if sort_depth is None:
+            dv_depth = device_view["depth"].detach().cpu().to(torch.float32)
+            dv_vis = device_view["radii"].detach().cpu() > 0
+            # culled-on-device Gaussians have no stored depth; they only matter if the oracle keeps them (then unresolved)
+            sort_depth = torch.where(dv_vis, dv_depth, g.depth.detach().to(torch.float32))
     bg = _f64(settings.bg).reshape(3)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     C = 3 + F + 1
@@ -330,6 +377,9 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     final_T = torch.ones(H, W, dtype=torch.float64)
     n_contrib = torch.zeros(H, W, dtype=torch.int64)
     fragile = torch.zeros(H, W, dtype=torch.bool)
+    tile_mask = torch.zeros(H, W, dtype=torch.bool)
+    tile_set = None if tiles is None else {(int(a), int(b)) for a, b in tiles}
+    frag_stats = {"gate": 0, "order": 0, "gauss": 0}
     opac = opacities.reshape(N)
     chans_all = torch.cat([g.rgb] + ([feats_in] if F else []) + [g.depth[:, None]], dim=-1)
     key = g.depth.detach() if sort_depth is None else sort_depth.to(torch.float64)
@@ -340,15 +390,29 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     t_loop = _time.perf_counter()
     pairs_done = 0
     stop = False
+    dev_state = None
+    if device_view is not None and device_view.get("conic_opacity") is not None:
+        # the device's float32 (centre, conic, opacity), promoted; Gaussians the device culled keep the oracle's values
+        dvis = (device_view["radii"].detach().cpu() > 0)[:, None]
+        co = device_view["conic_opacity"].detach().cpu().to(torch.float64)
+        dev_state = (torch.where(dvis, device_view["xy"].detach().cpu().to(torch.float64), g.xy.detach()),
+                     torch.where(dvis, co[:, :3], g.conic.detach()),
+                     torch.where(dvis[:, 0], co[:, 3], opac.detach()))
+    rows_needed = None if tile_set is None else {b for _, b in tile_set}
     for ty in range(gy):
         if stop:
             break
+        if rows_needed is not None and ty not in rows_needed:
+            continue
         in_row = vidx[(rect[vidx, 1] <= ty) & (rect[vidx, 3] > ty)]
         if in_row.numel() == 0:
             continue
         for tx in range(gx):
             if tile_step > 1 and (ty * gx + tx) % tile_step != 0:
                 continue
+            if tile_set is not None and (tx, ty) not in tile_set:
+                continue
+            tile_mask[ty * TILE:min(ty * TILE + TILE, H), tx * TILE:min(tx * TILE + TILE, W)] = True
             ids = in_row[(rect[in_row, 0] <= tx) & (rect[in_row, 2] > tx)]
             if ids.numel() == 0:
                 continue
@@ -364,8 +428,11 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
             ys, xs = torch.meshgrid(torch.arange(y_lo, y_hi), torch.arange(x_lo, x_hi), indexing="ij")
             pixx = xs.reshape(-1).to(torch.float64)
             pixy = ys.reshape(-1).to(torch.float64)
+            dev = None
+            if dev_state is not None:
+                dev = (dev_state[0][ids], dev_state[1][ids], dev_state[2][ids])
             o, Tf, nc, fr, contrib = blend_tile(g.xy[ids], g.conic[ids], opac[ids], g.depth[ids],
-                                       chans_all[ids], pixx, pixy, opt)
+                                       chans_all[ids], pixx, pixy, opt, dev=dev)
             hh, ww = y_hi - y_lo, x_hi - x_lo
             o = o.reshape(hh, ww, C)
             Tf2 = Tf.reshape(hh, ww)
@@ -374,16 +441,21 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
             final_T[y_lo:y_hi, x_lo:x_hi] = Tf2.detach()
             n_contrib[y_lo:y_hi, x_lo:x_hi] = nc.reshape(hh, ww)
             # depth-order fragility: near-equal float32 keys of neighbours in the list
+            frag_stats["gate"] += int(fr.sum())
             k = key[ids]
             if k.numel() > 1:
                 near = (k[1:] - k[:-1]).abs() < 4e-7 * k[1:].abs().clamp_min(1e-3)
                 if sort_depth is None and bool(near.any()):
                     # swapping two neighbours only changes pixels that blend both of them
+                    fr0 = fr
                     for j in torch.nonzero(near).reshape(-1).tolist():
                         fr = fr | (contrib[j] & contrib[j + 1])
+                    frag_stats["order"] += int((fr & ~fr0).sum())
             fragile[y_lo:y_hi, x_lo:x_hi] = fr.reshape(hh, ww)
-            # pixels touched by a fragile Gaussian inherit fragility
+            # a Gaussian whose membership of this tile is itself ambiguous (unresolved borderline rect / radius /
+            # near cull) makes the whole tile fragile -- with a device view these are adopted instead (see above)
             if bool(g.frag_gauss[ids].any()):
+                frag_stats["gauss"] += int((~fr).sum())
                 fragile[y_lo:y_hi, x_lo:x_hi] = True
     canvas = out
     if opt.feats_bg or opt.depth_normalised:
@@ -393,7 +465,9 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     depth = canvas[..., 3 + F:].permute(2, 0, 1)
     return OracleOut(image=img, radii=g.radii, feats=feats, depth=depth, fragile=fragile,
                      frag_gauss=g.frag_gauss, num_rendered=int(g.tiles_touched.sum()), geom=g,
-                     final_T=final_T, n_contrib=n_contrib, pairs_done=pairs_done)
+                     final_T=final_T, n_contrib=n_contrib, pairs_done=pairs_done,
+                     tile_mask=tile_mask if (tile_set is not None or tile_step > 1) else torch.ones(H, W, dtype=torch.bool),
+                     frag_stats=frag_stats)
 
 
 def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:
@@ -417,4 +491,65 @@ def _apply_radii_override(g: Geom, radii_override, W, H) -> Geom:
     g.radii = torch.where(take, radius, g.radii.to(torch.float64)).to(torch.int32)
     g.tiles_touched = torch.where(take, area, g.tiles_touched)
     g.frag_gauss = g.frag_rect | (g.frag_radius & ~take)
+    return g
+
+
+def _rect_f32(px, py, radius, gx, gy):
+    """The device's tile rect (trase_amd/csrc/gs_math.h tile_rect): float32 quotients, C truncation."""
+    import numpy as np
+    px, py, r = (np.asarray(v, dtype=np.float32) for v in (px, py, radius))
+    t = np.float32(TILE)
+    def edge(v, g):
+        return np.clip(np.trunc((v / t).astype(np.float32)).astype(np.int64), 0, g)
+    x0, y0 = edge(px - r, gx), edge(py - r, gy)
+    x1, y1 = edge(px + r + np.float32(TILE - 1), gx), edge(py + r + np.float32(TILE - 1), gy)
+    return torch.from_numpy(np.stack([x0, y0, x1, y1], -1))
+
+
+def _apply_device_view(g: Geom, dv: dict, W: int, H: int, opt: OracleOptions) -> Geom:
+    """Adopt the device's discrete preprocess decisions for the Gaussians this oracle marks borderline,
+    provided each adopted value is an admissible neighbour of the oracle's own (radius +-1, every rect
+    edge +-1, near cull only when |z - near| is inside the float32 error band).  The device's centre and
+    depth must agree with the oracle's to float32 accuracy for the adoption to be admissible."""
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    dr = dv["radii"].detach().cpu().to(torch.float64)
+    dxy = dv["xy"].detach().cpu().to(torch.float32)
+    ddepth = dv["depth"].detach().cpu().to(torch.float32)
+    dvis = dr > 0
+    cand = g.frag_gauss.clone()
+    if not bool(cand.any()):
+        return g
+    own_r = torch.ceil(g.r_real)
+    xy = g.xy.detach()
+    # (a) device keeps it: radius, centre and depth must be float32-close to ours
+    close = ((dxy.to(torch.float64) - xy).abs().amax(dim=1) < 2e-6 * max(W, H) + 1e-4) & \
+            ((ddepth.to(torch.float64) - g.depth.detach()).abs() < 1e-5 * g.depth.detach().abs().clamp_min(1.0))
+    rad_ok = ((dr - own_r).abs() <= 1.0)
+    drect = _rect_f32(dxy[:, 0].numpy(), dxy[:, 1].numpy(), dr.numpy(), gx, gy)
+    own_rect_r = []
+    pxd, pyd = xy[:, 0], xy[:, 1]
+    for lo_hi in (pxd - dr, pyd - dr, pxd + dr + (TILE - 1), pyd + dr + (TILE - 1)):
+        own_rect_r.append(torch.trunc(lo_hi / TILE))
+    own_rect = torch.stack([own_rect_r[0].clamp(0, gx), own_rect_r[1].clamp(0, gy),
+                            own_rect_r[2].clamp(0, gx), own_rect_r[3].clamp(0, gy)], -1).to(torch.int64)
+    rect_ok = ((drect - own_rect).abs() <= 1).all(dim=1)
+    area = (drect[:, 2] - drect[:, 0]) * (drect[:, 3] - drect[:, 1])
+    take_vis = cand & dvis & close & rad_ok & rect_ok & (area > 0) & (g.depth.detach() > opt.near_cull_z)
+    # (b) device culls it: admissible when our own decision is borderline for a reason that can cull
+    #     (near plane, or a rect that may be empty with the neighbouring radius / edge)
+    own_area_min = torch.ones_like(area)
+    for k in range(2):
+        lo = torch.minimum(g.rect[:, k], g.rect[:, k] + 1)
+        hi = torch.maximum(g.rect[:, k + 2] - 1, lo)
+        own_area_min = own_area_min * (hi - lo).clamp_min(0)
+    near_band = (g.depth.detach() - opt.near_cull_z).abs() < 1e-6
+    take_cull = cand & ~dvis & (near_band | (own_area_min == 0))
+    radius = torch.where(take_vis, dr, g.radii.to(torch.float64))
+    g.rect = torch.where(take_vis[:, None], drect, g.rect)
+    g.rect = torch.where(take_cull[:, None], torch.zeros_like(g.rect), g.rect)
+    g.valid = (g.valid | take_vis) & ~take_cull
+    g.radii = torch.where(g.valid, radius, torch.zeros_like(radius)).to(torch.int32)
+    new_area = (g.rect[:, 2] - g.rect[:, 0]) * (g.rect[:, 3] - g.rect[:, 1])
+    g.tiles_touched = torch.where(g.valid, new_area, torch.zeros_like(new_area))
+    g.frag_gauss = cand & ~(take_vis | take_cull)
     return g

@@ -41,10 +41,28 @@ def _gpu_call(act, st_cpu, colors=None, cov=None, need_grad=True):
     out = rast(means3D=leaves["means3D"], means2D=means2D, shs=leaves.get("shs"), sh_objs=leaves.get("sh_objs"),
                colors_precomp=leaves.get("colors_precomp"), opacities=leaves["opacities"], scales=leaves.get("scales"),
                rotations=leaves.get("rotations"), cov3D_precomp=leaves.get("cov3D_precomp"))
+    global _LAST_DEVICE_VIEW
+    _LAST_DEVICE_VIEW = device_view_of_last_forward(out[1])
     return out, leaves
 
 
-def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None):
+_LAST_DEVICE_VIEW = None
+
+
+def device_view_of_last_forward(radii):
+    """The device's own per-Gaussian forward state (radii, float32 centre and depth key) of the forward that just ran:
+    what the oracle may adopt for decisions that are ambiguous between float32 and float64 (oracle/raster_oracle.py
+    `device_view`).  Compared values never come from here."""
+    from trase_amd import rasterizer as R
+    n = radii.shape[0]
+    if n == 0:
+        return None
+    gv = R.last_geom_view(n)
+    return {"radii": radii.detach().cpu(), "xy": gv["xy"].cpu().clone(), "depth": gv["rgb_depth"][:, 3].cpu().clone(),
+            "conic_opacity": gv["conic_opacity"].cpu().clone()}
+
+
+def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None, tiles=None):
     leaves = {}
     for k in ("means3D", "opacities", "scales", "rotations", "shs", "sh_objs"):
         v = act.get(k)
@@ -61,36 +79,65 @@ def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None):
                        colors_precomp=leaves.get("colors_precomp"), opacities=leaves["opacities"],
                        scales=leaves.get("scales"), rotations=leaves.get("rotations"),
                        cov3D_precomp=leaves.get("cov3D_precomp"),
-                       radii_override=None if gpu is None else gpu[1].detach().cpu())
+                       device_view=None if gpu is None else _LAST_DEVICE_VIEW, tiles=tiles)
+    if gpu is not None and _LAST_DEVICE_VIEW is not None:
+        _check_device_view(out, _LAST_DEVICE_VIEW)
     return out, leaves
 
 
-def _check_maps(gpu_out, o, frag_budget=0.03):
+def _check_device_view(o, dv):
+    """The adopted device state must itself agree with the oracle to float32 accuracy (it is only allowed to settle
+    ties): centre within 2e-6 * image size + 1e-4 px, depth within 1e-5 relative, on every Gaussian both sides keep."""
+    both = (dv["radii"] > 0) & o.geom.valid
+    if not bool(both.any()):
+        return
+    W = float(o.image.shape[2] + o.image.shape[1])
+    dxy = (dv["xy"].double() - o.geom.xy.detach())[both].abs().max().item()
+    ddz = ((dv["depth"].double() - o.geom.depth.detach()).abs() / o.geom.depth.detach().abs().clamp_min(1.0))[both].max().item()
+    assert dxy < 2e-6 * W + 1e-4, f"device centres differ from the oracle by {dxy:.3e} px"
+    assert ddz < 1e-5, f"device depth keys differ from the oracle by {ddz:.3e} (relative)"
+    if dv.get("conic_opacity") is not None:
+        co = dv["conic_opacity"].double()
+        dco = ((co[:, :3] - o.geom.conic.detach()).abs() / o.geom.conic.detach().abs().amax(dim=1, keepdim=True).clamp_min(1e-12))[both]
+        assert dco.max().item() < 2e-3, f"device conics differ from the oracle by {dco.max().item():.3e} (relative to the largest entry)"
+
+
+FRAG_BUDGET = 0.01     # share of pixels that may be excluded as "a gate decision is within float32 rounding of its
+                       # threshold" (with the device view the typical figure is 0.1-0.4 %); never the whole-tile kind
+FRAG_MIN_PIXELS = 12   # tiny images: a handful of borderline pixels is not a percentage
+
+
+def _check_maps(gpu_out, o, frag_budget=FRAG_BUDGET):
+    """Maps at 1e-4 abs on every non-fragile pixel of the composited tiles (all tiles unless the oracle was sampled)."""
     image, radii, feats, depth = [t.detach().cpu() for t in gpu_out]
     okg = ~o.frag_gauss
+    assert int(o.frag_gauss.sum()) <= max(2, 1e-4 * okg.numel()), f"{int(o.frag_gauss.sum())} Gaussians left unresolved"
     assert torch.equal(radii[okg], o.radii[okg]), "radii mismatch on non-fragile Gaussians"
-    ok = ~o.fragile
-    assert ok.float().mean() > 1 - frag_budget, f"too many fragile pixels: {1 - ok.float().mean():.4f}"
+    region = o.tile_mask
+    n_frag, n_reg = int((o.fragile & region).sum()), int(region.sum())
+    assert n_frag <= max(frag_budget * n_reg, FRAG_MIN_PIXELS), f"too many fragile pixels: {n_frag} of {n_reg}"
+    ok = ~o.fragile & region
     for name, a, b in (("image", image, o.image), ("feats", feats, o.feats), ("depth", depth, o.depth)):
         assert a.shape == b.shape, (name, a.shape, b.shape)
-        if a.numel() == 0:
+        if a.numel() == 0 or not bool(ok.any()):
             continue
         err = (a.double() - b.detach()).abs()
         assert err[:, ok].max().item() < MAP_ATOL, f"{name}: max abs err {err[:, ok].max().item():.3e}"
         # even where a discrete gate may flip the damage is bounded by one alpha_min-sized contribution
         scale = max(1.0, b.detach().abs().max().item())
-        assert err.max().item() < 0.05 * scale, f"{name}: fragile-pixel error {err.max().item():.3e}"
+        assert err[:, region].max().item() < 0.05 * scale, f"{name}: fragile-pixel error {err[:, region].max().item():.3e}"
+    return n_frag, n_reg
 
 
 def _masked(cot, o):
     """Cotangents are zeroed at fragile pixels (on both sides), so that a legitimately flipped
     gate cannot leak into the per-Gaussian gradient sums that are compared."""
-    return cot * (~o.fragile).to(cot.dtype)[None]
+    return cot * (~o.fragile & o.tile_mask).to(cot.dtype)[None]
 
 
 def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5):
     keep = ~o.frag_gauss
-    assert keep.sum() > 0.9 * keep.numel(), "too many Gaussians excluded as fragile"
+    assert keep.sum() >= keep.numel() - max(2, 1e-4 * keep.numel()), "too many Gaussians excluded as fragile"
     for k in names:
         a, b = gl[k].grad, ol[k].grad
         assert a is not None, f"no gradient for {k}"

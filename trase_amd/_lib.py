@@ -110,6 +110,7 @@ SYMBOLS = [
     ("trase_rast_preprocess", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastInputs), C.POINTER(RastOutputs),
                                         C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_status", C.c_int, [C.POINTER(RastWorkspace), C.POINTER(C.c_int64 * 3), C.c_void_p]),
+    ("trase_rast_geom_layout", C.c_int, [C.c_int32, C.POINTER(C.c_int64 * 6)]),
     ("trase_rast_render", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastInputs), C.POINTER(RastOutputs),
                                     C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_forward", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastInputs), C.POINTER(RastOutputs),

@@ -198,6 +198,15 @@ int trase_rast_sizes(int32_t P, int32_t W, int32_t H, int32_t F, int64_t capacit
   return TRASE_OK;
 }
 
+int trase_rast_geom_layout(int32_t P, int64_t off[6]) {
+  if (P < 0 || !off) { set_error("trase_rast_geom_layout: bad arguments"); return TRASE_ERR_INVALID; }
+  const GeomBuf g = carve_geom(nullptr, P);
+  off[0] = (int64_t)((char*)g.hdr - (char*)nullptr); off[1] = (int64_t)((char*)g.xy - (char*)nullptr);
+  off[2] = (int64_t)((char*)g.conic_o - (char*)nullptr); off[3] = (int64_t)((char*)g.rgbd - (char*)nullptr);
+  off[4] = (int64_t)((char*)g.tiles - (char*)nullptr); off[5] = (int64_t)((char*)g.clamped - (char*)nullptr);
+  return TRASE_OK;
+}
+
 int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                           const TraseRastWorkspace* ws, trase_stream_t stream_) {
   int rc = validate(s, in);

@@ -75,6 +75,26 @@ def last_status():
     return int(st[0]), int(st[1]), int(st[2])
 
 
+def geom_view(geom: torch.Tensor, P: int) -> dict:
+    """Typed views of the per-Gaussian forward state inside a geom workspace (introspection for the parity tests;
+    the counterpart of inspecting the reference's geomBuffer): xy (P,2), conic_opacity (P,4), rgb_depth (P,4),
+    tiles (P,) int32.  Entries of culled Gaussians (radii == 0) are undefined."""
+    off = (C.c_int64 * 6)()
+    _lib.check(_lib.load().trase_rast_geom_layout(int(P), C.byref(off)), "trase_rast_geom_layout")
+
+    def sl(o, nbytes, dtype, *shape):
+        return geom[o:o + nbytes].view(dtype).reshape(*shape)
+    return {"xy": sl(off[1], 8 * P, torch.float32, P, 2), "conic_opacity": sl(off[2], 16 * P, torch.float32, P, 4),
+            "rgb_depth": sl(off[3], 16 * P, torch.float32, P, 4), "tiles": sl(off[4], 4 * P, torch.int32, P)}
+
+
+def last_geom_view(P: int) -> dict:
+    """geom_view of the most recent forward's geom workspace."""
+    if _Policy.last_geom is None:
+        raise RuntimeError("no forward has run yet")
+    return geom_view(_Policy.last_geom, P)
+
+
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

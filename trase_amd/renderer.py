@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import _lib
+from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _bytes, _fill_settings, _prep,
                          _stream)
@@ -254,8 +255,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
         shs = colors_precomp = None
         if override_color is None:
             if getattr(pipe, "convert_SHs_python", False):
-                raise NotImplementedError("convert_SHs_python: use the rasterizer's SH evaluation")
-            shs = pc.get_features
+                colors_precomp = sh_colors_python(pc, viewpoint_camera.camera_center)
+            else:
+                shs = pc.get_features
         else:
             colors_precomp = override_color
         sh_objs = pc.get_gaussian_features if not is_smooth_gaussian_features else \

@@ -188,6 +188,18 @@ class SynthGaussianModel:
     def get_gaussian_features(self):
         return self._gaussian_features
 
+    def get_covariance(self, scaling_modifier=1):
+        """Sigma = (R S)(R S)^T as six floats, R from the NORMALISED raw quaternion (scene/gaussian_model.py:37-41,
+        216-217 with utils/general_utils.py:108-156) -- what ``pipe.compute_cov3D_python`` feeds the rasterizer."""
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=-1)
+
 
 class SynthPipe:
     convert_SHs_python = False
