@@ -32,6 +32,8 @@ from trase_amd.rasterizer import GaussianRasterizationSettings, GaussianRasteriz
 from trase_amd.synthetic import make_scene, orbit_camera  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9               # peak engine clock
 C_RGB = 3
 
 
@@ -62,10 +64,33 @@ def settings_for(cam, device):
         sh_degree=3, campos=cam.camera_center.to(device), prefiltered=False, debug=False)
 
 
+def cpu_preprocess_baseline(scene_cpu, cam, budget_s):
+    """The CPU baseline BASELINE.json's north_star names: the reference's PyTorch-CPU preprocess (activations +
+    deformation add + feature normalisation, SH -> RGB via eval_sh, Sigma = RS(RS)^T, projection by
+    full_proj_transform; oracle/cpu_preprocess.py, pinned against the imported reference by
+    tests/test_cpu_preprocess.py), fp32, ALL Gaussians of the workload, every host core, repeated over whole views
+    until the time budget is spent -- no extrapolation."""
+    from oracle.cpu_preprocess import reference_cpu_preprocess
+    n = scene_cpu.xyz.shape[0]
+    z3, z4 = torch.zeros(n, 3), torch.zeros(n, 4)
+    args = (scene_cpu.xyz, scene_cpu.features_dc, scene_cpu.features_rest, scene_cpu.opacity, scene_cpu.scaling,
+            scene_cpu.rotation, scene_cpu.gaussian_features, z3, z4, z3, cam.full_proj_transform, cam.camera_center,
+            cam.image_width, cam.image_height)
+    with torch.no_grad():
+        reference_cpu_preprocess(*args)          # warm-up (thread pool, allocator)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            reference_cpu_preprocess(*args)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or reps >= 200:
+                break
+    return dt / reps, reps
+
+
 def cpu_baseline(scene_cpu, cam, feat, tile_step, budget_s):
-    """The oracle ("port") timed on the host cores on a bounded sample of the same workload:
-    full per-Gaussian preprocess + compositing fwd+bwd of every tile_step-th tile until the
-    forward time budget is spent; extrapolated by the (tile,Gaussian) pair count."""
+    """Secondary, clearly labelled sample: the float64 oracle (full per-Gaussian preprocess + compositing fwd+bwd of
+    every tile_step-th tile until the forward time budget is spent), extrapolated by the (tile,Gaussian) pair count."""
     from oracle import raster_oracle as ro
     st = settings_for(cam, "cpu")
     act = scene_cpu.activated()
@@ -97,9 +122,10 @@ def main():
     ap.add_argument("--bucket", choices=["auto", "sink", "accumulate"], default="auto",
                     help="gradient bucket of the N>1 exchange step; 'sink' / 'accumulate' force it on at N=1 (for timing the "
                          "bucket handling alone: the all-reduce is a no-op there)")
-    ap.add_argument("--cpu-tile-step", type=int, default=37)
-    ap.add_argument("--cpu-budget-s", type=float, default=6.0, help="forward wall-time budget of the CPU sample")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16)")
+    ap.add_argument("--cpu-tile-step", type=int, default=97)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="wall-time budget of the CPU preprocess baseline")
+    ap.add_argument("--cpu-oracle-budget-s", type=float, default=1.5, help="forward wall-time budget of the oracle sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core (os.cpu_count())")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
     args = ap.parse_args()
 
@@ -107,6 +133,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if world != args.gpus:
+        if "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+            sys.exit(f"bench.py: --gpus {args.gpus} but launched with WORLD_SIZE={world}; pass --nproc-per-node {args.gpus}")
+        if torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) are visible")
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves, exactly like the driver's launch line
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -227,13 +269,19 @@ def main():
         dom_ms = prof[dom]["ms"] if prof else float("nan")
         a_bytes = algorithmic_bytes(dom, N, r_used, P, F)
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        # per-launch PMC figures of the same command (profiles/run_pmc.sh -> profiles/pmc_per_launch.json):
+        # HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 note of MI355X_MICROARCH.md; VALU wave-instructions
+        traffic = valu_insts = mfma_insts = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                rec = json.load(open(tpath)).get(dom) or {}
+                traffic, valu_insts, mfma_insts = rec.get("hbm_bytes"), rec.get("valu_insts"), rec.get("mfma_insts")
             except Exception:
-                traffic = None
+                pass
+        # VALU fraction ("report HBM fraction AND VALU fraction"): a wave64 VALU instruction occupies its SIMD
+        # for 4 cycles; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+        valu_frac = None if valu_insts is None else valu_insts * 4.0 / (N_SIMD * dom_ms * 1e-3 * CLOCK_HZ)
         out = {
             # BASELINE.json's metric names the S4 configuration; other sizes (parity-test configurations) say so
             "metric": "views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
@@ -250,22 +298,35 @@ def main():
                                 else "gaussian_renderer.render() drop-in, A1 prep fused"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "valu_frac": None if valu_frac is None else round(valu_frac, 4), "valu_insts": valu_insts,
+                         "mfma_insts": mfma_insts,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
                          "view_frac": round(view_bytes(N, r_used, P, F) * views_per_s / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms_per_view": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
             host = os.cpu_count() or 1
-            threads = args.cpu_threads or min(host, 16)
+            threads = args.cpu_threads or host
             torch.set_num_threads(threads)
-            print(f"[bench] cpu baseline: oracle on {threads} of {host} host cores ...", file=sys.stderr, flush=True)
-            dt, r_cpu, pairs = cpu_baseline(scene_cpu, cams[0], F, args.cpu_tile_step, args.cpu_budget_s)
+            print(f"[bench] cpu baseline: reference PyTorch-CPU preprocess on {threads} of {host} host cores ...", file=sys.stderr, flush=True)
+            sec_view, reps = cpu_preprocess_baseline(scene_cpu, cams[0], args.cpu_budget_s)
+            pre_ms = (breakdown or {}).get("preprocess_fwd")
+            out["cpu_baseline"] = {
+                "value": round(1.0 / sec_view, 4), "unit": "views/s (preprocess stage only)", "cores": threads, "kind": "port",
+                "host_cores": host, "gaussians_per_s": round(N / sec_view, 1), "ms_per_view": round(sec_view * 1e3, 3),
+                "hip_preprocess_ms_per_view": pre_ms,
+                "sample": f"the reference's PyTorch-CPU preprocess restated (oracle/cpu_preprocess.py; fp32; activations + "
+                          f"eval_sh colours + covariance + projection) over ALL {N} Gaussians of the workload, {reps} whole "
+                          f"views in {sec_view * reps:.1f} s, torch.set_num_threads({threads}); no extrapolation"}
+            print(f"[bench] cpu oracle sample (secondary) ...", file=sys.stderr, flush=True)
+            torch.set_num_threads(min(host, 16))
+            dt, r_cpu, pairs = cpu_baseline(scene_cpu, cams[0], F, args.cpu_tile_step, args.cpu_oracle_budget_s)
             est_full = dt * r_cpu / max(pairs, 1)
-            out["cpu_baseline"] = {"value": round(1.0 / est_full, 6), "unit": "views/s", "cores": threads,
-                                   "kind": "port", "host_cores": host,
-                                   "sample": f"float64 oracle fwd+bwd on view 0: all {N} Gaussians preprocessed, "
-                                             f"{pairs} of {r_cpu} (tile,Gaussian) pairs composited "
-                                             f"(every {args.cpu_tile_step}th tile, {dt:.1f} s measured, extrapolated by pair count)"}
+            out["cpu_oracle_sample"] = {"value": round(1.0 / est_full, 6), "unit": "views/s (full fwd+bwd, extrapolated)",
+                                        "cores": min(host, 16), "kind": "port",
+                                        "sample": f"float64 oracle fwd+bwd on view 0: all {N} Gaussians preprocessed, "
+                                                  f"{pairs} of {r_cpu} (tile,Gaussian) pairs composited (every "
+                                                  f"{args.cpu_tile_step}th tile, {dt:.1f} s measured, extrapolated by pair count)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

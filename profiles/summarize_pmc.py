@@ -13,6 +13,7 @@ def short(name):
 def main():
     out, dbs = sys.argv[1], sys.argv[2:]
     lines = []
+    allagg = {}        # kernel -> counter -> average per launch
     for db in dbs:
         c = sqlite3.connect(db)
         cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
@@ -28,7 +29,10 @@ def main():
         agg = {}
         for kname, cname, n, tot in c.execute(q):
             agg.setdefault(short(kname), {})[cname] = (n, tot)
-        lines.append(f"## {db}\ncolumns: {cols}\n")
+        for k, d in agg.items():
+            if k.startswith("trase::"):
+                allagg.setdefault(k, {}).update({cn: v[1] / v[0] for cn, v in d.items()})
+        lines.append(f"## {db}\n")
         counters = sorted({cn for d in agg.values() for cn in d})
         lines.append("| kernel | dispatches | " + " | ".join(counters) + " |")
         lines.append("|---|---:|" + "---:|" * len(counters))
@@ -39,6 +43,8 @@ def main():
             lines.append(f"| {k} | {n} | " + " | ".join(f"{d[cn][1] / d[cn][0]:.4g}" if cn in d else "-" for cn in counters) + " |")
         lines.append("")
     open(out, "w").write("\n".join(lines) + "\n")
+    import json
+    open(out[:-3] + ".json" if out.endswith(".md") else out + ".json", "w").write(json.dumps(allagg, indent=1, sort_keys=True))
     print("\n".join(lines))
 
 

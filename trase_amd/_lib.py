@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be imported first: the library binds to torch's libamdhip64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrase_rast.so")
+LIB_PATH = os.environ.get("TRASE_RAST_LIB") or os.path.join(_HERE, "lib", "libtrase_rast.so")   # override: A/B builds
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -132,7 +132,7 @@ PairBuf carve_tmp(void* ptr, int64_t cap) {
   return t;
 }
 size_t bwd_tmp_bytes(int P, int F, int64_t cap) {
-  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up((size_t)cap) + align_up(sizeof(float) * bwd_row_floats(F) * (size_t)cap) +
+  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up((size_t)cap) + align_up(sizeof(float) * bwd_row_stride(F) * (size_t)cap) +
          align_up(bwd_chan_bytes(P));
 }
 
@@ -324,7 +324,7 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
   float* acc = (float*)ws->tmp;
   uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in->P);
   float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
-  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_floats(in->F) * (size_t)ws->capacity);
+  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_stride(in->F) * (size_t)ws->capacity);
   if (in->P == 0) return TRASE_OK;
   TraseRastGrads g2 = *gr;
   if (!(s->variant & 0x100)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
@@ -347,7 +347,8 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
     // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
     // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
     if (in2.F == 32 && !(s->variant & 0x40)) {
-      rc = launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+      rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
+                                : launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
     } else {
       TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
       rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags);
@@ -437,7 +438,7 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
   float* acc = (float*)ws->tmp;
   uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in.P);
   float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
-  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_floats(in.F) * (size_t)ws->capacity);
+  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_stride(in.F) * (size_t)ws->capacity);
   if (in.P == 0) return TRASE_OK;
   TraseRastGrads g2;
   memset(&g2, 0, sizeof(g2));
@@ -450,7 +451,8 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
     d_feats = nullptr;
   }
   if (in.F == 32 && !(s->variant & 0x40)) {
-    rc = launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+    rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
+                              : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
   } else {
     TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
     rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
     const uint32_t kk = kb + t;
     const unsigned long long wm = __ballot(kk < k1 && flags[kk] != 0);
     uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
-    const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * ROW) + t;
+    const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * bwd_row_stride(F)) + t;
     while (__any(m != 0)) {
       int b[U];
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
       float4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        v[u] = (col && b[u] >= 0) ? base[(size_t)b[u] * Q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = (col && b[u] >= 0) ? base[(size_t)b[u] * (bwd_row_stride(F) / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
     }

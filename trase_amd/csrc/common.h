@@ -153,16 +153,22 @@ __device__ __forceinline__ PairPoly pair_poly(float2 gxy, float4 co, float bx, f
 // row part (pixel row i) and full exponent (pixel column j)
 __device__ __forceinline__ float poly_row_base(const PairPoly& k, float i, float ii) { return fmaf(ii, k.kii, fmaf(i, k.ki, k.k0)); }
 __device__ __forceinline__ float poly_row_slope(const PairPoly& k, float i) { return fmaf(i, k.kij, k.kj); }
-__device__ __forceinline__ float poly_eval(const PairPoly& k, float base, float slope, float j, float jj) {
-  return fmaf(jj, k.kjj, fmaf(j, slope, base));
+// Horner in j: no j^2 operand (the half-wave backward keeps j per lane in a register; a second one for j^2 costs
+// occupancy).  Every kernel -- forward and all backward formulations -- evaluates this same tree.
+__device__ __forceinline__ float poly_eval(const PairPoly& k, float base, float slope, float j) {
+  return fmaf(j, fmaf(j, k.kjj, slope), base);
 }
 
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Mapping block b to the x-th
 // CONTIGUOUS eighth of the work (x = b mod 8) keeps spatially adjacent tiles -- which share their Gaussians'
 // rows -- on one XCD, so a per-Gaussian row is fetched into one L2 instead of eight.  Bijective for any nb.
 __device__ __forceinline__ int xcd_block(int b, int nb) {
+#ifdef TRASE_NO_XCD_MAP
+  return b;
+#else
   const int x = b & 7, loc = b >> 3, q = nb >> 3, r = nb & 7;
   return x * q + (x < r ? x : r) + loc;
+#endif
 }
 
 // value of lane-1 (lane 0 receives `ident`): DPP wave_shr:1
@@ -270,6 +276,12 @@ size_t pre_bytes(int P);
 size_t tmp_bytes(int64_t cap);
 size_t bwd_tmp_bytes(int P, int F, int64_t cap);
 static inline int bwd_row_floats(int F) { return F + 12; }
+// distance between the rows of consecutive slots, in floats (experiment knob: 64 puts every F = 32 row on its own pair of
+// 128-byte lines)
+#ifndef TRASE_ROW_STRIDE32
+#define TRASE_ROW_STRIDE32 44
+#endif
+constexpr int bwd_row_stride(int F) { return F == 32 ? TRASE_ROW_STRIDE32 : F + 12; }
 static inline size_t bwd_chan_bytes(int P) { return (size_t)P * 96 * 2; }   // render_bwd_mf.hip: [P][hi 48 | lo 48] bf16   // per-pair gradient row: F features + 10 scalars + 2 zeros (a multiple of 16 B)
 GeomBuf carve_geom(void* p, int P);
 BinBuf carve_bin(void* p, int64_t cap, int T);
@@ -322,6 +334,12 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
                          void* chan, size_t flag_bytes);   // clears flag_bytes (a multiple of 16) of row_flags itself
+int launch_split_channels(const LaunchCtx& c, const TraseRastInputs& in, const GeomBuf& g, void* chan, uint8_t* row_flags,
+                          size_t flag_bytes);
+// half-wave formulation (32-entry chunks, 128 VGPRs): the default for F = 32; variant bit 0x800 selects the 64-entry kernel
+int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
+                         void* chan, size_t flag_bytes);
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

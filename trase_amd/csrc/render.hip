@@ -53,7 +53,7 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
   const bool inside = px < a.W && py < a.H;
   const float bx = (float)((tile % a.gx8) * SUB), by = (float)((tile / a.gx8) * SUB);
   const float fj = (float)(lane & 7), fi = (float)(lane >> 3);
-  const float fjj = fj * fj, fii = fi * fi;
+  const float fii = fi * fi;
   const uint2 range = a.ranges[tile];
   float T = 1.0f;
   uint32_t last = 0;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
       const float4 q1 = s_k1[wave][j];
       PairPoly k;
       k.k0 = q0.x; k.kj = q0.y; k.ki = q0.z; k.kjj = q0.w; k.kii = q1.x; k.kij = q1.y; k.thr = q1.z;
-      const float e = poly_eval(k, poly_row_base(k, fi, fii), poly_row_slope(k, fi), fj, fjj);
+      const float e = poly_eval(k, poly_row_base(k, fi, fii), poly_row_slope(k, fi), fj);
       const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(e));
       const bool gate = (live != 0.0f) && (e <= k.thr) && (e >= LOG2_ALPHA_MIN);
       const float test_T = T * (1.0f - alpha);

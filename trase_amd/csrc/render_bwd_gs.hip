@@ -133,7 +133,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
         const uint32_t plast = __builtin_amdgcn_readfirstlane(__float_as_uint(pst.z));
         if (plast <= c0) continue;                       // nothing of this chunk was blended into pixel p
         const float T_end = pst.x, U_end = pst.y;
-        const float e = poly_eval(k, base, slope, (float)j, (float)(j * j));
+        const float e = poly_eval(k, base, slope, (float)j);
         const float araw = __builtin_amdgcn_exp2f(e);    // opacity * exp(power)
         const bool ok = (e <= k.thr) && (e >= LOG2_ALPHA_MIN) && (pos_cmp < plast);
         const float al = ok ? fminf(ALPHA_MAX, araw) : 0.0f;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
     // ---- write this chunk's per-Gaussian sums: one row per pair --------------------------------
     if (lane_valid && !(a.ablate & 1)) {
-      float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * ROW);
+      float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * bwd_row_stride(F));
       if (F > 0) {
 #pragma unroll
         for (int q = 0; q < F / 4; ++q) row[q] = make_float4(af2[2 * q].x, af2[2 * q].y, af2[2 * q + 1].x, af2[2 * q + 1].y);

@@ -1,0 +1,394 @@
+// render_bwd_hw.hip -- backward of the compositing stage, half-wave formulation (default for F = 32).
+//
+// Same mathematics as render_bwd_mf.hip (lane = Gaussian, DPP scans along the list, both channel contractions as
+// bf16-split MFMA GEMMs, one gradient row per (sub-tile, Gaussian) pair, no atomics) with a different shape:
+//
+//   * a chunk is 32 list entries, not 64: lane l = (g = l & 31, h = l >> 5).  Both lane halves hold the SAME 32
+//     Gaussians; half h visits the pixels of columns 4h..4h+3 of the 8x8 sub-tile.  One instruction still handles 64
+//     (pixel, Gaussian) pairs, but
+//       - a scan along the list is 5 DPP steps (row_shr 1,2,4,8 + row_bcast:15) instead of 6,
+//       - the tail of a list wastes on average 16 lanes instead of 32,
+//       - GEMM 1 (s[p][g] = <cot[p], chan[g]>) leaves lane (g,h) with exactly its own pixels
+//         (row 8q+4h+r of a 32x32 block = pixel row q, column 4h+r): no permlane swaps,
+//       - GEMM 2 (dchan[c][g] = sum_p cot[p][c] w[p][g]) takes the lane's own eight weights of two pixel rows as its
+//         B fragment directly (the K index is ordered to match; the cot^T fragment is gathered in the same order),
+//       - the accumulators of GEMM 2 are 2 x 16 registers instead of 4 x 16, those of GEMM 1 16 instead of 32:
+//         the kernel fits 128 VGPRs (four waves per SIMD instead of three).
+//   * the pixel-major cotangent image in LDS has pitch 40 bf16 (36 channels + 4 zeros): 11.25 KB per wave, two waves
+//     per workgroup -> 14 waves per CU.  K-step 2 of GEMM 1 reads eight columns past the row for h = 1; the channel
+//     table holds zeros there (split_channels_kernel), so the product is zero whatever finite values LDS returns.
+//
+// Row format and everything downstream (reduce_rows, preprocess_bwd) are unchanged.
+#include "common.h"
+
+namespace trase {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HW_WPB = 2;     // waves (sub-tiles) per workgroup
+constexpr int HW_CH = 48;     // channel-table row: [hi 48 | lo 48] bf16 (render_bwd_mf.hip split_channels_kernel)
+constexpr int HW_LD = 40;     // LDS row pitch in bf16 (80 B)
+constexpr int HW_G = 32;      // list entries per chunk
+
+struct HwWaveLds {            // contiguous on purpose: the over-read of GEMM 1's last K-step stays inside it
+  __bf16 hi[WAVE * HW_LD];
+  __bf16 lo[WAVE * HW_LD];
+  __bf16 pad[8];              // zeros: what the over-read of the last row of `lo` finds (the low half of a float is not a finite bf16)
+  float4 pix[WAVE];           // T_end, U_end, last (bits), -
+};
+
+struct BwdHwArgs {
+  const uint2* ranges; const uint32_t* point_list;
+  const float2* xy; const float4* conic_o; const float* bg;
+  const float* d_img; const float* d_feat; const float* d_depth;
+  const float* final_T; const uint32_t* n_contrib;
+  const uint32_t* pair_slot;
+  const __bf16* chan;  // [P][96]
+  float* rows;         // (capacity, 44)
+  uint8_t* row_flags;
+  uint32_t* prof;      // 8 counters (TIMING builds) or null
+  int W, H, gx8, ntiles;
+};
+
+// LDS that only ONE wave produces and consumes: the LDS queue of a wave is in order, so a later ds_read sees an earlier
+// ds_write of another lane without any wait.  A wavefront-scope fence keeps the compiler from reordering the accesses
+// and -- unlike a workgroup-scope release -- does not drain vmcnt (the gradient-row stores of the chunk, the loads in
+// flight for the next one).
+__device__ __forceinline__ void wave_lds_sync_hw() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Two independent inclusive scans over each 32-lane half, interleaved (the partner's instruction is one of the two
+// wait states a DPP read needs after the VALU write of its source).
+#define TRASE_HSCAN2(OP, CTRL) OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void half_scan_mul2(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               TRASE_HSCAN2("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+               TRASE_HSCAN2("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               TRASE_HSCAN2("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               TRASE_HSCAN2("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+               : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void half_scan_add2_out(float a, float b, float& oa, float& ob) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 0\n\t"
+               TRASE_HSCAN2("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+               TRASE_HSCAN2("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+               TRASE_HSCAN2("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+               : "=&v"(oa), "=&v"(ob) : "v"(a), "v"(b));
+}
+#undef TRASE_HSCAN2
+
+// cot^T fragment of one channel column for a K-step (two pixel rows): the lane half h supplies the pixels of columns
+// 4h..4h+3 -- rows base+0..3 (first pixel row) and base+8..11 (second pixel row) of the pixel-major image.
+__device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ col) {
+  const unsigned short* c = reinterpret_cast<const unsigned short*>(col);
+  u32x4 r;
+  r[0] = (unsigned)c[0 * HW_LD] | ((unsigned)c[1 * HW_LD] << 16);
+  r[1] = (unsigned)c[2 * HW_LD] | ((unsigned)c[3 * HW_LD] << 16);
+  r[2] = (unsigned)c[8 * HW_LD] | ((unsigned)c[9 * HW_LD] << 16);
+  r[3] = (unsigned)c[10 * HW_LD] | ((unsigned)c[11 * HW_LD] << 16);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool FEAT_ONLY, bool TIMING>
+#ifndef HW_OCC
+#define HW_OCC 4
+#endif
+__global__ __launch_bounds__(HW_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(HW_OCC, HW_OCC)))
+void render_bwd_hw_kernel(BwdHwArgs a) {
+  constexpr int F = 32, ROW = F + 12;
+  __shared__ __attribute__((aligned(16))) HwWaveLds s_w[HW_WPB];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int g = lane & 31, h = lane >> 5;
+  const int tile = xcd_block(blockIdx.x, gridDim.x) * HW_WPB + wave;
+  if (tile >= a.ntiles) return;
+  const int tx = tile % a.gx8, ty = tile / a.gx8;
+  const uint2 range = a.ranges[tile];
+  HwWaveLds& L = s_w[wave];
+  uint64_t t_mark = 0, t_acc[5] = {0, 0, 0, 0, 0};
+  auto tick = [&](int k) { if constexpr (TIMING) { const uint64_t t = __builtin_readcyclecounter(); t_acc[k] += t - t_mark; t_mark = t; } };
+  if constexpr (TIMING) t_mark = __builtin_readcyclecounter();
+  // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
+  uint32_t last;
+  {
+    const int px = tx * SUB + (lane & 7), py = ty * SUB + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const size_t hw = (size_t)a.H * a.W;
+    const size_t pix = (size_t)py * a.W + px;
+    float v[HW_LD];
+#pragma unroll
+    for (int c = 0; c < HW_LD; ++c) v[c] = 0.f;
+    float Tf = 0.f;
+    last = 0;
+    if (inside) {
+      Tf = a.final_T[pix];
+      last = a.n_contrib[pix];
+      if (a.d_feat) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[c] = a.d_feat[(size_t)c * hw + pix];
+      }
+      if (a.d_img) { v[F] = a.d_img[pix]; v[F + 1] = a.d_img[hw + pix]; v[F + 2] = a.d_img[2 * hw + pix]; }
+      if (a.d_depth) v[F + 3] = a.d_depth[pix];
+    }
+    __bf16* rh = L.hi + lane * HW_LD;
+    __bf16* rl = L.lo + lane * HW_LD;
+#pragma unroll
+    for (int c8 = 0; c8 < HW_LD / 8; ++c8) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[8 * c8 + e]; lo[e] = (__bf16)(v[8 * c8 + e] - (float)hi[e]); }
+      *reinterpret_cast<bf16x8*>(rh + 8 * c8) = hi;
+      *reinterpret_cast<bf16x8*>(rl + 8 * c8) = lo;
+    }
+    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2];
+    L.pix[lane] = make_float4(Tf, Tf * bdot, __uint_as_float(last), 0.f);
+    if (lane == 0) *reinterpret_cast<uint4*>(L.pad) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  uint32_t wave_last = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
+  wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+  // a step of the pixel loop visits pixels p, p+1 (half 0) and p+4, p+5 (half 1): lane p of `last4` holds the largest
+  // last-contributor index of that group, so the per-step skip test is one v_readlane + one scalar compare
+  uint32_t last4 = max(last, (uint32_t)__shfl_xor((int)last, 1));
+  last4 = max(last4, (uint32_t)__shfl_xor((int)last4, 4));
+  wave_lds_sync_hw();
+  const float ddx = 0.5f * (float)a.W, ddy = 0.5f * (float)a.H;
+  const float bx = (float)(tx * SUB), by = (float)(ty * SUB);
+  const __bf16* const ahi = L.hi;
+  const __bf16* const alo = L.lo;
+  // pixel columns of this lane half: j = 4h + r
+  float jv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) jv[r] = (float)(4 * h + r);
+  // channel column of this lane for the cot^T gathers: block nb covers channels nb*32 + g; columns >= 40 do not exist
+  // (they are zero): read column 39, which is zero, instead
+  const int col0 = g, col1 = min(32 + g, HW_LD - 1);
+  tick(0);
+  // The list entries of a chunk are requested one chunk ahead (two registers): one level less in the dependent chain
+  // entry -> geometry / channel rows at a chunk start.
+  uint32_t id_n = 0, slot_n = 0xffffffffu;
+  {
+    const uint32_t n0 = min(wave_last, (uint32_t)HW_G);
+    const bool v0 = (uint32_t)g < n0;
+    const uint32_t p0 = v0 ? (wave_last - 1 - g) : 0;
+    if (wave_last > 0) { id_n = a.point_list[range.x + p0]; slot_n = v0 ? a.pair_slot[range.x + p0] : 0xffffffffu; }
+  }
+  // ---- chunks of 32 list entries, back to front ----------------------------------------------------
+  for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > HW_G) ? c1 - HW_G : 0) {
+    const uint32_t c0 = (c1 > HW_G) ? c1 - HW_G : 0;
+    const uint32_t n = c1 - c0;
+    const bool lane_valid = (uint32_t)g < n;
+    const uint32_t pos = lane_valid ? (c1 - 1 - g) : 0;        // g = 0: farthest entry of the chunk
+    const uint32_t id = id_n;
+    const uint32_t slot = slot_n;
+    const float2 gxy = a.xy[id];
+    const float4 co = a.conic_o[id];
+    if (c0 > 0) {                                              // next (nearer) chunk's entries
+      const uint32_t c0n = (c0 > HW_G) ? c0 - HW_G : 0;
+      const bool vn = (uint32_t)g < c0 - c0n;
+      const uint32_t pn = vn ? (c0 - 1 - g) : 0;
+      id_n = a.point_list[range.x + pn];
+      slot_n = vn ? a.pair_slot[range.x + pn] : 0xffffffffu;
+    }
+    const PairPoly k = pair_poly(gxy, co, bx, by);
+    const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;
+    const __bf16* const crow = a.chan + (size_t)id * (2 * HW_CH) + 8 * h;   // this lane's B fragments of GEMM 1
+    tick(1);
+    f32x16 D[2];                                         // D[channel block]: rows = channels, columns = Gaussians
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) D[nb][r] = 0.f;
+    float S0 = 0.f, Sj = 0.f, Si = 0.f, Sjj = 0.f, Sij = 0.f, Sii = 0.f;
+    unsigned wh[4], wl[4];                               // 8 weights of the current K-step, packed bf16 pairs
+    // ---- GEMM 1: S[mb][p][g] for both 32-pixel halves, the channel fragments loaded once -----------------------
+    // a = cot fragment (row = pixel mb*32 + (lane & 31), 8 channels), b = channel fragment (column = Gaussian g).
+    // Lane (g,h) then holds Gaussian g, pixels mb*32 + 8q + 4h + r in register 4q + r: pixel row 4mb + q, column 4h + r.
+    f32x16 Sm[2];
+    if constexpr (!FEAT_ONLY) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sm[mb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(crow + ks * 16);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(crow + ks * 16 + HW_CH);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const bf16x8 ph = *reinterpret_cast<const bf16x8*>(ahi + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
+          const bf16x8 pl = *reinterpret_cast<const bf16x8*>(alo + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
+          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, Sm[mb], 0, 0, 0);
+          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, Sm[mb], 0, 0, 0);
+          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, Sm[mb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f32x16& S = Sm[mb];
+      tick(2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = mb * 4 + q;
+        const float fi = (float)i, fii = (float)(i * i);
+        const float base = poly_row_base(k, fi, fii);
+        const float slope = poly_row_slope(k, fi);
+        float R0 = 0.f, R1 = 0.f, R2 = 0.f;              // row sums of q, q*j, q*j^2 over this lane's four columns
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {                   // two pixels per half and step: their scans are interleaved
+          // last-contributor indices of the four pixels of this step (lane = pixel register, wave-uniform reads)
+          const int p0 = i * SUB + r;                      // half 0: p0, p0+1; half 1: p0+4, p0+5
+          float wa = 0.f, wb = 0.f;
+          if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) {
+            const int pl = p0 + 4 * h;                     // this lane's first pixel of the step
+            const float4 pa = L.pix[pl], pb = L.pix[pl + 1];
+            const uint32_t lasta = __float_as_uint(pa.z), lastb = __float_as_uint(pb.z);
+            const float ea = poly_eval(k, base, slope, jv[r]);
+            const float eb = poly_eval(k, base, slope, jv[r + 1]);
+            const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
+            const bool okb = (eb <= k.thr) && (eb >= LOG2_ALPHA_MIN) && (pos_cmp < lastb);
+            const float ra = __builtin_amdgcn_exp2f(oka ? ea : -INFINITY);   // opacity * exp(power); closed gate = 0
+            const float rb = __builtin_amdgcn_exp2f(okb ? eb : -INFINITY);
+            const float ala = fminf(ALPHA_MAX, ra), alb = fminf(ALPHA_MAX, rb);
+            const float roma = __builtin_amdgcn_rcpf(1.0f - ala), romb = __builtin_amdgcn_rcpf(1.0f - alb);
+            float Pa = roma, Pb = romb;
+            half_scan_mul2(Pa, Pb);
+            const float Ta = pa.x * Pa, Tb = pb.x * Pb;   // transmittance in front of this Gaussian
+            wa = ala * Ta; wb = alb * Tb;
+            if constexpr (FEAT_ONLY) {
+              if (g == HW_G - 1) { L.pix[pl].x = Ta; L.pix[pl + 1].x = Tb; }
+            } else {
+              const float sa = S[4 * q + r], sb = S[4 * q + r + 1];
+              const float wsa = wa * sa, wsb = wb * sb;
+              float ia, ib;
+              half_scan_add2_out(wsa, wsb, ia, ib);
+              const float Ua = pa.y + (ia - wsa), Ub = pb.y + (ib - wsb);
+              const float dLa = Ta * sa - Ua * roma, dLb = Tb * sb - Ub * romb;
+              if (g == HW_G - 1) {                         // carries for the next (nearer) chunk
+                L.pix[pl].x = Ta;     L.pix[pl].y = pa.y + ia;
+                L.pix[pl + 1].x = Tb; L.pix[pl + 1].y = pb.y + ib;
+              }
+              const float qa = ra * dLa, qb = rb * dLb;    // == opacity * G * dL/dalpha (straight-through clamp)
+              const float qja = qa * jv[r], qjb = qb * jv[r + 1];
+              R0 += qa + qb;
+              R1 += qja + qjb;
+              R2 = fmaf(qjb, jv[r + 1], fmaf(qja, jv[r], R2));
+            }
+          }
+          {                                                // split the two weights, packed: w = hi + lo
+            unsigned hb, lb;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb) : "v"(wa), "v"(wb));
+            const float ra2 = wa - __uint_as_float(hb << 16), rb2 = wb - __uint_as_float(hb & 0xffff0000u);
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lb) : "v"(ra2), "v"(rb2));
+            wh[2 * (q & 1) + (r >> 1)] = hb;               // K index = 4 * (pixel row parity) + r
+            wl[2 * (q & 1) + (r >> 1)] = lb;
+          }
+        }
+        if constexpr (!FEAT_ONLY) {
+          S0 += R0; Sj += R1; Sjj += R2;
+          Si = fmaf(fi, R0, Si); Sii = fmaf(fii, R0, Sii); Sij = fmaf(fi, R1, Sij);
+        }
+        if (q & 1) {
+          tick(3);
+          // ---- GEMM 2, K-step t = i/2: pixel rows 2t, 2t+1 ---------------------------------------------
+          const bf16x8 Bh = __builtin_bit_cast(bf16x8, (u32x4){wh[0], wh[1], wh[2], wh[3]});
+          const bf16x8 Bl = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
+          const int rowoff = ((i >> 1) * 16 + 4 * h) * HW_LD;
+          constexpr int NBLK = FEAT_ONLY ? 1 : 2;          // channel block 1 = r g b depth
+#pragma unroll
+          for (int nb = 0; nb < NBLK; ++nb) {
+            const int col = nb == 0 ? col0 : col1;
+            const bf16x8 Ah = gather_column_hw(ahi + rowoff + col), Al = gather_column_hw(alo + rowoff + col);
+            D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, D[nb], 0, 0, 0);
+            D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, D[nb], 0, 0, 0);
+            D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, D[nb], 0, 0, 0);
+          }
+          tick(4);
+        }
+      }
+    }
+    // ---- one row per pair: [32 feature sums | nx ny ca cb | cc op r g | b d 0 0] -------------------------
+    // moment sums of the two lane halves (columns 0..3 and 4..7) -> totals in both halves
+    auto both = [](float x) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    };
+    if (slot != 0xffffffffu) {
+      float* row = a.rows + (size_t)slot * bwd_row_stride(F);
+      // D[0]: lane (g,h), register 4q + r = channel 8q + 4h + r
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
+    }
+    if constexpr (!FEAT_ONLY) {
+      S0 = both(S0); Sj = both(Sj); Si = both(Si); Sjj = both(Sjj); Sij = both(Sij); Sii = both(Sii);
+    }
+    if (slot != 0xffffffffu && h == 0) {
+      float* row = a.rows + (size_t)slot * bwd_row_stride(F) + F;
+      // moments about the sub-tile origin -> sums over dx = rx - j, dy = ry - i
+      const float rx = gxy.x - bx, ry = gxy.y - by;
+      const float Qx = rx * S0 - Sj, Qy = ry * S0 - Si;
+      const float Qxx = rx * (rx * S0 - 2.0f * Sj) + Sjj;
+      const float Qyy = ry * (ry * S0 - 2.0f * Si) + Sii;
+      const float Qxy = rx * (ry * S0 - Si) - ry * Sj + Sij;
+      const float a_nx = -(co.x * Qx + co.y * Qy);
+      const float a_ny = -(co.z * Qy + co.y * Qx);
+      const float a_ca = -0.5f * Qxx, a_cb = -Qxy, a_cc = -0.5f * Qyy;
+      const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
+      *reinterpret_cast<float4*>(row) = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
+      // channels 32..35 (r g b depth sums): registers 0..3 of channel block 1 in the h = 0 half
+      *reinterpret_cast<float4*>(row + 4) = make_float4(a_cc, a_op, D[1][0], D[1][1]);
+      *reinterpret_cast<float4*>(row + 8) = make_float4(D[1][2], D[1][3], 0.f, 0.f);
+      a.row_flags[slot] = 1;
+    }
+    wave_lds_sync_hw();                                   // carries written by lanes 31 / 63 are read by the next chunk
+    tick(0);
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && a.prof) {
+#pragma unroll
+      for (int k2 = 0; k2 < 5; ++k2) atomicAdd(a.prof + k2, (uint32_t)(t_acc[k2] >> 6));
+      atomicAdd(a.prof + 5, 1u);
+    }
+  }
+}
+
+int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
+                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
+                         void* chan, size_t flag_bytes) {
+  BwdHwArgs a;
+  a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
+  a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot;
+  a.chan = (const __bf16*)chan; a.rows = rows; a.row_flags = row_flags;
+  a.prof = g.hdr + 32;                                   // header words 32..39: phase cycle counters of the TIMING build
+  a.W = s.image_width; a.H = s.image_height;
+  a.gx8 = (a.W + SUB - 1) / SUB;
+  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  int rc = launch_split_channels(c, in, g, chan, row_flags, flag_bytes);
+  if (rc) return rc;
+  {
+    ProfScope ps("render_bwd", c.stream);
+    const dim3 grid((a.ntiles + HW_WPB - 1) / HW_WPB), block(HW_WPB * WAVE);
+    if (c.variant & 0x400) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);   // feature gradients only
+    else if (c.variant & 0x1000) hipLaunchKernelGGL((render_bwd_hw_kernel<false, true>), grid, block, 0, c.stream, a);   // phase timing
+    else hipLaunchKernelGGL((render_bwd_hw_kernel<false, false>), grid, block, 0, c.stream, a);
+  }
+  TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);
+  return TRASE_OK;
+}
+
+}  // namespace trase

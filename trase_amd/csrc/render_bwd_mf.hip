@@ -238,8 +238,8 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
         // a pixel whose last blended entry lies behind this chunk passes no gate (pos >= c0 >= last): processing it
         // next to a live neighbour changes nothing, so the skip is per pair
         if (max(lasta, lastb) > c0) {
-          const float ea = poly_eval(k, base, slope, (float)j, (float)(j * j));
-          const float eb = poly_eval(k, base, slope, (float)(j + 1), (float)((j + 1) * (j + 1)));
+          const float ea = poly_eval(k, base, slope, (float)j);
+          const float eb = poly_eval(k, base, slope, (float)(j + 1));
           const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
           const bool okb = (eb <= k.thr) && (eb >= LOG2_ALPHA_MIN) && (pos_cmp < lastb);
           // a closed gate is exp2(-inf) = 0: alpha, the weight and q = araw * dL/dalpha all vanish without selects
@@ -328,7 +328,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
     const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
     // ---- one row per pair: [32 feature sums | nx ny ca cb | cc op r g | b d 0 0] -----------------------
     if (lane_valid) {
-      float* row = a.rows + (size_t)slot * ROW + F;
+      float* row = a.rows + (size_t)slot * bwd_row_stride(F) + F;
       *reinterpret_cast<float4*>(row) = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
       *reinterpret_cast<float2*>(row + 4) = make_float2(a_cc, a_op);
       *reinterpret_cast<float2*>(row + 10) = make_float2(0.f, 0.f);
@@ -342,7 +342,7 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
 #pragma unroll
       for (int gb = 0; gb < 2; ++gb) {
         if (sl[gb] != 0xffffffffu) {
-          float* row = a.rows + (size_t)sl[gb] * ROW;
+          float* row = a.rows + (size_t)sl[gb] * bwd_row_stride(F);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(row + 8 * q + 4 * h) =
@@ -358,6 +358,18 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
   }
 }
 
+// per view: channel table for the MFMA backward kernels + clears the row flags (saves a fill launch)
+int launch_split_channels(const LaunchCtx& c, const TraseRastInputs& in, const GeomBuf& g, void* chan, uint8_t* row_flags,
+                          size_t flag_bytes) {
+  {
+    ProfScope ps("split_channels", c.stream);
+    hipLaunchKernelGGL(split_channels_kernel, dim3((in.P * 6 + 255) / 256), dim3(256), 0, c.stream, in.sh_objs, g.rgbd, in.P,
+                       (__bf16*)chan, reinterpret_cast<uint4*>(row_flags), flag_bytes / 16);
+  }
+  TRASE_POST_LAUNCH("split_channels", c.stream, c.debug);
+  return TRASE_OK;
+}
+
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
                          void* chan, size_t flag_bytes) {
@@ -369,12 +381,8 @@ int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
-  {
-    ProfScope ps("split_channels", c.stream);
-    hipLaunchKernelGGL(split_channels_kernel, dim3((in.P * 6 + 255) / 256), dim3(256), 0, c.stream, in.sh_objs, g.rgbd, in.P,
-                       (__bf16*)chan, reinterpret_cast<uint4*>(row_flags), flag_bytes / 16);
-  }
-  TRASE_POST_LAUNCH("split_channels", c.stream, c.debug);
+  int rc = launch_split_channels(c, in, g, chan, row_flags, flag_bytes);
+  if (rc) return rc;
   {
     ProfScope ps("render_bwd", c.stream);
     const dim3 grid((a.ntiles + MF_WPB - 1) / MF_WPB), block(MF_WPB * WAVE);
