@@ -293,9 +293,21 @@ def blend_tile(xy, conic, opac, depth, chans, pixx, pixy, opt: OracleOptions, de
             alive_d = cp_d >= opt.t_stop
             live_before_d = torch.cat([torch.ones(1, P, dtype=torch.bool), alive_d[:-1]], dim=0)
             lb = live_before | live_before_d
-            m_a = opt.frag_rel_arith
-            f_alpha = (torch.abs(alpha_d - opt.alpha_min) < 4 * m_a * opt.alpha_min) & keep_pd
-            f_pow = (torch.abs(power_d) < 1e-6) & (opac_d[:, None] >= opt.alpha_min)
+            # The device evaluates e = log2(e) * power + log2(opacity) as a polynomial about the origin of the pixel's
+            # 8x8 block (trase_amd/csrc/common.h pair_poly / poly_eval); its float32 rounding error scales with the size
+            # of the cancelling terms, i.e. with the exponent's value at the block origin, not with e itself.
+            L2E = 1.4426950408889634
+            bxo = torch.floor(pixx / 8.0) * 8.0
+            byo = torch.floor(pixy / 8.0) * 8.0
+            RX = (xy_d[:, 0:1] - bxo[None, :]).abs()
+            RY = (xy_d[:, 1:2] - byo[None, :]).abs()
+            lo2 = torch.log2(opac_d.clamp_min(1e-30))[:, None]
+            M = L2E * (0.5 * (conic_d[:, 0:1].abs() * RX * RX + conic_d[:, 2:3].abs() * RY * RY)
+                       + conic_d[:, 1:2].abs() * RX * RY) + lo2.abs()
+            marg = torch.clamp(8 * 5.96e-8 * (M + 8.0), min=4 * opt.frag_rel_arith * L2E)     # absolute, in log2 units
+            e_d = L2E * power_d + lo2
+            f_alpha = (torch.abs(e_d - math.log2(opt.alpha_min)) < marg) & keep_pd
+            f_pow = (torch.abs(L2E * power_d) < marg) & (opac_d[:, None] >= opt.alpha_min)
             f_stop = (torch.abs(cp_d - opt.t_stop) < 8 * rel * opt.t_stop) & keep_d
             flip = (keep != keep_d) | (alive != alive_d)
             fragile = ((f_alpha | f_pow | f_stop | flip) & lb).any(dim=0)

@@ -58,7 +58,9 @@ def test_linearity_in_colours_and_determinism_full_size():
     (i1, r1, f1, d1), _, _ = _render(act, st, colors=c1)
     (i2, _, _, _), _, _ = _render(act, st, colors=c2)
     (i12, _, f12, d12), _, _ = _render(act, st, colors=0.25 * c1 + 0.75 * c2)
-    assert (i12 - (0.25 * i1 + 0.75 * i2)).abs().max().item() < 1e-5     # geometry-only weights, black bg
+    # geometry-only weights, black bg; the forward accumulates the channels as bf16-split MFMA products (~2^-16 relative
+    # per term), so linearity holds to a few 1e-5 of the colour scale -- well inside the 1e-4 parity bar
+    assert (i12 - (0.25 * i1 + 0.75 * i2)).abs().max().item() < 4e-5
     assert torch.equal(f1, f12) and torch.equal(d1, d12)                   # colours do not touch feats/depth
     (i1b, r1b, f1b, d1b), _, _ = _render(act, st, colors=c1)
     assert torch.equal(i1, i1b) and torch.equal(f1, f1b) and torch.equal(d1, d1b) and torch.equal(r1, r1b)

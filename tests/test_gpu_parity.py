@@ -136,7 +136,7 @@ def _masked(cot, o):
 
 
 def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5):
-    """Per entry: |a - b| <= rtol |b| + atol_rel * max|b| * sqrt(footprint / 64).  A gradient entry is a sum over the
+    """Per entry: |a - b| <= rtol max(|b|, 0.1 rowmax|b|) + atol_rel * max|b| * sqrt(footprint / 64).  A gradient entry is a sum over the
     Gaussian's pixels; float32 (and bf16-split MFMA) rounding noise of such a sum grows like the square root of the
     number of terms, and for a screen-filling Gaussian under a random-sign cotangent the sum itself cancels to a small
     fraction of max|b| -- so the absolute term scales with sqrt(pixels covered / one 8x8 sub-tile); for the usual
@@ -152,10 +152,18 @@ def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5):
         assert a is not None, f"no gradient for {k}"
         a = a.detach().cpu().double().reshape(a.shape[0], -1)[keep]
         b = b.reshape(b.shape[0], -1)[keep]
-        tol = rtol * b.abs() + atol_rel * max(b.abs().max().item(), 1e-12) * grow + 1e-9
+        # components of one Gaussian's gradient row share their accumulations (e.g. the x / y screen-space gradient through
+        # the conic's cross term): a component that cancels to far below its row's scale is judged against 10 % of that scale
+        b_eff = torch.maximum(b.abs(), 0.1 * b.abs().amax(dim=1, keepdim=True))
+        tol = rtol * b_eff + atol_rel * max(b.abs().max().item(), 1e-12) * grow + 1e-9
         bad = (a - b).abs() > tol
-        assert not bad.any(), (f"{k}: {int(bad.sum())} / {bad.numel()} entries off; worst "
-                               f"{((a - b).abs() / (b.abs() + 1e-12)).max().item():.3e} rel, {(a - b).abs().max().item():.3e} abs")
+        if bad.any():
+            w = int(torch.nonzero(bad.any(dim=1))[0])
+            gi = int(torch.nonzero(keep).reshape(-1)[w])
+            raise AssertionError(f"{k}: {int(bad.sum())} / {bad.numel()} entries off; worst "
+                                 f"{((a - b).abs() / (b.abs() + 1e-12)).max().item():.3e} rel, {(a - b).abs().max().item():.3e} abs; "
+                                 f"first bad Gaussian {gi}: radius {int(o.radii[gi])}, centre {o.geom.xy[gi].tolist()}, got {a[w].tolist()[:4]}, "
+                                 f"want {b[w].tolist()[:4]}, max|want| {b.abs().max().item():.3e}")
         rel_l2 = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
         assert rel_l2 < 2e-4, f"{k}: relative L2 error {rel_l2:.3e}"
 

@@ -329,6 +329,8 @@ int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const ui
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss = nullptr,
                       uint32_t cap = 0);
+int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
+                         const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss, uint32_t cap);
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,

@@ -147,6 +147,8 @@ static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const Tr
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss, uint32_t cap) {
+  if (in.F == 32 && !(c.variant & 0x2000))               // default: channel accumulation on the matrix cores
+    return launch_render_fwd_mf(c, s, in, out, g, b, im, pair_gauss, cap);
   RenderArgs a;
   fill_render_args(a, s, in, g, b);
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
