@@ -221,7 +221,7 @@ typedef struct TraseMlpWeights {
   int32_t is_blender;    /* 0: cat(PE(x), PE(t)), 84 inputs.  1 (D-NeRF, utils/time_utils.py:74-86): cat(PE(x),
                           * timenet(PE(t))), 93 inputs -- the caller evaluates the tiny timenet and passes its 30 outputs
                           * as `t` with t_stride 0 (train.py:190-202 feeds the same time to every row when is_blender) */
-  int32_t is_6dof;       /* must be 0 */
+  int32_t is_6dof;       /* 1: the 3-vector head is a screw-axis branch (branch_w / branch_v); trase_amd/deform.py runs the network twice */
   int32_t variant;       /* 0 = default (block-GEMM inference kernel); bit 0 = first-generation kernel, bit 1 = per-wave
                           * weight streaming (both kept for A/B) */
   int32_t reserved;

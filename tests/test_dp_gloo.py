@@ -52,14 +52,16 @@ class _WritesIntoSink(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sink, *params):
         ctx.sink = sink
+        ctx.ids = [id(p) for p in params]         # the sink is keyed by parameter OBJECT (FlatGradBucket.sink)
         ctx.save_for_backward(*params)
         return sum((p * p).sum() for p in params)
 
     @staticmethod
     def backward(ctx, g):
         outs = []
-        for p in ctx.saved_tensors:
-            buf = ctx.sink[p.data_ptr()]
+        for p, pid in zip(ctx.saved_tensors, ctx.ids):
+            ref, buf = ctx.sink[pid]
+            assert ref() is not None and id(ref()) == pid
             buf.copy_(2 * p * g)                 # "the kernel writes the gradient once, in place"
             outs.append(buf.view(buf.shape))     # a fresh view object: AccumulateGrad adopts it without a copy
         return (None, *outs)
@@ -96,3 +98,51 @@ def test_grad_sink_bucket_is_adopted_and_reduced_in_place():
     out = mgr.dict()
     mp.spawn(_sink_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_bucket_owns_every_gradient_before_the_exchange():
+    """What the reference loop does between iterations must not leave the all-reduce acting on a stale buffer:
+    optimizer.zero_grad(set_to_none=True) (train.py:384-386) detaches the views -> the next backward allocates fresh
+    .grad tensors -> gather_grads() copies them in and re-attaches; a parameter without a gradient this step has its
+    slice zeroed (not reduced as stale bytes); a changed parameter set (densification) raises."""
+    from trase_amd.dp import FlatGradBucket
+    torch.manual_seed(1)
+    a, b, c = (torch.randn(7, 3, requires_grad=True), torch.randn(7, 1, 32, requires_grad=True), torch.randn(7, 4, requires_grad=True))
+    bucket = FlatGradBucket([a, b, c])
+    bucket.flat.fill_(123.0)                       # stale contents
+    for p in (a, b, c):
+        p.grad = None                              # zero_grad(set_to_none=True)
+    ((a * a).sum() + (c * 3).sum()).backward()     # b receives no gradient this step
+    assert not bucket.adopted()
+    fixed = bucket.gather_grads()
+    assert fixed == 3
+    assert bucket._owns(a.grad) and bucket._owns(c.grad) and b.grad is None
+    n_a, n_b = a.numel(), b.numel()
+    assert torch.equal(bucket.flat[:n_a].view_as(a), 2 * a.detach())
+    assert float(bucket.flat[n_a:n_a + n_b].abs().max()) == 0.0
+    assert torch.equal(bucket.flat[n_a + n_b:].view_as(c), torch.full_like(c, 3.0))
+    bucket.allreduce()                             # single process: a no-op after the ownership pass
+    # a second backward now accumulates in place (views are attached again)
+    (a.sum()).backward()
+    assert bucket._owns(a.grad) and torch.equal(a.grad, 2 * a.detach() + 1)
+    a.data = torch.randn(9, 3)                     # "densification": the parameter set changed
+    a.grad = None
+    try:
+        bucket.gather_grads()
+        raise AssertionError("a changed parameter shape must raise")
+    except RuntimeError as e:
+        assert "new bucket" in str(e)
+
+
+def test_state_aware_bucket_sizes():
+    """236 B / Gaussian in the GAUSSIAN state, 128 B in the FEATURE state, MLP parameters ride along."""
+    from types import SimpleNamespace
+    from trase_amd.dp import FlatGradBucket
+    n = 11
+    mk = lambda *s: torch.zeros(n, *s, requires_grad=True)
+    pc = SimpleNamespace(_xyz=mk(3), _features_dc=mk(1, 3), _features_rest=mk(15, 3), _opacity=mk(1), _scaling=mk(3),
+                         _rotation=mk(4), _gaussian_features=mk(1, 32))
+    assert FlatGradBucket.for_state(pc, "GAUSSIAN").bytes_per_step == 236 * n
+    assert FlatGradBucket.for_state(pc, "feature").bytes_per_step == 128 * n
+    mlp = [torch.zeros(256, 84, requires_grad=True), torch.zeros(256, requires_grad=True)]
+    assert FlatGradBucket.for_state(pc, "GAUSSIAN", extra=mlp).bytes_per_step == 236 * n + 4 * (256 * 84 + 256)

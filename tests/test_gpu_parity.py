@@ -289,6 +289,43 @@ def test_nosync_capacity_policy_and_overflow_flag():
         R.set_sync(True)
 
 
+def test_nosync_policy_sizes_itself_and_raises_after_an_overflow():
+    """set_sync(False) without a capacity: the first forward measures once; later forwards do not synchronise.  When the
+    scene outgrows the buffer (densification), the overflowing call cannot know -- the NEXT call (or check_overflow())
+    raises, and the capacity has been grown so that re-running the iteration succeeds (SURVEY.md 8b 'overflow => caller
+    re-allocates and retries, Python wrapper raises RuntimeError')."""
+    from trase_amd import rasterizer as R
+    small, cam = small_case(n=300, w=128, h=96, feat=32, seed=3)
+    big, _ = small_case(n=4000, w=128, h=96, feat=32, seed=4, scale_mult=1.5)
+    st = settings_for(cam)
+    try:
+        R.set_sync(True)
+        want, _ = _gpu_call(big, st, need_grad=False)
+        n_big = R.last_status()[2]
+        R.set_sync(False)                                  # capacity unknown
+        _gpu_call(small, st, need_grad=False)              # sizes itself (one synchronising read), 1.5x headroom
+        cap0 = R._Policy.capacity
+        assert 0 < cap0 < n_big
+        _gpu_call(small, st, need_grad=False)
+        R.check_overflow()                                 # nothing to report
+        _gpu_call(big, st, need_grad=False)                # overflows silently on the device ...
+        with pytest.raises(RuntimeError, match="pair buffer overflowed"):
+            R.check_overflow()                             # ... and is reported here (or by the next forward)
+        assert R._Policy.capacity >= n_big                 # grown from the count the overflowing call measured
+        got, _ = _gpu_call(big, st, need_grad=False)       # the retry fits
+        R.check_overflow()
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        # the non-blocking path: the next forward itself raises once the header copy has landed
+        R.set_sync(False, capacity=cap0)
+        _gpu_call(big, st, need_grad=False)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="pair buffer overflowed"):
+            _gpu_call(small, st, need_grad=False)
+    finally:
+        R.set_sync(True)
+
+
 def test_distcuda2_matches_kdtree():
     from scipy.spatial import cKDTree
     from simple_knn._C import distCUDA2

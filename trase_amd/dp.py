@@ -1,52 +1,107 @@
 """Data parallelism over camera views: one process per GPU renders a different
-view; the only exchange step is ONE all-reduce of a flat per-Gaussian gradient bucket (RCCL over
-xGMI on the GPU box, gloo in the CPU tests).  The reference itself is single-process."""
+view; the only exchange step is ONE all-reduce of a flat gradient bucket (RCCL over xGMI on the
+GPU box, gloo in the CPU tests).  The reference itself is single-process.
+
+The bucket holds exactly the parameters that receive a gradient in the current optimisation state
+(scene/gaussian_model.py:303-315): 236 B / Gaussian in the GAUSSIAN state (xyz, f_dc, f_rest,
+opacity, scaling, rotation), 128 B / Gaussian in the FEATURE state (gaussian features), plus --
+when given -- the deformation network's parameters (2 MB), so that the step still ends with one
+collective."""
 from __future__ import annotations
 
-from typing import Iterable, List
+import weakref
+from typing import Iterable, List, Optional
 
 import torch
+
+GAUSSIAN_STATE_ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+FEATURE_STATE_ATTRS = ("_gaussian_features",)
 
 
 class FlatGradBucket:
     """Makes ``.grad`` of every parameter a view into one contiguous buffer, so that the step ends
-    with a single collective of sum(numel) floats (364 B/Gaussian for the TRASE parameter set)."""
+    with a single collective of sum(numel) floats.
+
+    Two ways to fill it:
+    * accumulate: ``zero()`` before the backward; autograd accumulates into the views in place;
+    * sink: ``trase_amd.renderer.set_grad_sink(bucket.sink())`` + ``detach_grads()`` before the backward; the fused
+      backward writes each gradient once, straight into the bucket, and autograd adopts the views as ``.grad``.
+
+    ``allreduce()`` first makes the bucket own every gradient: a parameter whose ``.grad`` was replaced by a fresh tensor
+    (``optimizer.zero_grad(set_to_none=True)`` of the reference loop, train.py:384-386, followed by a backward outside the
+    sink; a KNN-smoothed feature tensor whose gradient reaches the leaf through autograd) is copied in and re-attached; one
+    that received NO gradient has its slice zeroed instead of reducing stale bytes.  When the parameter set itself changed
+    (densify / prune replaces every nn.Parameter) it raises: build a new bucket (``for_state``)."""
 
     def __init__(self, params: Iterable[torch.Tensor]):
         self.params: List[torch.Tensor] = list(params)
         assert self.params, "no parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dt)
+        self._shapes = [tuple(p.shape) for p in self.params]
+        self._refs = [weakref.ref(p) for p in self.params]
+        self._views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self._views.append(v)
+            p.grad = v
             off += p.numel()
+
+    @classmethod
+    def for_state(cls, pc, state: str, extra: Optional[Iterable[torch.Tensor]] = None) -> "FlatGradBucket":
+        """Bucket over what the given optimisation state trains (``"GAUSSIAN"`` / ``"FEATURE"``,
+        scene/gaussian_model.py:303-315) plus ``extra`` (e.g. the deformation MLP's parameters)."""
+        attrs = {"GAUSSIAN": GAUSSIAN_STATE_ATTRS, "FEATURE": FEATURE_STATE_ATTRS}[state.upper()]
+        return cls([getattr(pc, a) for a in attrs] + list(extra or []))
+
+    @property
+    def bytes_per_step(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
 
     def zero(self):
         self.flat.zero_()
 
     def sink(self):
-        """{param.data_ptr(): view of its slice} for ``trase_amd.renderer.set_grad_sink``: the fused backward writes
-        each gradient once, straight into the bucket.  Use with ``detach_grads()`` before every backward (autograd adopts a
-        gradient without copying only when ``.grad`` is None); parameters that receive no gradient in a step keep stale
-        bucket contents -- ``zero()`` first if that can happen."""
-        out, off = {}, 0
-        for p in self.params:
-            out[p.data_ptr()] = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        return out
+        """{id(param): (weakref(param), view of its slice)} for ``trase_amd.renderer.set_grad_sink``.  Keyed by the
+        parameter OBJECT (checked through the weak reference), not by its address: after densification a new tensor
+        may reuse a freed allocation."""
+        return {id(p): (r, v) for p, r, v in zip(self.params, self._refs, self._views)}
 
     def detach_grads(self):
         for p in self.params:
             p.grad = None
 
-    def adopted(self) -> bool:
-        """True when every parameter's ``.grad`` lives inside the bucket (the sink path was taken)."""
+    def _owns(self, t: Optional[torch.Tensor]) -> bool:
+        if t is None:
+            return False
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * self.flat.element_size()
-        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
+        return lo <= t.data_ptr() < hi
+
+    def adopted(self) -> bool:
+        """True when every parameter's ``.grad`` lives inside the bucket."""
+        return all(self._owns(p.grad) for p in self.params)
+
+    def gather_grads(self) -> int:
+        """Make the bucket own every gradient (see the class docstring).  Returns how many slices had to be fixed."""
+        fixed = 0
+        for p, shape, v in zip(self.params, self._shapes, self._views):
+            if tuple(p.shape) != shape:
+                raise RuntimeError("FlatGradBucket: a parameter changed shape (densify / prune replaced the parameters) -- "
+                                   "build a new bucket for the new parameter set")
+            g = p.grad
+            if g is None:
+                v.zero_()                          # no gradient this step: do not reduce whatever the slice held before
+                fixed += 1
+            elif not (self._owns(g) and g.data_ptr() == v.data_ptr()):
+                v.copy_(g)
+                p.grad = v
+                fixed += 1
+        return fixed
 
     def allreduce(self, average: bool = False):
         import torch.distributed as dist
+        self.gather_grads()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

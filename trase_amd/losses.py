@@ -39,6 +39,9 @@ class _L1SSIM(torch.autograd.Function):
     def backward(ctx, g_l1, g_ssim):
         lib = _lib.load()
         x, y, ws = ctx.saved_tensors
+        # the shared evaluation cached by _fused() has served its iteration: drop it, so that it neither keeps the saved
+        # images / derivative maps alive until the next call nor hands out outputs whose graph has been freed
+        _last["img"] = _last["gt"] = _last["val"] = None
         dev = x.device
         c, h, w = x.shape
         z = torch.zeros((), device=dev)
@@ -69,8 +72,9 @@ _last = {"img": None, "gt": None, "ver": None, "val": None}
 
 def _fused(img, gt):
     """One fused evaluation shared by l1_loss(x, gt) and ssim(x, gt) when train.py calls them back to back on the same
-    tensors.  The cache holds WEAK references and compares object identity + version counters: a new tensor that
-    happens to reuse a freed tensor's id() can never hit it."""
+    tensors.  The cache holds WEAK references to the inputs and compares object identity + version counters: a new tensor
+    that happens to reuse a freed tensor's id() can never hit it.  The cached outputs are released by the backward (a
+    logging call after loss.backward() re-evaluates instead of returning outputs of a freed graph)."""
     ri, rg = _last["img"], _last["gt"]
     ver = (img._version, gt._version, torch.is_grad_enabled(), img.requires_grad)
     if ri is None or ri() is not img or rg() is not gt or _last["ver"] != ver:

@@ -39,27 +39,96 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # --------------------------------------------------------------------------------------
-# capacity policy for the (tile, Gaussian) pair buffers
+# capacity policy for the (sub-tile, Gaussian) pair buffers
 # --------------------------------------------------------------------------------------
 class _Policy:
-    # sync=True : like the reference, read the pair count back after stage 1 and allocate exactly.
-    # sync=False: no host synchronisation; buffers are sized from `capacity` (grown from the last
-    #             observed count); overflow is detected by `last_status()` / at the next call.
+    """sync=True  (default): like the reference, read the pair count back after stage 1 and allocate exactly
+                  (one host synchronisation per forward).
+    sync=False: no host synchronisation on the steady path.  Buffers are sized from ``capacity``; the very first
+                forward (capacity unknown) sizes itself with one synchronising read.  After every forward the geom
+                header (pair count, overflow flag, binning guards) is copied to pinned host memory behind an event;
+                the NEXT forwards poll those events without stalling, grow the capacity to 1.25 x the largest count seen,
+                and RAISE if a previous forward overflowed (its images / gradients were incomplete): the caller re-runs
+                that iteration -- the capacity has already been grown.  ``check_overflow()`` drains the queue blocking."""
     sync = os.environ.get("TRASE_RAST_SYNC", "1") != "0"
     capacity = 0
     variant = int(os.environ.get("TRASE_RAST_VARIANT", "0"), 0)
     last_geom: Optional[torch.Tensor] = None
     last_capacity = 0
+    pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
+    max_pending = 8
 
 
 def set_sync(flag: bool, capacity: int = 0):
-    """Choose the capacity policy; capacity (pairs) is only used when flag is False."""
+    """Choose the capacity policy.  ``capacity`` (pairs) seeds the sync-free policy; 0 = measure on the first call."""
     _Policy.sync = bool(flag)
     _Policy.capacity = int(capacity)
+    _Policy.pending = []
 
 
 def set_variant(v: int):
     _Policy.variant = int(v)
+
+
+def _header_verdict(h, cap: int, what: str):
+    """h: 32 int32 words of a geom header.  Grows the capacity; raises on overflow / tripped binning guards."""
+    r_eff = int(h[2]) & 0xffffffff
+    if _Policy.capacity:
+        _Policy.capacity = max(_Policy.capacity, int(r_eff * 1.25) + 1024)
+    if int(h[16]) or int(h[20]):
+        raise RuntimeError(f"trase_amd rasterizer: binning guard tripped in {what} (key flag {int(h[16])}, slot flag {int(h[20])})")
+    if int(h[1]):
+        raise RuntimeError(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
+                           f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
+                           f"has been grown to {_Policy.capacity}; re-run the iteration (or use set_sync(True)).")
+
+
+def _poll_pending(block: bool = False):
+    keep = []
+    err = None
+    for k, (ev, pin, cap) in enumerate(_Policy.pending):
+        must = block or (len(_Policy.pending) - k) > _Policy.max_pending
+        if must:
+            ev.synchronize()
+        if must or ev.query():
+            try:
+                _header_verdict(pin.tolist(), cap, "a previous sync-free forward")
+            except RuntimeError as e:      # report the first, still drain the rest
+                err = err or e
+        else:
+            keep.append((ev, pin, cap))
+    _Policy.pending = keep
+    if err is not None:
+        raise err
+
+
+def check_overflow():
+    """Blocking: wait for every sync-free forward issued so far and raise if one of them overflowed its pair buffer."""
+    _poll_pending(block=True)
+
+
+def _pick_capacity(lib, ws, stream) -> int:
+    """Pair capacity of the forward whose stage 1 has just been enqueued on `stream`."""
+    if _Policy.sync or _Policy.capacity <= 0:
+        st = (C.c_int64 * 3)()
+        _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
+        need = max(int(st[2]), 1)              # pairs after exact sub-tile culling
+        if _Policy.sync:
+            return need
+        _Policy.capacity = int(need * 1.5) + 1024      # first sync-free call: measured once, with headroom
+        return _Policy.capacity
+    _poll_pending()
+    return max(int(_Policy.capacity), 1)
+
+
+def _after_render(geom: torch.Tensor, capacity: int):
+    _Policy.last_geom, _Policy.last_capacity = geom, capacity
+    if not _Policy.sync:
+        pin = torch.empty(32, dtype=torch.int32).pin_memory()
+        pin.copy_(geom[:128].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(geom.device))
+        _Policy.pending.append((ev, pin, capacity))
 
 
 def last_status():
@@ -190,12 +259,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
                    "trase_rast_preprocess")
-        if _Policy.sync:
-            st = (C.c_int64 * 3)()
-            _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
-            capacity = max(int(st[2]), 1)      # pairs after exact sub-tile culling
-        else:
-            capacity = max(int(_Policy.capacity), 1)
+        capacity = _pick_capacity(lib, ws, stream)
         _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
         binb = _bytes(sizes.bin_bytes, device)
         tmp = _bytes(sizes.tmp_bytes, device)
@@ -204,9 +268,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ws.capacity = capacity
         _lib.check(lib.trase_rast_render(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
                    "trase_rast_render")
-        _Policy.last_geom, _Policy.last_capacity = geom, capacity
+        _after_render(geom, capacity)
 
         ctx.raster_settings = raster_settings
+        ctx.variant = s.variant
         ctx.capacity = capacity
         ctx.dims = (P, M, F, H, W)
         ctx.set_materialize_grads(False)
@@ -224,6 +289,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         device = means3D.device
         keep: list = []
         s = _fill_settings(ctx.raster_settings, device, keep)
+        s.variant = ctx.variant                # the forward's variant (a global change in between must not split the pair)
         inp = _lib.RastInputs()
         inp.P, inp.M, inp.F = P, M, F
         inp.means3D = _lib.ptr(means3D)

@@ -17,8 +17,8 @@ import torch
 from . import _lib
 from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _bytes, _fill_settings, _prep,
-                         _stream)
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _bytes, _fill_settings,
+                         _pick_capacity, _prep, _stream)
 
 
 def set_backward_scope(scope: str = "all") -> None:
@@ -40,10 +40,11 @@ _GRAD_SINK: dict = {}
 
 
 def set_grad_sink(sink=None) -> None:
-    """``sink``: {parameter.data_ptr(): preallocated gradient buffer of the parameter's shape} or None.  The fused
-    backward then writes the gradients of those parameters directly into the given buffers (and autograd adopts them as
-    ``.grad`` when ``.grad`` is None) instead of allocating fresh tensors -- used by ``trase_amd.dp.FlatGradBucket`` so
-    that the view-parallel all-reduce bucket is filled without a zero-fill and an accumulation pass."""
+    """``sink``: {id(parameter): (weakref(parameter), preallocated gradient buffer of the parameter's shape)} or None
+    (``trase_amd.dp.FlatGradBucket.sink()``).  The fused backward then writes the gradients of those parameters directly
+    into the given buffers (and autograd adopts them as ``.grad`` when ``.grad`` is None) instead of allocating fresh
+    tensors, so that the view-parallel all-reduce bucket is filled without a zero-fill and an accumulation pass.  A
+    parameter is recognised by object identity (checked through the weak reference), never by its address."""
     global _GRAD_SINK
     _GRAD_SINK = dict(sink) if sink else {}
 
@@ -56,6 +57,8 @@ class _RenderRaw(torch.autograd.Function):
         device = xyz.device
         if device.type != "cuda":
             raise RuntimeError("trase_amd render runs on the GPU only (there is no CPU path)")
+        param_ids = dict(xyz=id(xyz), f_dc=id(f_dc), f_rest=id(f_rest), opacity=id(opacity), scaling=id(scaling),
+                         rotation=id(rotation), gfeat=id(gfeat))
         T = lambda t, n: _prep(t, n, device)
         xyz, f_dc, f_rest, opacity = T(xyz, "xyz"), T(f_dc, "features_dc"), T(f_rest, "features_rest"), T(opacity, "opacity")
         scaling, rotation = T(scaling, "scaling"), T(rotation, "rotation")
@@ -95,12 +98,7 @@ class _RenderRaw(torch.autograd.Function):
         stream = _stream(device)
         _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                    "trase_rast_preprocess_raw")
-        if _Policy.sync:
-            st = (C.c_int64 * 3)()
-            _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
-            capacity = max(int(st[2]), 1)
-        else:
-            capacity = max(int(_Policy.capacity), 1)
+        capacity = _pick_capacity(lib, ws, stream)
         _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
         binb, tmp = _bytes(sizes.bin_bytes, device), _bytes(sizes.tmp_bytes, device)
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
@@ -108,8 +106,10 @@ class _RenderRaw(torch.autograd.Function):
         ws.capacity = capacity
         _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                    "trase_rast_render_raw")
-        _Policy.last_geom, _Policy.last_capacity = geom, capacity
+        _after_render(geom, capacity)
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
+        ctx.variant = s.variant
+        ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
         ctx.norm_features = bool(norm_features)
         ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
         ctx.set_materialize_grads(False)
@@ -131,6 +131,7 @@ class _RenderRaw(torch.autograd.Function):
         device = xyz.device
         keep: list = []
         s = _fill_settings(ctx.raster_settings, device, keep)
+        s.variant = ctx.variant                # the forward's variant, not whatever the global says now
         raw = _lib.RastRawInputs()
         raw.P, raw.F, raw.norm_features = P, F, int(ctx.norm_features)
         raw.xyz, raw.d_xyz = _lib.ptr(xyz), (_lib.ptr(d_xyz) if has_dxyz else None)
@@ -153,25 +154,31 @@ class _RenderRaw(torch.autograd.Function):
         ws.capacity = ctx.capacity
         need = ctx.needs_input_grad   # xyz0 d_xyz1 f_dc2 f_rest3 opacity4 scaling5 d_scaling6 rotation7 d_rotation8 gfeat9 means2D10
 
-        def alloc(flag, like, sink=True):
+        pid = ctx.param_ids
+
+        def alloc(flag, like, name=None):
             if not flag:
                 return None
-            buf = _GRAD_SINK.get(like.data_ptr()) if (_GRAD_SINK and sink) else None
-            if buf is not None and buf.shape == like.shape and buf.device == like.device:
-                # a FRESH view object: autograd's AccumulateGrad then adopts it as .grad without a copy (it clones a
-                # gradient that somebody else still references), so the gradient is written once, in place, into the
-                # caller's buffer (trase_amd.dp.FlatGradBucket: the all-reduce bucket)
-                return buf.view(buf.shape)
+            ent = _GRAD_SINK.get(pid[name]) if (_GRAD_SINK and name) else None
+            if ent is not None:
+                ref, buf = ent
+                p = ref()
+                if p is not None and id(p) == pid[name] and buf.shape == like.shape and buf.device == like.device:
+                    # a FRESH view object: autograd's AccumulateGrad then adopts it as .grad without a copy (it clones a
+                    # gradient that somebody else still references), so the gradient is written once, in place, into the
+                    # caller's buffer (trase_amd.dp.FlatGradBucket: the all-reduce bucket)
+                    return buf.view(buf.shape)
             return torch.empty_like(like)
 
-        g_xyz = alloc(True, xyz)
-        g_dxyz = alloc(need[1] and has_dxyz, xyz, sink=False)      # the deformation offsets are not bucket parameters
+        # the kernel always produces dL/dxyz (the position chain needs it); it only lands in the sink when it is asked for
+        g_xyz = alloc(True, xyz, "xyz" if need[0] else None)
+        g_dxyz = alloc(need[1] and has_dxyz, xyz)                  # the deformation offsets are not bucket parameters
         g_m2d = torch.empty(P, 3, device=device)
-        g_dc, g_rest = alloc(need[2], f_dc), alloc(need[3], f_rest)
-        g_op, g_sc, g_rot = alloc(need[4], opacity), alloc(need[5], scaling), alloc(need[6 + 1], rotation)
-        g_dsc = alloc(need[6] and has_dscale, scaling, sink=False)
-        g_drot = alloc(need[8] and has_drot, rotation, sink=False)
-        g_feat = alloc(need[9] and has_feat and F > 0, gfeat) if has_feat else None
+        g_dc, g_rest = alloc(need[2], f_dc, "f_dc"), alloc(need[3], f_rest, "f_rest")
+        g_op, g_sc, g_rot = alloc(need[4], opacity, "opacity"), alloc(need[5], scaling, "scaling"), alloc(need[6 + 1], rotation, "rotation")
+        g_dsc = alloc(need[6] and has_dscale, scaling)
+        g_drot = alloc(need[8] and has_drot, rotation)
+        g_feat = alloc(need[9] and has_feat and F > 0, gfeat, "gfeat") if has_feat else None
         g = _lib.RastRawGrads()
         g.dL_dimage = _lib.ptr(_prep(grad_image, "grad_image", device))
         g.dL_dfeats = _lib.ptr(_prep(grad_feats, "grad_feats", device)) if F > 0 else None
