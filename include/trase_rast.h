@@ -60,6 +60,12 @@ typedef struct TraseRastSettings {
   int32_t debug;           /* !=0: synchronise + check after every kernel */
   int32_t device;          /* HIP device ordinal of all pointers and of `stream` */
   int32_t variant;         /* kernel variant selector for A/B ablation; 0 = default */
+  /* Tile-row strip (second multi-GPU axis, SURVEY.md 8e: one view sharded over ranks by rows of 16x16 tiles).  Rows
+   * [tile_row_begin, tile_row_end) are binned, composited and differentiated; pixels outside the strip are not written,
+   * per-Gaussian gradients are this strip's partial sums (the ranks' strips add up to the full gradient), radii stay
+   * whole-image.  begin == end == 0 means the whole image. */
+  int32_t tile_row_begin;
+  int32_t tile_row_end;
 } TraseRastSettings;
 
 /* Inputs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:137-146).

@@ -1,0 +1,71 @@
+"""Tile-row strips (SURVEY.md 8e second axis, BASELINE config 5) on ONE GPU: rendering k strips and summing what they
+produce must equal the full render -- maps bit-identical inside each strip and zero outside, per-Gaussian gradients equal
+to fp32 reassociation, radii whole-image -- through the operator and through the fused render()."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n=6000, w=200, h=150, seed=3):
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    dev = torch.device("cuda", 0)
+    scene = make_scene(n, feat_dim=32, seed=seed, scale_mult=0.9).to(dev)
+    cam = orbit_camera(w, h, angle=0.4).to(dev)
+    return scene, cam, dev, SynthGaussianModel, SynthPipe
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_reassemble_the_full_render(world):
+    from gaussian_renderer import render
+    from trase_amd import rasterizer as R
+    from trase_amd.dp import strip_pixel_rows, tile_row_partition
+    scene, cam, dev, Model, Pipe = _scene()
+    H, W = cam.image_height, cam.image_width
+    bg = torch.tensor([0.2, 0.3, 0.1], device=dev)
+    g = torch.Generator().manual_seed(0)
+    gi, gf = torch.randn(3, H, W, generator=g).to(dev), torch.randn(32, H, W, generator=g).to(dev)
+
+    def run(rows):
+        pc = Model(scene)
+        with R.tile_rows(*rows):
+            out = render(cam, pc, Pipe(), bg, 0.0, 0.0, 0.0)
+        torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])   # after the context: the ctx carries the strip
+        grads = [p.grad.clone() for p in pc.parameters()] + [out["viewspace_points"].grad.clone()]
+        return out, grads
+
+    full, g_full = run((0, 0))
+    part = tile_row_partition(H, world)
+    acc = [torch.zeros_like(t) for t in g_full]
+    for r in range(world):
+        o, gs = run(part[r])
+        y0, y1 = strip_pixel_rows(part, r, H)
+        assert torch.equal(o["radii"], full["radii"])
+        for k in ("render", "render_gaussian_features", "depth"):
+            assert torch.equal(o[k][:, y0:y1], full[k][:, y0:y1]), f"rank {r}: {k} differs inside its strip"
+            assert float(o[k][:, :y0].abs().sum()) == 0 and float(o[k][:, y1:].abs().sum()) == 0, f"rank {r}: {k} written outside its strip"
+        for a, t in zip(acc, gs):
+            a += t
+    for name, a, b in zip(["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "features", "means2D"], acc, g_full):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale, f"{name}: strips do not add up ({float((a - b).abs().max()):.3e} vs scale {scale:.3e})"
+
+
+def test_operator_level_strip_and_empty_strip():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from trase_amd import rasterizer as R
+    from tests.util import settings_for
+    scene, cam, dev, _, _ = _scene(n=1500, w=96, h=70)
+    act = scene.activated()
+    st = settings_for(cam, bg=(0.5, 0.5, 0.5), device=dev)
+    kw = dict(means3D=act["means3D"], means2D=torch.zeros_like(act["means3D"]), shs=act["shs"], sh_objs=act["sh_objs"],
+              opacities=act["opacities"], scales=act["scales"], rotations=act["rotations"])
+    full = GaussianRasterizer(st)(**kw)
+    with R.tile_rows(1, 3):                                # tile rows 1, 2 = pixel rows 16..47
+        strip = GaussianRasterizer(st)(**kw)
+    assert torch.equal(strip[0][:, 16:48], full[0][:, 16:48]) and torch.equal(strip[2][:, 16:48], full[2][:, 16:48])
+    assert float(strip[0][:, :16].abs().sum()) == 0 and float(strip[0][:, 48:].abs().sum()) == 0
+    with R.tile_rows(5, 5):                                # an empty range (a rank beyond the last tile row)
+        none = GaussianRasterizer(st)(**kw)
+    assert float(none[0].abs().sum()) == 0 and torch.equal(none[1], full[1])
+    assert R._Policy.tile_rows == (0, 0)

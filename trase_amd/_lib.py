@@ -26,6 +26,7 @@ class RastSettings(C.Structure):
         ("sh_degree", C.c_int32), ("campos", C.c_void_p),
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("device", C.c_int32), ("variant", C.c_int32),
+        ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
     ]
 
 

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
                                                          uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key,
-                                                         uint2* __restrict__ ranges) {
+                                                         uint2* __restrict__ ranges, int sy_lo, int sy_hi) {
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = gt >> 2, q = gt & 3;
   // the sub-tile ranges (trash_key + 1 entries incl. the sentinel) are cleared here: tile_ranges runs after the sort
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
       const int row = (int)(((float)c + 0.5f) * inv_w);   // exact: c < 2^22, the quotient is >= 0.5/w8 away from an integer
       const int sx = 2 * x0 + (c - row * w8), sy = 2 * y0 + row;
       const int bx = sx * SUB, by = sy * SUB;
-      if (bx < W && by < H && subtile_cull_live(cull, bx, by, W, H)) live |= 1ull << k;
+      if (bx < W && by < H && sy >= sy_lo && sy < sy_hi && subtile_cull_live(cull, bx, by, W, H)) live |= 1ull << k;
     }
     // exclusive prefix of the lanes' counts inside the quad (DPP quad_perm broadcasts)
     const uint32_t cnt = (uint32_t)__popcll(live);
@@ -415,11 +415,14 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
                       uint2* ranges_to_clear) {
   const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+  int sy_lo, sy_hi;
+  strip_subtile_rows(s, sy_lo, sy_hi);
   {
     ProfScope ps("emit_pairs", c.stream);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((4 * P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
                        g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
-                       (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)), ranges_to_clear);
+                       (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)), ranges_to_clear,
+                       sy_lo, sy_hi);
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
   return TRASE_OK;

@@ -224,6 +224,18 @@ bool prof_on();
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// 8x8 sub-tile rows [lo, hi) of the strip the settings select (whole image when tile_row_begin == tile_row_end == 0)
+static inline void strip_subtile_rows(const TraseRastSettings& s, int& lo, int& hi) {
+  const int gy8 = (s.image_height + SUB - 1) / SUB;
+  lo = 0; hi = gy8;
+  if (s.tile_row_begin != 0 || s.tile_row_end != 0) {
+    lo = 2 * s.tile_row_begin; hi = 2 * s.tile_row_end;
+    if (lo < 0) lo = 0;
+    if (hi > gy8) hi = gy8;
+    if (hi < lo) hi = lo;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // workspace carving (must match trase_rast_sizes)
 // ----------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ struct PreArgs {
   const float* rots; const float* cov3d; const float* vm; const float* pm; const float* cam;
   int P, M, deg, W, H;
   float tanx, tany, mod;
+  int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
 };
 
 __device__ __forceinline__ void fill_view(const PreArgs& a, View& v) {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   if (vis) {
     const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, opac);
     // candidates: per sub-tile row only the columns the ellipse can reach (subtile_row_span), each decided exactly
-    for (int sy = 2 * o.y0; sy < 2 * o.y1 && sy * SUB < a.H; ++sy) {
+    for (int sy = max(2 * o.y0, a.sy_lo); sy < min(2 * o.y1, a.sy_hi) && sy * SUB < a.H; ++sy) {
       int sx0, sx1;
       subtile_row_span(cull, sy, a.H, 2 * o.x0, 2 * o.x1, sx0, sx1);
       for (int sx = sx0; sx < sx1; ++sx)
@@ -114,6 +115,7 @@ static void fill_pre_args(PreArgs& a, const TraseRastSettings& s, const TraseRas
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = in.P; a.M = in.M; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  strip_subtile_rows(s, a.sy_lo, a.sy_hi);
 }
 
 int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,

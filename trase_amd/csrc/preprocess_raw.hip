@@ -21,6 +21,7 @@ struct RawFwdArgs {
   const float* vm; const float* pm; const float* cam;
   int P, F, deg, W, H, norm_features;
   float tanx, tany, mod;
+  int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
 };
 
 __device__ __forceinline__ void raw_view(const RawFwdArgs& a, View& v) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
   if (vis) {
     const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, act.opac);
     // candidates: per sub-tile row only the columns the ellipse can reach (subtile_row_span), each decided exactly
-    for (int sy = 2 * o.y0; sy < 2 * o.y1 && sy * SUB < a.H; ++sy) {
+    for (int sy = max(2 * o.y0, a.sy_lo); sy < min(2 * o.y1, a.sy_hi) && sy * SUB < a.H; ++sy) {
       int sx0, sx1;
       subtile_row_span(cull, sy, a.H, 2 * o.x0, 2 * o.x1, sx0, sx1);
       for (int sx = sx0; sx < sx1; ++sx)
@@ -142,6 +143,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  strip_subtile_rows(s, a.sy_lo, a.sy_hi);
   const dim3 grid((raw.P + 255) / 256), block(256);
   {
     ProfScope ps("preprocess_fwd", c.stream);
@@ -240,6 +242,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
+  strip_subtile_rows(s, a.sy_lo, a.sy_hi);
   RawBwdOut o;
   o.d_xyz = gr.dL_dxyz; o.d_dxyz = gr.dL_dd_xyz; o.d_means2D = gr.dL_dmeans2D; o.d_f_dc = gr.dL_dfeatures_dc;
   o.d_f_rest = gr.dL_dfeatures_rest; o.d_opacity = gr.dL_dopacity; o.d_scaling = gr.dL_dscaling;

@@ -16,6 +16,7 @@ struct RenderArgs {
   const uint2* ranges; const uint32_t* point_list;
   const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
   int W, H, gx8, ntiles;
+  int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
   // forward only: when set, the list still holds emit-order slots; the staging step translates them to Gaussian
   // ids (slot -> id is one more dependent load, hidden like the others) and records the ids for the backward
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
@@ -32,7 +33,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ int subtile_of_wave(const RenderArgs& a, int& px, int& py, int& wave, int& lane) {
   wave = threadIdx.x >> 6;
   lane = threadIdx.x & 63;
-  const int tile = xcd_block(blockIdx.x, gridDim.x) * WPB + wave;
+  const int local = xcd_block(blockIdx.x, gridDim.x) * WPB + wave;
+  if (local >= a.ntiles) return -1;
+  const int tile = a.tile0 + local;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   px = tx * SUB + (lane & 7);
   py = ty * SUB + (lane >> 3);
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
   __shared__ float4 s_cd[WPB][WAVE];
   int px, py, wave, lane;
   const int tile = subtile_of_wave(a, px, py, wave, lane);
-  if (tile >= a.ntiles) return;
+  if (tile < 0) return;
   const bool inside = px < a.W && py < a.H;
   const float bx = (float)((tile % a.gx8) * SUB), by = (float)((tile / a.gx8) * SUB);
   const float fj = (float)(lane & 7), fi = (float)(lane >> 3);
@@ -141,7 +144,7 @@ static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const Tr
   a.ranges = b.ranges; a.point_list = b.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
   a.feats = in.sh_objs; a.bg = s.bg; a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
-  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   a.pair_slot = nullptr; a.pair_gauss = nullptr; a.point_list_w = nullptr; a.cap = 0;
 }
 
@@ -152,6 +155,7 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
   RenderArgs a;
   fill_render_args(a, s, in, g, b);
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
+  if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip
   const int T = (a.ntiles + WPB - 1) / WPB;
   {
     ProfScope ps("render_fwd", c.stream);
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(RB) void render_bwd_kernel(RenderBwdArgs b) {
   __shared__ uint32_t s_id[WPB][WAVE];
   int px, py, wave, lane;
   const int tile = subtile_of_wave(a, px, py, wave, lane);
-  if (tile >= a.ntiles) return;
+  if (tile < 0) return;
   const bool inside = px < a.W && py < a.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = a.ranges[tile];
@@ -299,6 +303,7 @@ int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
   fill_render_args(a, s, in, g, bb);
   b.d_img = gr.dL_dimage; b.d_feat = gr.dL_dfeats; b.d_depth = gr.dL_ddepth;
   b.final_T = im.final_T; b.n_contrib = im.n_contrib; b.acc = acc; b.d_feats_out = gr.dL_dsh_objs;
+  if (a.ntiles <= 0) return TRASE_OK;
   const int T = (a.ntiles + WPB - 1) / WPB;
   {
     ProfScope ps("render_bwd", c.stream);

@@ -31,6 +31,7 @@ struct BwdGsArgs {
   float* rows;         // (capacity, F+12) one gradient row per pair, indexed by slot
   uint8_t* row_flags;  // (capacity) 1 where a row was written (zeroed by the caller beforehand)
   int W, H, gx8, ntiles;
+  int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
   int ablate;          // debug/A-B (variant bits 4..7): bit0 skip the row writes, bit1 builtin instead of asm DPP scans
 };
 
@@ -47,8 +48,9 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
   __shared__ __attribute__((aligned(16))) float4 s_pix[GWPB][WAVE];      // T_end, U_end, last (bits), -
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int tile = xcd_block(blockIdx.x, gridDim.x) * GWPB + wave;
-  if (tile >= a.ntiles) return;
+  const int local = xcd_block(blockIdx.x, gridDim.x) * GWPB + wave;
+  if (local >= a.ntiles) return;
+  const int tile = a.tile0 + local;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];
   // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
@@ -215,8 +217,9 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.rows = rows; a.row_flags = row_flags;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
-  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   a.ablate = (c.variant >> 4) & 0xf;
+  if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the caller has cleared the flags)
   const int blocks = (a.ntiles + GWPB - 1) / GWPB;
   {
     ProfScope ps("render_bwd", c.stream);

@@ -50,6 +50,7 @@ struct BwdHwArgs {
   uint8_t* row_flags;
   uint32_t* prof;      // 8 counters (TIMING builds) or null
   int W, H, gx8, ntiles;
+  int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
 };
 
 // LDS that only ONE wave produces and consumes: the LDS queue of a wave is in order, so a later ds_read sees an earlier
@@ -111,8 +112,9 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int g = lane & 31, h = lane >> 5;
-  const int tile = xcd_block(blockIdx.x, gridDim.x) * HW_WPB + wave;
-  if (tile >= a.ntiles) return;
+  const int local = xcd_block(blockIdx.x, gridDim.x) * HW_WPB + wave;
+  if (local >= a.ntiles) return;
+  const int tile = a.tile0 + local;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];
   HwWaveLds& L = s_w[wave];
@@ -377,9 +379,10 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.prof = g.hdr + 32;                                   // header words 32..39: phase cycle counters of the TIMING build
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
-  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   int rc = launch_split_channels(c, in, g, chan, row_flags, flag_bytes);
   if (rc) return rc;
+  if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the flags are cleared)
   {
     ProfScope ps("render_bwd", c.stream);
     const dim3 grid((a.ntiles + HW_WPB - 1) / HW_WPB), block(HW_WPB * WAVE);

@@ -83,6 +83,7 @@ struct BwdMfArgs {
   float* rows;         // (capacity, 44)
   uint8_t* row_flags;
   int W, H, gx8, ntiles;
+  int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
 };
 
 // 8 consecutive pixels (rows p0 .. p0+7 of the pixel-major image) of one channel column -> one MFMA fragment.
@@ -109,8 +110,9 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int tile = xcd_block(blockIdx.x, gridDim.x) * MF_WPB + wave;
-  if (tile >= a.ntiles) return;
+  const int local = xcd_block(blockIdx.x, gridDim.x) * MF_WPB + wave;
+  if (local >= a.ntiles) return;
+  const int tile = a.tile0 + local;
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];
   // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
@@ -380,9 +382,10 @@ int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.chan = (const __bf16*)chan; a.rows = rows; a.row_flags = row_flags;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
-  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   int rc = launch_split_channels(c, in, g, chan, row_flags, flag_bytes);
   if (rc) return rc;
+  if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the flags are cleared)
   {
     ProfScope ps("render_bwd", c.stream);
     const dim3 grid((a.ntiles + MF_WPB - 1) / MF_WPB), block(MF_WPB * WAVE);

@@ -46,6 +46,7 @@ struct FwdMfArgs {
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
   float* out_img; float* out_feat; float* out_depth; float* final_T; uint32_t* n_contrib;
   int W, H, gx8, ntiles;
+  int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
 };
 
 __device__ __forceinline__ void wave_lds_order() {     // wave-private LDS: the queue is in order, only the compiler must not reorder
@@ -71,8 +72,9 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int tile = xcd_block(blockIdx.x, gridDim.x) * FM_WPB + wave;
-  if (tile >= a.ntiles) return;
+  const int local = xcd_block(blockIdx.x, gridDim.x) * FM_WPB + wave;
+  if (local >= a.ntiles) return;
+  const int tile = a.tile0 + local;
   FmWaveLds& L = s_w[wave];
   const int tx = tile % a.gx8, ty = tile / a.gx8;
   const uint2 range = a.ranges[tile];
@@ -314,7 +316,8 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
-  a.ntiles = a.gx8 * ((a.H + SUB - 1) / SUB);
+  { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
+  if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip
   {
     ProfScope ps("render_fwd", c.stream);
     hipLaunchKernelGGL(render_fwd_mf_kernel, dim3((a.ntiles + FM_WPB - 1) / FM_WPB), dim3(FM_WPB * WAVE), 0, c.stream, a);

@@ -117,3 +117,62 @@ def allreduce_densify_stats(xyz_gradient_accum, denom, max_radii2D):
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM)
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# second axis (SURVEY.md 8e, BASELINE config 5): ONE view sharded over the ranks by rows of 16x16 tiles
+# --------------------------------------------------------------------------------------------------------------------
+TILE = 16
+
+
+def tile_row_partition(image_height: int, world: int):
+    """[(begin, end)] tile-row ranges, one per rank: contiguous, disjoint, covering ceil(H / 16) rows, sizes differing by at
+    most one (ranks beyond the number of tile rows get an empty range)."""
+    rows = (int(image_height) + TILE - 1) // TILE
+    base, extra = divmod(rows, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < extra else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+def strip_pixel_rows(part, rank: int, image_height: int, halo_px: int = 0):
+    """Pixel rows [y0, y1) of a rank's strip, optionally widened by a halo (clipped to the image): the 11x11 SSIM window
+    of utils/loss_utils.py:56-86 needs 5 rows of its neighbours' pixels."""
+    b, e = part[rank]
+    y0, y1 = min(b * TILE, image_height), min(e * TILE, image_height)
+    return max(0, y0 - halo_px), min(image_height, y1 + halo_px)
+
+
+def allgather_strips(local: torch.Tensor, part, image_height: int):
+    """Every rank contributes the rows of ITS strip of a (C, H, W) map (what ``render`` under ``tile_rows`` returned: zeros
+    elsewhere); every rank gets the full map.  One all-reduce(SUM) of the zero-padded maps -- the strips are disjoint, so the
+    sum IS the concatenation, and unlike all_gather it needs no equal-sized chunks.  Differentiable: the gradient of a
+    rank's strip is the matching slice of the full map's gradient."""
+    return _AllGatherStrips.apply(local, part, image_height)
+
+
+class _AllGatherStrips(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, local, part, image_height):
+        import torch.distributed as dist
+        ctx.rows = None
+        full = local.detach().clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            ctx.rows = strip_pixel_rows(part, dist.get_rank(), image_height)
+            y0, y1 = ctx.rows
+            full[:, :y0] = 0
+            full[:, y1:] = 0                     # only the own strip contributes
+            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.rows is None:
+            return g, None, None
+        y0, y1 = ctx.rows
+        out = torch.zeros_like(g)
+        out[:, y0:y1] = g[:, y0:y1]
+        return out, None, None

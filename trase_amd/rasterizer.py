@@ -57,6 +57,7 @@ class _Policy:
     last_capacity = 0
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
     max_pending = 8
+    tile_rows = (0, 0)          # strip of 16x16-tile rows to render; (0, 0) = the whole image
 
 
 def set_sync(flag: bool, capacity: int = 0):
@@ -68,6 +69,31 @@ def set_sync(flag: bool, capacity: int = 0):
 
 def set_variant(v: int):
     _Policy.variant = int(v)
+
+
+def set_tile_rows(begin: int = 0, end: int = 0):
+    """Render only the rows [begin, end) of 16x16 tiles (the tile-sharding axis of SURVEY.md 8e: one view split over
+    ranks; ``trase_amd.dp.tile_row_partition`` gives each rank its range).  Pixels outside the strip come back as zeros,
+    per-Gaussian gradients are the strip's partial sums (the ranks' gradients add up to the whole view's -- the same
+    all-reduce as for view parallelism), ``radii`` stay whole-image.  (0, 0) restores the whole image."""
+    if begin < 0 or end < begin:
+        raise ValueError("tile rows must satisfy 0 <= begin <= end")
+    _Policy.tile_rows = (int(begin), int(end))
+
+
+class tile_rows:
+    """``with tile_rows(b, e): out = render(...); loss.backward()`` -- the backward uses the strip its forward ran with."""
+
+    def __init__(self, begin: int, end: int):
+        self.rows = (begin, end)
+
+    def __enter__(self):
+        self.saved = _Policy.tile_rows
+        set_tile_rows(*self.rows)
+        return self
+
+    def __exit__(self, *exc):
+        _Policy.tile_rows = self.saved
 
 
 def _header_verdict(h, cap: int, what: str):
@@ -196,6 +222,7 @@ def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _li
     s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(rs.debug)   # debug=2 additionally names every kernel on stderr
     s.device = device.index if device.index is not None else torch.cuda.current_device()
     s.variant = _Policy.variant
+    s.tile_row_begin, s.tile_row_end = _Policy.tile_rows
     for name in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _prep(getattr(rs, name), name, device)
         if t is None:
@@ -238,9 +265,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         inp.opacities, inp.scales, inp.rotations = _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations)
         inp.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
 
-        image = torch.empty(3, H, W, device=device)
-        feats = torch.empty(F, H, W, device=device)
-        depth = torch.empty(1, H, W, device=device)
+        mk = torch.zeros if (s.tile_row_begin or s.tile_row_end) else torch.empty    # a strip leaves the other rows untouched
+        image = mk(3, H, W, device=device)
+        feats = mk(F, H, W, device=device)
+        depth = mk(1, H, W, device=device)
         radii = torch.empty(P, dtype=torch.int32, device=device)
         out = _lib.RastOutputs()
         out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
@@ -271,7 +299,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _after_render(geom, capacity)
 
         ctx.raster_settings = raster_settings
-        ctx.variant = s.variant
+        ctx.variant, ctx.tile_rows = s.variant, (s.tile_row_begin, s.tile_row_end)
         ctx.capacity = capacity
         ctx.dims = (P, M, F, H, W)
         ctx.set_materialize_grads(False)
@@ -290,6 +318,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep: list = []
         s = _fill_settings(ctx.raster_settings, device, keep)
         s.variant = ctx.variant                # the forward's variant (a global change in between must not split the pair)
+        s.tile_row_begin, s.tile_row_end = ctx.tile_rows
         inp = _lib.RastInputs()
         inp.P, inp.M, inp.F = P, M, F
         inp.means3D = _lib.ptr(means3D)

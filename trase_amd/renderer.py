@@ -81,9 +81,10 @@ class _RenderRaw(torch.autograd.Function):
         raw.gaussian_features = _lib.ptr(gfeat) if F > 0 else None
         raw.featn = _lib.ptr(featn)
 
-        image = torch.empty(3, H, W, device=device)
-        feats = torch.empty(F, H, W, device=device)
-        depth = torch.empty(1, H, W, device=device)
+        mk = torch.zeros if (s.tile_row_begin or s.tile_row_end) else torch.empty    # a strip leaves the other rows untouched
+        image = mk(3, H, W, device=device)
+        feats = mk(F, H, W, device=device)
+        depth = mk(1, H, W, device=device)
         radii = torch.empty(P, dtype=torch.int32, device=device)
         out = _lib.RastOutputs()
         out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
@@ -108,7 +109,7 @@ class _RenderRaw(torch.autograd.Function):
                    "trase_rast_render_raw")
         _after_render(geom, capacity)
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
-        ctx.variant = s.variant
+        ctx.variant, ctx.tile_rows = s.variant, (s.tile_row_begin, s.tile_row_end)
         ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
         ctx.norm_features = bool(norm_features)
         ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
@@ -131,7 +132,8 @@ class _RenderRaw(torch.autograd.Function):
         device = xyz.device
         keep: list = []
         s = _fill_settings(ctx.raster_settings, device, keep)
-        s.variant = ctx.variant                # the forward's variant, not whatever the global says now
+        s.variant = ctx.variant                # the forward's variant and strip, not whatever the globals say now
+        s.tile_row_begin, s.tile_row_end = ctx.tile_rows
         raw = _lib.RastRawInputs()
         raw.P, raw.F, raw.norm_features = P, F, int(ctx.norm_features)
         raw.xyz, raw.d_xyz = _lib.ptr(xyz), (_lib.ptr(d_xyz) if has_dxyz else None)
