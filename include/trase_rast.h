@@ -326,6 +326,17 @@ int trase_contrastive_backward(const float* C, const float* C_F, const float* we
  * (param, exp_avg, exp_avg_sq), with torch.optim.Adam's arithmetic (no weight decay, no amsgrad):
  * scene/gaussian_model.py:253-300 builds Adam(l, lr=0.0, eps=1e-15) over per-parameter groups; train.py:376-389
  * steps it.  The tables (pointers to device tensors, sizes, learning rates, steps) are HOST arrays. */
+/* ---- nearest-neighbour feature matching style loss (utils/loss_utils.py:223-228; train_style_transfer_nnfm.py:201-203) ----
+ * loss = mean_i min_j (1 - cos(feat1[:, i], feats2[:, j])) for feat1 (C, N1), feats2 (C, N2) fp32, C a multiple of 64 up
+ * to 512 (VGG conv4_1).  The N1 x N2 cosine matrix is never formed: bf16 MFMA GEMM with a running row maximum selects
+ * the neighbour, its cosine is re-evaluated in fp32.  The backward differentiates through the arg-min w.r.t. feat1 only
+ * (the style reference carries no graph).  `ws` from the forward is handed back to the backward unchanged. */
+int trase_nnfm_sizes(int32_t C, int32_t N1, int32_t N2, size_t* ws_bytes);
+int trase_nnfm_forward(const float* feat1, const float* feats2, int32_t C, int32_t N1, int32_t N2, float* loss, void* ws,
+                       size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_nnfm_backward(const float* feat1, const float* feats2, int32_t C, int32_t N1, int32_t N2, const float* g_loss,
+                        const void* ws, size_t ws_bytes, float* dL_dfeat1, int32_t device, trase_stream_t stream);
+
 int trase_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
                     double beta2, float eps, int32_t device, trase_stream_t stream);

@@ -169,6 +169,11 @@ SYMBOLS = [
     ("trase_featnorm_sizes", C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     ("trase_featnorm_forward", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_featnorm_backward", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("trase_nnfm_sizes", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("trase_nnfm_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_int32, C.c_void_p]),
+    ("trase_nnfm_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_adam_step", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),

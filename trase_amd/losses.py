@@ -195,3 +195,48 @@ negative_pixel_pair_loss = {
     "all": pixel_mask_correspondence_loss_negative,
     "soft": pixel_mask_correspondence_loss_soft_negative,
 }
+
+
+# ---- NNFM style loss (utils/loss_utils.py:223-228) -----------------------------------------------------------------------
+class _NNFM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat1, feats2):
+        lib = _lib.load()
+        dev = feat1.device
+        f1 = feat1.detach().float().contiguous()
+        f2 = feats2.detach().float().contiguous()
+        c, n1, n2 = f1.shape[0], f1.shape[1], f2.shape[1]
+        nbytes = C.c_size_t()
+        _lib.check(lib.trase_nnfm_sizes(c, n1, n2, C.byref(nbytes)), "trase_nnfm_sizes")
+        ws = _bytes(nbytes.value, dev)
+        loss = torch.empty(1, device=dev)
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_nnfm_forward(_lib.ptr(f1), _lib.ptr(f2), c, n1, n2, _lib.ptr(loss), _lib.ptr(ws), ws.numel(), d,
+                                          _stream(dev)), "trase_nnfm_forward")
+        ctx.save_for_backward(f1, f2, ws)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f1, f2, ws = ctx.saved_tensors
+        dev = f1.device
+        c, n1, n2 = f1.shape[0], f1.shape[1], f2.shape[1]
+        g1 = g.detach().float().reshape(1).contiguous()
+        d_f1 = torch.empty_like(f1)
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_nnfm_backward(_lib.ptr(f1), _lib.ptr(f2), c, n1, n2, _lib.ptr(g1), _lib.ptr(ws), ws.numel(),
+                                           _lib.ptr(d_f1), d, _stream(dev)), "trase_nnfm_backward")
+        return d_f1, None
+
+
+def loss_nnfm_style(feat1: torch.Tensor, feats2: torch.Tensor) -> torch.Tensor:
+    """utils/loss_utils.py:223-228: feat1 (C, N1) rendered-frame features, feats2 (C, N2) style features ->
+    mean_i min_j (1 - cosine).  Gradient w.r.t. feat1 only (the reference's style features carry no graph to the scene)."""
+    if feat1.device.type != "cuda":
+        raise RuntimeError("trase_amd.losses runs on the GPU only (there is no CPU path)")
+    if feat1.dim() != 2 or feats2.dim() != 2 or feat1.shape[0] != feats2.shape[0]:
+        raise ValueError(f"expected (C, N1) and (C, N2) feature matrices, got {tuple(feat1.shape)} and {tuple(feats2.shape)}")
+    if feats2.requires_grad:
+        raise NotImplementedError("loss_nnfm_style: a gradient w.r.t. the style features is not produced")
+    return _NNFM.apply(feat1, feats2)
