@@ -34,7 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FM_WAVES = 2;       // waves per sub-tile (= workgroup)
-constexpr int FM_G = 64;          // list entries per chunk
+#ifndef FM_G_
+#define FM_G_ 64
+#endif
+constexpr int FM_G = FM_G_;       // list entries per chunk
 constexpr int FM_LD = FM_G + 8;   // tile row pitch in bf16 (entries + 8 pad: conflict-free fragment reads)
 constexpr int FM_CH = 40;         // tile rows: 32 features, r g b depth, 4 zero rows
 
