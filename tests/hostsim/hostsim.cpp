@@ -97,3 +97,30 @@ extern "C" int hs_subtile_enumerate(float gx, float gy, float A, float B, float 
   *mismatch = bad; *tested_full = nf; *tested_pruned = np;
   return live;
 }
+
+// live sub-tiles of a splat's tile rect by the per-row interval rule (subtile_row_live) vs the per-block rule
+// (subtile_cull_live): *only_block = blocks the block rule keeps and the row rule drops, *only_row = the converse.
+// out_mask (may be null): one byte per candidate of the rect, row major: bit 0 = block rule, bit 1 = row rule.
+extern "C" int hs_subtile_rows(float gx, float gy, float A, float B, float C, float opacity, int radius, int W, int H,
+                               int* only_block, int* only_row, unsigned char* out_mask, int out_cap, int* rect) {
+  using namespace trase;
+  const int gxt = (W + TILE - 1) / TILE, gyt = (H + TILE - 1) / TILE;
+  int x0, y0, x1, y1;
+  tile_rect(gx, gy, radius, gxt, gyt, x0, y0, x1, y1);
+  if (rect) { rect[0] = 2 * x0; rect[1] = 2 * y0; rect[2] = 2 * x1; rect[3] = 2 * y1; }
+  const SubtileCull cull = subtile_cull_setup(gx, gy, A, B, C, opacity);
+  int live = 0, ob = 0, orow = 0, k = 0;
+  for (int sy = 2 * y0; sy < 2 * y1; ++sy) {
+    int c0, c1;
+    subtile_row_live(cull, sy, W, H, 2 * x0, 2 * x1, c0, c1);
+    for (int sx = 2 * x0; sx < 2 * x1; ++sx, ++k) {
+      const int bx = sx * SUB, by = sy * SUB;
+      const bool blk = bx < W && by < H && subtile_cull_live(cull, bx, by, W, H);
+      const bool row = sx >= c0 && sx < c1;
+      if (out_mask && k < out_cap) out_mask[k] = (unsigned char)((blk ? 1 : 0) | (row ? 2 : 0));
+      live += row; ob += (blk && !row); orow += (row && !blk);
+    }
+  }
+  *only_block = ob; *only_row = orow;
+  return live;
+}

@@ -77,3 +77,57 @@ def test_row_span_prefilter_never_drops_a_live_subtile(hostsim):
     assert tot_live > 100000
     assert tot_pruned < 0.75 * tot_full, (tot_pruned, tot_full)       # the pre-filter does prune
     assert tot_pruned >= tot_live
+
+
+def test_row_interval_rule_is_conservative_and_matches_the_block_rule(hostsim):
+    """subtile_row_live (gs_math.h) decides a whole sub-tile row at once from the x-extent of the ellipse inside the
+    row's band.  Over random splats (elongated, rotated, crossing the image border, tiny, huge, low opacity) its live set
+    must (a) contain every block in which some PIXEL passes the blend gate -- checked against a float64 pixel-level
+    evaluation --, (b) contain the per-block rule's set up to a vanishing number of boundary blocks, and (c) be only
+    marginally larger than it."""
+    fn = hostsim.hs_subtile_rows
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_float] * 6 + [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(2)
+    W, H = 333, 205
+    tot_row = tot_only_row = tot_only_blk = missed = checked = 0
+    mask = (C.c_ubyte * 65536)()
+    rect = (C.c_int * 4)()
+    for it in range(30000):
+        gx, gy = rng.uniform(-40, W + 40), rng.uniform(-40, H + 40)
+        big = it % 7 == 0
+        s1 = rng.uniform(0.55, 60.0 if big else 12.0)
+        s2 = s1 * rng.uniform(0.02, 1.0) if it % 3 == 0 else rng.uniform(0.55, 60.0 if big else 12.0)
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cov = R @ np.diag([s1 * s1, max(s2, 0.55) ** 2]) @ R.T
+        con = np.linalg.inv(cov)
+        A, B, Cc = np.float32(con[0, 0]), np.float32(con[0, 1]), np.float32(con[1, 1])
+        op = np.float32(rng.choice([rng.uniform(0.004, 0.02), rng.uniform(0.02, 1.0)]))
+        lam = 0.5 * (cov[0, 0] + cov[1, 1]) + np.sqrt(max(0.1, (0.5 * (cov[0, 0] + cov[1, 1])) ** 2 - np.linalg.det(cov)))
+        radius = int(np.ceil(3.0 * np.sqrt(lam)))
+        ob, orow = C.c_int(), C.c_int()
+        live = fn(np.float32(gx), np.float32(gy), A, B, Cc, op, radius, W, H, C.byref(ob), C.byref(orow), mask, 65536, rect)
+        tot_row += live; tot_only_row += orow.value; tot_only_blk += ob.value
+        if it % 10 == 0:                                # pixel-level truth on a subset (it is the slow part)
+            sx0, sy0, sx1, sy1 = rect[0], rect[1], rect[2], rect[3]
+            ncol = sx1 - sx0
+            if ncol <= 0 or (sy1 - sy0) * ncol > 65536:
+                continue
+            xs = np.arange(sx0 * 8, min(sx1 * 8, W), dtype=np.float64)
+            ys = np.arange(sy0 * 8, min(sy1 * 8, H), dtype=np.float64)
+            if xs.size == 0 or ys.size == 0:
+                continue
+            dx = np.float64(np.float32(gx)) - xs[None, :]
+            dy = np.float64(np.float32(gy)) - ys[:, None]
+            power = -0.5 * (float(A) * dx * dx + float(Cc) * dy * dy) - float(B) * dx * dy
+            ok = (power <= 0) & (float(op) * np.exp(np.minimum(power, 0)) >= 1.0 / 255.0 * (1 - 1e-6))
+            for r in range(ys.size // 8 + (ys.size % 8 > 0)):
+                for c in range(xs.size // 8 + (xs.size % 8 > 0)):
+                    if ok[8 * r:8 * r + 8, 8 * c:8 * c + 8].any():
+                        checked += 1
+                        missed += not (mask[r * ncol + c] & 2)
+    assert missed == 0 and checked > 20000, (missed, checked)
+    assert tot_row > 100000
+    assert tot_only_blk <= 1e-4 * tot_row, (tot_only_blk, tot_row)      # boundary blocks at rounding level only
+    assert tot_only_row <= 0.01 * tot_row, (tot_only_row, tot_row)      # and the row rule is as tight as the block rule

@@ -337,12 +337,15 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 }
 
 // ---- emit (tile, id) pairs in depth-rank order --------------------------------------------------
-// Four lanes (a DPP quad) share one depth rank: with one thread per rank the kernel is a single round of ~4.7k
-// waves whose run time is the serial candidate loop of the slowest lane (~150 iterations).  Each lane of the quad
-// evaluates every fourth candidate sub-tile of the splat's rect, 64 candidates per lane and chunk, keeps the
-// decisions as a bit mask, and the quad's prefix sum places the live ones.  The set of live sub-tiles is the one the
-// preprocess counted (same predicate, bit-identical); the ORDER inside a Gaussian's run is irrelevant -- every key
-// of a run is distinct and the list is sorted by key afterwards.
+// A DPP-quad-sized group of four lanes per depth rank writes the (sub-tile key, Gaussian id) pairs of its splat: per
+// sub-tile row the live columns are an interval (subtile_row_live -- the SAME function, compiled with FP contraction off,
+// that the preprocess counted with).  Every lane of the group walks all rows (a few instructions each) to know where a
+// row's run starts and writes the rows q, q+4, ...: a store instruction then touches 16 splats' runs instead of 64.
+// A splat's pairs are contiguous (its emit-order slots).
+// Splats with many rows would make their wave wait for one lane: those (more than EMIT_BIG pairs) are handed to the whole
+// wave afterwards, 64 rows at a time (lane = row, wave prefix sum of the row counts).
+constexpr uint32_t EMIT_BIG = 160;
+
 __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ sorted_ids, int P,
                                                          const uint32_t* __restrict__ offsets,
                                                          const float2* __restrict__ xy, const float4* __restrict__ conic_o,
@@ -363,52 +366,68 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   const bool in = r < P;
   const uint32_t id = in ? sorted_ids[r] : 0;
   const uint32_t nt = in ? tiles[id] : 0;
-  if (nt == 0) return;                            // the whole quad leaves together
-  uint32_t off = offsets[r] - nt;
-  const uint32_t end = off + nt;                  // this Gaussian owns exactly [off, end) -- never more, never less
-  const float2 p = xy[id];
-  const float4 co = conic_o[id];
-  int x0, y0, x1, y1;
-  tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
+  const uint32_t end = in ? offsets[r] : 0;           // this Gaussian owns exactly [end - nt, end) -- never more, never less
+  const uint32_t off0 = end - nt;
   const int gx8 = (W + SUB - 1) / SUB;
-  const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
-  const int w8 = 2 * (x1 - x0), n = w8 * 2 * (y1 - y0);            // candidates: the rect in sub-tile units, row major
-  const float inv_w = 1.0f / (float)w8;
-  for (int c0 = 0; c0 < n; c0 += 256) {
-    unsigned long long live = 0ull;
-    for (int k = 0; k < 64; ++k) {
-      const int c = c0 + 4 * k + q;
-      if (c >= n) break;
-      const int row = (int)(((float)c + 0.5f) * inv_w);   // exact: c < 2^22, the quotient is >= 0.5/w8 away from an integer
-      const int sx = 2 * x0 + (c - row * w8), sy = 2 * y0 + row;
-      const int bx = sx * SUB, by = sy * SUB;
-      if (bx < W && by < H && sy >= sy_lo && sy < sy_hi && subtile_cull_live(cull, bx, by, W, H)) live |= 1ull << k;
-    }
-    // exclusive prefix of the lanes' counts inside the quad (DPP quad_perm broadcasts)
-    const uint32_t cnt = (uint32_t)__popcll(live);
-    const uint32_t c_0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x00, 0xf, 0xf, false);   // quad lane 0
-    const uint32_t c_1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x55, 0xf, 0xf, false);   // quad lane 1
-    const uint32_t c_2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xAA, 0xf, 0xf, false);   // quad lane 2
-    const uint32_t c_3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xFF, 0xf, 0xf, false);   // quad lane 3
-    uint32_t pos = off + (q > 0 ? c_0 : 0u) + (q > 1 ? c_1 : 0u) + (q > 2 ? c_2 : 0u);
-    while (live) {
-      const int k = __builtin_ctzll(live);
-      live &= live - 1;
-      if (pos < end && pos < cap) {
-        const int c = c0 + 4 * k + q;
-        const int row = (int)(((float)c + 0.5f) * inv_w);
-        keys[pos] = (uint32_t)((2 * y0 + row) * gx8 + 2 * x0 + (c - row * w8));
-        pair_gauss[pos] = id;
-      }
-      ++pos;
-    }
-    off += c_0 + c_1 + c_2 + c_3;
+  float2 p = make_float2(0.f, 0.f);
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (nt) {
+    p = xy[id]; co = conic_o[id];
+    tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
   }
-  // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused
-  // slots go to the sentinel sub-tile `trash_key` that no kernel renders (a dropped or padded borderline pair
-  // is below the alpha gate by the culling slack, so the image is unaffected)
-  for (uint32_t o = off + q; o < end; o += 4)
-    if (o < cap) { keys[o] = trash_key; pair_gauss[o] = id; }
+  const bool big = nt > EMIT_BIG;
+  if (nt && !big) {
+    const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
+    uint32_t pos = off0;
+    int row = 0;
+    for (int sy = max(2 * y0, sy_lo); sy < min(2 * y1, sy_hi) && sy * SUB < H; ++sy, ++row) {
+      int c0, c1;
+      subtile_row_live(cull, sy, W, H, 2 * x0, 2 * x1, c0, c1);
+      if ((row & 3) == q) {
+        uint32_t w = pos;
+        for (int sx = c0; sx < c1; ++sx, ++w)
+          if (w < end && w < cap) { keys[w] = (uint32_t)(sy * gx8 + sx); pair_gauss[w] = id; }
+      }
+      pos += (uint32_t)(c1 - c0);
+    }
+    // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused slots go
+    // to the sentinel sub-tile `trash_key` that no kernel renders
+    for (pos += q; pos < end; pos += 4)
+      if (pos < cap) { keys[pos] = trash_key; pair_gauss[pos] = id; }
+  }
+  // ---- big splats: the whole wave, one splat after the other -------------------------------------------------------
+  unsigned long long todo = __ballot(big && q == 0);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const float bpx = __shfl(p.x, l), bpy = __shfl(p.y, l);
+    const float ba = __shfl(co.x, l), bb = __shfl(co.y, l), bc = __shfl(co.z, l), bo = __shfl(co.w, l);
+    const int bx0 = __shfl(x0, l), by0 = __shfl(y0, l), bx1 = __shfl(x1, l), by1 = __shfl(y1, l);
+    const uint32_t bid = (uint32_t)__shfl((int)id, l), bend = (uint32_t)__shfl((int)end, l);
+    uint32_t run = (uint32_t)__shfl((int)off0, l);
+    const SubtileCull cull = subtile_cull_setup(bpx, bpy, ba, bb, bc, bo);
+    const int r_lo = max(2 * by0, sy_lo), r_hi = min(2 * by1, sy_hi);
+    for (int rb = r_lo; rb < r_hi; rb += WAVE) {
+      const int sy = rb + lane;
+      int c0 = 0, c1 = 0;
+      if (sy < r_hi && sy * SUB < H) subtile_row_live(cull, sy, W, H, 2 * bx0, 2 * bx1, c0, c1);
+      const uint32_t cnt = (uint32_t)(c1 - c0);
+      uint32_t incl = cnt;                              // inclusive prefix of the rows' counts over the wave
+#pragma unroll
+      for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += y;
+      }
+      uint32_t pos = run + incl - cnt;
+      for (int sx = c0; sx < c1; ++sx, ++pos)
+        if (pos < bend && pos < cap) { keys[pos] = (uint32_t)(sy * gx8 + sx); pair_gauss[pos] = bid; }
+      run += (uint32_t)__shfl((int)incl, WAVE - 1);
+    }
+    for (uint32_t o = run + lane; o < bend; o += WAVE)
+      if (o < cap) { keys[o] = trash_key; pair_gauss[o] = bid; }
+  }
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,

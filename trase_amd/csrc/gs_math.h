@@ -269,6 +269,47 @@ TRASE_HD void subtile_row_span(const SubtileCull& s, int sy, int H, int sxmin, i
   sx0 = c0; sx1 = c1 > c0 ? c1 : c0;
 }
 
+// Live sub-tile columns [c0, c1) of sub-tile row `sy`, decided per ROW instead of per block: the blocks of a row that
+// the ellipse q <= tau reaches are exactly those whose pixel-centre column range meets the x-extent of the ellipse
+// restricted to the row's band of pixel centres (the restriction is convex, so its projection is an interval and every
+// x of the interval is attained).  The extent is attained at the ellipse's extreme point when that lies inside the band,
+// otherwise at one of the band's (clipped) ends.  Same live set as subtile_cull_live's continuous-box minimum up to
+// rounding; `pad` keeps it conservative (the gate threshold already carries its own slack in tau).  O(rows) instead of
+// O(rows x columns) per splat -- the count (preprocess) and the emit pass both call THIS function, with FP contraction
+// off, so they agree bit for bit.
+TRASE_HD void subtile_row_live(const SubtileCull& s, int sy, int W, int H, int sxmin, int sxmax, int& c0, int& c1) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  c0 = sxmin; c1 = sxmax;
+  if (s.mode == 1 || sy * SUB >= H) { c1 = c0; return; }
+  // columns that exist in the image
+  const int sx_img = (W + SUB - 1) / SUB;
+  if (c1 > sx_img) c1 = sx_img;
+  if (c1 < c0) c1 = c0;
+  if (s.mode == 2) return;                           // not positive definite: every block of the rect row is kept
+  const float y0 = (float)(sy * SUB), y1 = (float)imin(sy * SUB + SUB - 1, H - 1);
+  const float pad = 4e-3f;                           // pixels: covers the rounding of the roots below
+  float da = y0 - s.gy, db = y1 - s.gy;              // band of dy = pixel centre - mean
+  if (da > s.ymax + pad || db < -s.ymax - pad) { c1 = c0; return; }
+  da = fmaxf(da, -s.ymax); db = fminf(db, s.ymax);   // the part of the band inside the ellipse's y-extent
+  // x-interval of the ellipse at the two clipped band ends: centre -B dy / A, half-width sqrt(A tau - det dy^2) / A
+  const float Da = fmaxf(s.A * s.tau - s.det * da * da, 0.0f), Db = fmaxf(s.A * s.tau - s.det * db * db, 0.0f);
+  const float ca = -s.B * da * s.inv_a, cb = -s.B * db * s.inv_a;
+  const float ra = sqrtf(Da) * s.inv_a, rb = sqrtf(Db) * s.inv_a;
+  float hi = fmaxf(ca + ra, cb + rb), lo = fminf(ca - ra, cb - rb);
+  if (s.dy_xmax >= da && s.dy_xmax <= db) hi = s.xmax;       // rightmost point of the ellipse inside the band
+  if (-s.dy_xmax >= da && -s.dy_xmax <= db) lo = -s.xmax;    // leftmost point inside the band
+  const float xr = s.gx + hi + pad, xl = s.gx + lo - pad;
+  // block sx holds the pixel centres 8 sx .. 8 sx + 7: it meets [xl, xr] iff 8 sx <= xr and 8 sx + 7 >= xl
+  const float f1 = floorf(xr * (1.0f / (float)SUB));
+  const float f0 = ceilf((xl - (float)(SUB - 1)) * (1.0f / (float)SUB));
+  // clamp in float first: the products can exceed the int range for degenerate splats
+  const int a0 = (int)fminf(fmaxf(f0, (float)c0), (float)c1);
+  const int a1 = (int)fminf(fmaxf(f1 + 1.0f, (float)c0), (float)c1);
+  c0 = a0; c1 = a1 > a0 ? a1 : a0;
+}
+
 TRASE_HD bool subtile_cull_live(const SubtileCull& s, int bx, int by, int W, int H) {
 #if defined(__clang__)
 #pragma clang fp contract(off)

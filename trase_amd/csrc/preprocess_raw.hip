@@ -102,12 +102,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
   uint32_t live = 0;
   if (vis) {
     const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, act.opac);
-    // candidates: per sub-tile row only the columns the ellipse can reach (subtile_row_span), each decided exactly
+    // per sub-tile row the live columns are an interval (subtile_row_live): O(rows) per splat
     for (int sy = max(2 * o.y0, a.sy_lo); sy < min(2 * o.y1, a.sy_hi) && sy * SUB < a.H; ++sy) {
-      int sx0, sx1;
-      subtile_row_span(cull, sy, a.H, 2 * o.x0, 2 * o.x1, sx0, sx1);
-      for (int sx = sx0; sx < sx1; ++sx)
-        if (sx * SUB < a.W && subtile_cull_live(cull, sx * SUB, sy * SUB, a.W, a.H)) ++live;
+      int c0, c1;
+      subtile_row_live(cull, sy, a.W, a.H, 2 * o.x0, 2 * o.x1, c0, c1);
+      live += (uint32_t)(c1 - c0);
     }
   }
   if (active) {
