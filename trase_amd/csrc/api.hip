@@ -99,7 +99,7 @@ static size_t sort_bytes_common(size_t n) {   // hist + digit_total
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 5 + align_up(sizeof(uint32_t) * (p / 1024 + 2)) + sort_bytes_common(p);
+  return align_up(sizeof(uint32_t) * p) * 5 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2) + sort_bytes_common(p);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -108,7 +108,7 @@ PreBuf carve_pre(void* ptr, int P) {
   for (int i = 0; i < 2; ++i) { t.sort.keys[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   for (int i = 0; i < 2; ++i) { t.sort.vals[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   t.offsets = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
-  t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2));
+  t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2);
   t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(p);
@@ -232,7 +232,8 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
     return TRASE_ERR_INVALID;
   }
   // the pair count is compared against the capacity later (stage 2 knows it); 0xffffffff = no limit yet
-  return launch_scan_tiles(c, g, t.sort.vals[0], in->P, t, 0xffffffffu);
+  return launch_scan_tiles(c, g, t.sort.vals[0], in->P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
+                           (s->image_height + TILE - 1) / TILE);
 }
 
 int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream_) {
@@ -403,7 +404,8 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)in.P, 0, 32, true, &idx);
   if (rc) return rc;
   if (idx != 0) { set_error("internal: depth sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-  return launch_scan_tiles(c, g, t.sort.vals[0], in.P, t, 0xffffffffu);
+  return launch_scan_tiles(c, g, t.sort.vals[0], in.P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
+                           (s->image_height + TILE - 1) / TILE);
 }
 
 int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,

@@ -264,12 +264,34 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* sh /*[
   return sh[threadIdx.x];
 }
 
+// Also totals the lineage's pair count R = sum of the 16x16-tile rect areas (what its num_rendered reports; here a
+// statistic only): recomputed from the stored centre + radius in natural order and reduced per block -- one same-address
+// atomic per wave in the preprocess kernel cost more than the rest of that kernel (0.04 ms at 300k Gaussians, 0.22 ms at
+// 2.5 M: device-scope atomics on one address serialise at ~12 ns each).
 __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t* __restrict__ tiles,
                                                                   const uint32_t* __restrict__ ids, int P,
                                                                   uint32_t* __restrict__ offsets,
-                                                                  uint32_t* __restrict__ block_sums) {
+                                                                  uint32_t* __restrict__ block_sums,
+                                                                  const int32_t* __restrict__ radii,
+                                                                  const float2* __restrict__ xy, int gx, int gy,
+                                                                  uint32_t* __restrict__ block_R) {
   __shared__ uint32_t sh[SC_THREADS];
   const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  uint32_t area = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    const int n = blockIdx.x * SC_TILE + i * SC_THREADS + threadIdx.x;     // natural order, coalesced
+    const int rad = (n < P) ? radii[n] : 0;
+    if (rad > 0) {
+      const float2 c = xy[n];
+      int x0, y0, x1, y1;
+      tile_rect(c.x, c.y, rad, gx, gy, x0, y0, x1, y1);
+      area += (uint32_t)((x1 - x0) * (y1 - y0));
+    }
+  }
+  const uint32_t area_incl = block_incl_scan(area, sh);
+  if (threadIdx.x == SC_THREADS - 1) block_R[blockIdx.x] = area_incl;
+  __syncthreads();
   uint32_t v[SC_ITEMS];
   uint32_t sum = 0;
 #pragma unroll
@@ -290,7 +312,8 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks,
-                                                               uint32_t* __restrict__ hdr, uint32_t cap) {
+                                                               uint32_t* __restrict__ hdr, uint32_t cap,
+                                                               const uint32_t* __restrict__ block_R) {
   __shared__ uint32_t sh[SC_THREADS];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -310,6 +333,11 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
     hdr[HDR_R_EFF] = R;
     hdr[HDR_OVERFLOW] = (R > cap) ? 1u : 0u;
   }
+  uint32_t part = 0;
+  for (int b = threadIdx.x; b < nblocks; b += SC_THREADS) part += block_R[b];
+  __syncthreads();
+  const uint32_t total = block_incl_scan(part, sh);
+  if (threadIdx.x == SC_THREADS - 1) hdr[HDR_R] = total;
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __restrict__ offsets, int P,
@@ -323,13 +351,15 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __rest
   }
 }
 
-int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap) {
+int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
+                      const int32_t* radii, int gx, int gy) {
   const int nblocks = (P + SC_TILE - 1) / SC_TILE;
+  uint32_t* const block_R = t.block_sums + ((size_t)P / 1024 + 2);
   {
     ProfScope ps("scan_tiles", c.stream);
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, sorted_ids, P,
-                       t.offsets, t.block_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap);
+                       t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums);
   }
   TRASE_POST_LAUNCH("scan_tiles", c.stream, c.debug);
@@ -339,8 +369,8 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 // ---- emit (tile, id) pairs in depth-rank order --------------------------------------------------
 // A DPP-quad-sized group of four lanes per depth rank writes the (sub-tile key, Gaussian id) pairs of its splat: per
 // sub-tile row the live columns are an interval (subtile_row_live -- the SAME function, compiled with FP contraction off,
-// that the preprocess counted with).  Every lane of the group walks all rows (a few instructions each) to know where a
-// row's run starts and writes the rows q, q+4, ...: a store instruction then touches 16 splats' runs instead of 64.
+// that the preprocess counted with).  Lane q evaluates and writes the rows q, q+4, ...; the start of a row's run is a prefix
+// over the quad.  A store instruction touches 16 splats' runs instead of 64.
 // A splat's pairs are contiguous (its emit-order slots).
 // Splats with many rows would make their wave wait for one lane: those (more than EMIT_BIG pairs) are handed to the whole
 // wave afterwards, 64 rows at a time (lane = row, wave prefix sum of the row counts).
@@ -379,17 +409,23 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   const bool big = nt > EMIT_BIG;
   if (nt && !big) {
     const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
+    // lane q of the quad evaluates the rows q, q+4, ... (one subtile_row_live per four rows and lane); where a row's run
+    // starts = the pairs of the rows before it: an exclusive prefix over the quad (DPP quad broadcasts) + a running base
     uint32_t pos = off0;
-    int row = 0;
-    for (int sy = max(2 * y0, sy_lo); sy < min(2 * y1, sy_hi) && sy * SUB < H; ++sy, ++row) {
-      int c0, c1;
-      subtile_row_live(cull, sy, W, H, 2 * x0, 2 * x1, c0, c1);
-      if ((row & 3) == q) {
-        uint32_t w = pos;
-        for (int sx = c0; sx < c1; ++sx, ++w)
-          if (w < end && w < cap) { keys[w] = (uint32_t)(sy * gx8 + sx); pair_gauss[w] = id; }
-      }
-      pos += (uint32_t)(c1 - c0);
+    const int s_lo = max(2 * y0, sy_lo), s_hi = min(min(2 * y1, sy_hi), (H + SUB - 1) / SUB);
+    for (int sb = s_lo; sb < s_hi; sb += 4) {                 // trip count is uniform over the quad
+      const int sy = sb + q;
+      int c0 = 0, c1 = 0;
+      if (sy < s_hi) subtile_row_live(cull, sy, W, H, 2 * x0, 2 * x1, c0, c1);
+      const int cnt = c1 - c0;
+      const int n0 = __builtin_amdgcn_update_dpp(0, cnt, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+      const int n1 = __builtin_amdgcn_update_dpp(0, cnt, 0x55, 0xf, 0xf, false);   // [1,1,1,1]
+      const int n2 = __builtin_amdgcn_update_dpp(0, cnt, 0xAA, 0xf, 0xf, false);   // [2,2,2,2]
+      const int n3 = __builtin_amdgcn_update_dpp(0, cnt, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
+      uint32_t w = pos + (uint32_t)((q > 0 ? n0 : 0) + (q > 1 ? n1 : 0) + (q > 2 ? n2 : 0));
+      for (int sx = c0; sx < c1; ++sx, ++w)
+        if (w < end && w < cap) { keys[w] = (uint32_t)(sy * gx8 + sx); pair_gauss[w] = id; }
+      pos += (uint32_t)(n0 + n1 + n2 + n3);
     }
     // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused slots go
     // to the sentinel sub-tile `trash_key` that no kernel renders

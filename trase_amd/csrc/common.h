@@ -268,7 +268,7 @@ struct SortBufs {          // ping-pong storage of one radix sort
 struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
   SortBufs sort;           // depth sort; sorted ids end in sort.vals[0]
   uint32_t* offsets;       // (P) inclusive scan of tiles in depth-rank order
-  uint32_t* block_sums;    // scan partials
+  uint32_t* block_sums;    // scan partials: (P/1024 + 2) of the live sub-tile counts, then as many of the rect areas
 };
 struct PairBuf {           // stage-2 scratch (capacity-sized)
   SortBufs sort;           // vals[] = {spare, bin.pair_slot} arranged by the caller
@@ -322,7 +322,8 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
                      bool vals_are_iota, int* out_idx);
 int radix_passes(int bit_lo, int bit_hi);
 
-int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap);
+int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
+                      const int32_t* radii, int gx, int gy);
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
                       uint2* ranges_to_clear = nullptr);

@@ -80,10 +80,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   Splat o;
   const bool vis = splat_forward<USE_COV, USE_SH>(v, p, sc, q, cv, shl, col, o) && active;
   if (active) radii[i] = vis ? o.radius : 0;
-  // lineage pair count R (tiles of the 16x16 rect) -> one atomic per wave
-  const float rect_area = vis ? (float)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0.f;
-  const float wave_area = wave_sum_lane63(rect_area);
-  if ((threadIdx.x & 63) == 63 && wave_area > 0.f) atomicAdd(&hdr[HDR_R], (uint32_t)wave_area);
+  // (the lineage pair count R is totalled by scan_partial_kernel from radii + centres: no same-address atomics here)
   // live 8x8 sub-tiles inside the rect (exact culling, see gs_math.h)
   uint32_t live = 0;
   const float opac = a.opac[i];

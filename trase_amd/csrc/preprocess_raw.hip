@@ -56,27 +56,87 @@ __device__ __forceinline__ void activate(const RawFwdArgs& a, int i, Activated& 
   o.opac = o.sig;
 }
 
-__device__ __forceinline__ void load_sh_split(const RawFwdArgs& a, int i, float shl[48]) {
-  const int n3 = 3 * ncoef(a.deg);
-  const float* dc = a.f_dc + 3 * (size_t)i;
-  const float* rest = a.f_rest + 45 * (size_t)i;
-  shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
-  // 45 consecutive floats per Gaussian, 4-byte aligned: eleven 16-byte loads + one instead of 45 dword loads (a
-  // wave-wide dword load of a 180-byte-strided array touches 64 lines per instruction either way)
-  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-  float r[48];
-#pragma unroll
-  for (int k4 = 0; k4 < 11; ++k4) {
-    const f4u v = *reinterpret_cast<const f4u*>(rest + 4 * k4);
-    r[4 * k4] = v[0]; r[4 * k4 + 1] = v[1]; r[4 * k4 + 2] = v[2]; r[4 * k4 + 3] = v[3];
-  }
-  r[44] = rest[44];
-#pragma unroll
-  for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? r[k - 3] : 0.f;
+// ---- wave-cooperative access to the [P][45] f_rest rows ------------------------------------------------------------
+// A lane that reads ITS row straight from memory issues twelve 16-byte loads at a 180-byte stride: every instruction
+// touches 64 cache lines and the texture-address unit serialises them (measured: TA busy 45 % of the kernel, VALU 20 %).
+// Instead the wave copies the 64 consecutive rows (11 520 contiguous bytes) with fully coalesced loads into a wave-private
+// LDS slab and each lane reads its row from there (row stride 45 words: odd, conflict-free).
+constexpr int REST_W = 45;
+constexpr int REST_SLAB = 64 * REST_W;                       // floats per wave
+constexpr int REST_Q = REST_SLAB / 4 / 64 + 1;               // 16-byte loads per lane (the last one covers 16 lanes)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+struct RestRegs { float4 q[REST_Q]; };
+
+// issue the loads (rows [row0, row0 + 64) of `base`, clipped to P); `aligned16` is wave-uniform
+__device__ __forceinline__ void rest_rows_load(const float* __restrict__ base, int row0, int P, bool aligned16, RestRegs& r) {
+  const int lane = threadIdx.x & 63;
+  const int nfl = min(64, P - row0) * REST_W;                 // valid floats of this wave's block
+  const float* src = base + (size_t)row0 * REST_W;
+#pragma unroll
+  for (int k = 0; k < REST_Q; ++k) {
+    const int e = 4 * (k * 64 + lane);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aligned16 && e + 3 < nfl) v = *reinterpret_cast<const float4*>(src + e);
+    else {
+      if (e < nfl) v.x = src[e];
+      if (e + 1 < nfl) v.y = src[e + 1];
+      if (e + 2 < nfl) v.z = src[e + 2];
+      if (e + 3 < nfl) v.w = src[e + 3];
+    }
+    r.q[k] = v;
+  }
+}
+
+__device__ __forceinline__ void rest_rows_to_lds(const RestRegs& r, float* slab) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < REST_Q; ++k) {
+    const int e = 4 * (k * 64 + lane);
+    if (e < REST_SLAB) *reinterpret_cast<float4*>(slab + e) = r.q[k];
+  }
+  wave_lds_sync();
+}
+
+// the lane's 16 x 3 coefficients: f_dc from memory (12-byte stride, three lines per instruction), f_rest from the slab
+__device__ __forceinline__ void load_sh_split(const RawFwdArgs& a, int i, const float* slab, float shl[48]) {
+  const int n3 = 3 * ncoef(a.deg);
+  const float* dc = a.f_dc + 3 * (size_t)i;
+  shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
+  const float* row = slab + (threadIdx.x & 63) * REST_W;
+#pragma unroll
+  for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? row[k - 3] : 0.f;
+}
+
+// cooperative store of 64 rows held in a slab (the backward's dL/df_rest)
+__device__ __forceinline__ void rest_rows_store(float* __restrict__ base, int row0, int P, bool aligned16, const float* slab) {
+  const int lane = threadIdx.x & 63;
+  const int nfl = min(64, P - row0) * REST_W;
+  float* dst = base + (size_t)row0 * REST_W;
+#pragma unroll
+  for (int k = 0; k < REST_Q; ++k) {
+    const int e = 4 * (k * 64 + lane);
+    if (e >= REST_SLAB) continue;
+    const float4 v = *reinterpret_cast<const float4*>(slab + e);
+    if (aligned16 && e + 3 < nfl) *reinterpret_cast<float4*>(dst + e) = v;
+    else {
+      if (e < nfl) dst[e] = v.x;
+      if (e + 1 < nfl) dst[e + 1] = v.y;
+      if (e + 2 < nfl) dst[e + 2] = v.z;
+      if (e + 3 < nfl) dst[e + 3] = v.w;
+    }
+  }
+}
+
+constexpr int RAW_BLOCK = 64;                                // one wave per workgroup: 11.5 KB of LDS each
+
 template <int F>
-__global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
+__global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
                                                                  float2* __restrict__ xy, float4* __restrict__ conic_o,
                                                                  float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
                                                                  uint32_t* __restrict__ clamped,
@@ -86,19 +146,23 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
   if (gi == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;
   const bool active = gi < a.P;
   const int i = active ? gi : a.P - 1;
+  __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
+  float* const slab = slabs[threadIdx.x >> 6];
+  const int row0 = gi & ~63;                                  // first Gaussian of this wave (< P: the grid is ceil(P / 64) waves)
+  const bool rest16 = ((reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0);
+  RestRegs rr;
+  rest_rows_load(a.f_rest, row0, a.P, rest16, rr);
   View v;
   raw_view(a, v);
   Activated act;
   activate(a, i, act);
+  rest_rows_to_lds(rr, slab);
   float shl[48];
-  load_sh_split(a, i, shl);
+  load_sh_split(a, i, slab, shl);
   const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
   Splat o;
   const bool vis = splat_forward<false, true>(v, act.p, act.sc, act.q, cv, shl, col, o) && active;
   if (active) radii[i] = vis ? o.radius : 0;
-  const float rect_area = vis ? (float)((o.x1 - o.x0) * (o.y1 - o.y0)) : 0.f;
-  const float wave_area = wave_sum_lane63(rect_area);
-  if ((threadIdx.x & 63) == 63 && wave_area > 0.f) atomicAdd(&hdr[HDR_R], (uint32_t)wave_area);
   uint32_t live = 0;
   if (vis) {
     const SubtileCull cull = subtile_cull_setup(o.px, o.py, o.ca, o.cb, o.cc, act.opac);
@@ -119,17 +183,35 @@ __global__ __launch_bounds__(256) void preprocess_fwd_raw_kernel(RawFwdArgs a, i
     rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }
-  // feature row the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121)
-  if (F > 0 && active && vis && live) {
-    const float4* src = reinterpret_cast<const float4*>(a.features + (size_t)i * F);
-    float4 r[F > 0 ? F / 4 : 1];
-    float n2 = 0.f;
+  // feature rows the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121).  F / 4 lanes per
+  // Gaussian, one float4 each: the wave's 64 rows are read and written as contiguous 1 KB runs; the squared norm is summed
+  // over the lane group with DPP (quad swaps + half-row mirror).
+  if constexpr (F > 0) {
+    constexpr int LPG = F / 4, GPI = 64 / LPG;               // lanes per Gaussian, Gaussians per wave-wide access
+    static_assert(LPG == 4 || LPG == 8, "feature width 16 or 32");
+    const unsigned long long need = __ballot(active && vis && live);
+    const int lane = threadIdx.x & 63;
+    float4 r[LPG];
+    bool on[LPG];
 #pragma unroll
-    for (int k = 0; k < F / 4; ++k) { r[k] = src[k]; n2 += r[k].x * r[k].x + r[k].y * r[k].y + r[k].z * r[k].z + r[k].w * r[k].w; }
-    const float s = a.norm_features ? 1.0f / (sqrtf(n2) + 1e-9f) : 1.0f;
-    float4* dst = reinterpret_cast<float4*>(a.featn + (size_t)i * F);
+    for (int k = 0; k < LPG; ++k) {
+      const int gl = k * GPI + lane / LPG;
+      on[k] = (need >> gl) & 1ull;
+      r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (on[k]) r[k] = reinterpret_cast<const float4*>(a.features + (size_t)(row0 + gl) * F)[lane % LPG];
+    }
 #pragma unroll
-    for (int k = 0; k < F / 4; ++k) dst[k] = make_float4(r[k].x * s, r[k].y * s, r[k].z * s, r[k].w * s);
+    for (int k = 0; k < LPG; ++k) {
+      float n2 = r[k].x * r[k].x + r[k].y * r[k].y + r[k].z * r[k].z + r[k].w * r[k].w;
+      n2 += dpp_f<0xB1>(n2);                                  // quad_perm [1,0,3,2]
+      n2 += dpp_f<0x4E>(n2);                                  // quad_perm [2,3,0,1]
+      if (LPG == 8) n2 += dpp_f<0x141>(n2);                   // row_half_mirror: the other quad of the 8-lane group
+      const float sc = a.norm_features ? 1.0f / (sqrtf(n2) + 1e-9f) : 1.0f;
+      const int gl = k * GPI + lane / LPG;
+      if (on[k])
+        reinterpret_cast<float4*>(a.featn + (size_t)(row0 + gl) * F)[lane % LPG] =
+            make_float4(r[k].x * sc, r[k].y * sc, r[k].z * sc, r[k].w * sc);
+    }
   }
 }
 
@@ -143,7 +225,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
   strip_subtile_rows(s, a.sy_lo, a.sy_hi);
-  const dim3 grid((raw.P + 255) / 256), block(256);
+  const dim3 grid((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), block(RAW_BLOCK);
   {
     ProfScope ps("preprocess_fwd", c.stream);
 #define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr)
@@ -165,12 +247,22 @@ struct RawBwdOut {
   float* d_scaling; float* d_dscaling; float* d_rotation; float* d_drotation;
 };
 
-__global__ __launch_bounds__(256) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
-                                                                 const uint32_t* __restrict__ clamped,
-                                                                 const float* __restrict__ acc, RawBwdOut o) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.P) return;
-  const bool vis = radii[i] > 0;
+__global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
+                                                                       const uint32_t* __restrict__ clamped,
+                                                                       const float* __restrict__ acc, RawBwdOut o) {
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = gidx < a.P;                               // no early return: the wave moves the f_rest rows together
+  const int i = active ? gidx : a.P - 1;
+  const bool vis = active && radii[i] > 0;
+  __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
+  float* const slab = slabs[threadIdx.x >> 6];
+  const int row0 = gidx & ~63;
+  const bool wave_vis = __ballot(vis) != 0ull;
+  if (wave_vis) {
+    RestRegs rr;
+    rest_rows_load(a.f_rest, row0, a.P, (reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0, rr);
+    rest_rows_to_lds(rr, slab);
+  }
   SplatGradOut go;
   float dsh[48];
 #pragma unroll
@@ -199,11 +291,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_raw_kernel(RawFwdArgs a, c
     raw_view(a, v);
     activate(a, i, act);
     float shl[48];
-    load_sh_split(a, i, shl);
+    load_sh_split(a, i, slab, shl);
     const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     splat_backward<false, true>(v, act.p, act.sc, act.q, cv, shl, clamped[i], gi, go, dsh);
   }
   // chain through the activations
+  if (active) {
   if (o.d_xyz) { o.d_xyz[3 * i] = go.d_p[0]; o.d_xyz[3 * i + 1] = go.d_p[1]; o.d_xyz[3 * i + 2] = go.d_p[2]; }
   if (o.d_dxyz) { o.d_dxyz[3 * i] = go.d_p[0]; o.d_dxyz[3 * i + 1] = go.d_p[1]; o.d_dxyz[3 * i + 2] = go.d_p[2]; }
   if (o.d_means2D) { o.d_means2D[3 * i] = gi.d_ndcx; o.d_means2D[3 * i + 1] = gi.d_ndcy; o.d_means2D[3 * i + 2] = 0.f; }
@@ -222,13 +315,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_raw_kernel(RawFwdArgs a, c
                     (go.d_quat[2] - act.qn[2] * dot) * act.inv_n, (go.d_quat[3] - act.qn[3] * dot) * act.inv_n);
   }
   if (o.d_f_dc) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
+  }
   if (o.d_f_rest) {
-    float* dst = o.d_f_rest + 45 * (size_t)i;
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 180-byte rows: 4-byte aligned 16-byte stores
+    // 180-byte rows: through the wave's slab (each lane rewrites ITS row, already consumed above), then contiguous stores
+    float* row = slab + (threadIdx.x & 63) * REST_W;
 #pragma unroll
-    for (int k4 = 0; k4 < 11; ++k4)
-      *reinterpret_cast<f4u*>(dst + 4 * k4) = f4u{dsh[3 + 4 * k4], dsh[4 + 4 * k4], dsh[5 + 4 * k4], dsh[6 + 4 * k4]};
-    dst[44] = dsh[47];
+    for (int k = 0; k < REST_W; ++k) row[k] = dsh[3 + k];
+    wave_lds_sync();
+    rest_rows_store(o.d_f_rest, row0, a.P, (reinterpret_cast<uintptr_t>(o.d_f_rest) & 15) == 0, slab);
   }
 }
 
@@ -248,7 +342,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((raw.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped, acc, o);
+    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, acc, o);
   }
   TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
   return TRASE_OK;
