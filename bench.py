@@ -122,6 +122,13 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference's PyTorch prep ops around GaussianRasterizer instead of the fused render()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-chunks", type=int, default=1,
+                    help="Gaussian-index ranges of the overlapped gradient exchange (sink bucket): the all-reduce of a range "
+                         "starts while the backward's per-Gaussian tail is still computing the next one; 1 (default) = one "
+                         "all-reduce after the backward.  Every extra range costs ~0.025 ms of kernel ramp/tail at S4 "
+                         "(measured at N=1), so this only pays where the exchange is long compared with that")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N=1 only: create a one-rank RCCL process group and issue the exchange collectives anyway")
     ap.add_argument("--bucket", choices=["auto", "sink", "accumulate"], default="auto",
                     help="gradient bucket of the N>1 exchange step; 'sink' / 'accumulate' force it on at N=1 (for timing the "
                          "bucket handling alone: the all-reduce is a no-op there)")
@@ -158,6 +165,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+    elif args.force_collectives:
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     if args.variant is not None:
         R.set_variant(args.variant)
 
@@ -177,7 +191,10 @@ def main():
     if use_sink:
         # the fused backward writes every gradient once, straight into the bucket: no zero-fill, no accumulation pass
         from trase_amd.renderer import set_grad_sink
-        set_grad_sink(bucket.sink())
+        if args.exchange_chunks > 1:
+            set_grad_sink(**bucket.overlapped(args.exchange_chunks, force_collectives=args.force_collectives))
+        else:
+            set_grad_sink(bucket.sink())
 
     n_views = 16
     cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
@@ -276,7 +293,7 @@ def main():
         # HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 note of MI355X_MICROARCH.md; VALU wave-instructions
         traffic = valu_insts = mfma_insts = None
         tpath = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (N, W, H, F) == (300_000, 1920, 1080, 32) and not args.unfused:   # collected on S4 only
             try:
                 rec = json.load(open(tpath)).get(dom) or {}
                 traffic, valu_insts, mfma_insts = rec.get("hbm_bytes"), rec.get("valu_insts"), rec.get("mfma_insts")
@@ -298,7 +315,12 @@ def main():
                        "subtile_pairs_mean": round(reff_mean),
                        "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant,
                        "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
-                                else "gaussian_renderer.render() drop-in, A1 prep fused"},
+                                else "gaussian_renderer.render() drop-in, A1 prep fused",
+                       "exchange": (None if bucket is None else
+                                    f"flat bucket {bucket.bytes_per_step} B/step, "
+                                    + ("zero + accumulate" if not use_sink else
+                                       (f"sink, all-reduce in {args.exchange_chunks} Gaussian ranges overlapped with the backward tail"
+                                        if args.exchange_chunks > 1 else "sink, one all-reduce after the backward")))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "valu_frac": None if valu_frac is None else round(valu_frac, 4), "valu_insts": valu_insts,
@@ -337,8 +359,13 @@ def main():
                                         "sample": f"float64 oracle fwd+bwd on view 0: all {N} Gaussians preprocessed, "
                                                   f"{pairs} of {r_cpu} (tile,Gaussian) pairs composited (every "
                                                   f"{args.cpu_tile_step}th tile, {dt:.1f} s measured, extrapolated by pair count)"}
+        try:                                   # RCCL prints its version banner through C stdio: get it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

@@ -59,7 +59,11 @@ typedef struct TraseRastSettings {
   int32_t prefiltered;
   int32_t debug;           /* !=0: synchronise + check after every kernel */
   int32_t device;          /* HIP device ordinal of all pointers and of `stream` */
-  int32_t variant;         /* kernel variant selector for A/B ablation; 0 = default */
+  int32_t variant;         /* kernel variant selector for A/B ablation; 0 = default.  Bits: 0x1 first-generation lane = pixel
+                            * backward with atomics; 0x40 VALU-only backward for every F; 0x100 dL_ddepth is honoured;
+                            * 0x200 point-list gather fused into tile_ranges; 0x400 feature-only backward;
+                            * 0x800 round-1 64-entry-chunk MFMA backward; 0x1000 timing instrumentation of the backward;
+                            * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch) */
   /* Tile-row strip (second multi-GPU axis, SURVEY.md 8e: one view sharded over ranks by rows of 16x16 tiles).  Rows
    * [tile_row_begin, tile_row_end) are binned, composited and differentiated; pixels outside the strip are not written,
    * per-Gaussian gradients are this strip's partial sums (the ranks' strips add up to the full gradient), radii stay
@@ -200,6 +204,20 @@ int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* 
                           const TraseRastWorkspace* ws, trase_stream_t stream);
 int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                             const TraseRastWorkspace* ws, const TraseRastRawGrads* g, trase_stream_t stream);
+
+/* The same backward in two phases, for a view-parallel caller that starts exchanging the gradients of the first Gaussians
+ * while the last ones are still being reduced (trase_amd/dp.py; the reference is single-process, train.py:303):
+ *   _compose    the compositing backward over every sub-tile -- one gradient row per (sub-tile, Gaussian) pair in the
+ *               workspace, no per-Gaussian output yet (only dL_dgaussian_features is zero-filled when dL_dfeats is NULL);
+ *   _gaussians  the per-Gaussian tail for the ids [p_begin, p_end): sums their pair rows and writes THEIR entries of every
+ *               gradient tensor in `g` (same pointers as for the whole call: the tensors' bases).  p_begin must be a
+ *               multiple of 64, p_end a multiple of 64 or P.
+ * _compose followed by _gaussians over a partition of [0, P) equals trase_rast_backward_raw bit for bit. */
+int trase_rast_backward_raw_compose(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                                    const TraseRastWorkspace* ws, const TraseRastRawGrads* g, trase_stream_t stream);
+int trase_rast_backward_raw_gaussians(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                                      const TraseRastWorkspace* ws, const TraseRastRawGrads* g, int32_t p_begin, int32_t p_end,
+                                      trase_stream_t stream);
 
 /* simple_knn._C.distCUDA2 (scene/gaussian_model.py:237): mean squared distance
  * to the 3 nearest neighbours.  ws_bytes from trase_knn_sizes. */

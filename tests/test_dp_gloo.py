@@ -146,3 +146,62 @@ def test_state_aware_bucket_sizes():
     assert FlatGradBucket.for_state(pc, "feature").bytes_per_step == 128 * n
     mlp = [torch.zeros(256, 84, requires_grad=True), torch.zeros(256, requires_grad=True)]
     assert FlatGradBucket.for_state(pc, "GAUSSIAN", extra=mlp).bytes_per_step == 236 * n + 4 * (256 * 84 + 256)
+
+
+class _WritesIntoSinkInRanges(torch.autograd.Function):
+    """Stands in for the fused backward in its range-by-range mode (trase_amd.renderer._RenderRaw with
+    set_grad_sink(chunks=..., on_chunk=...)): the rows [a, b) of every sink buffer are written, then the hook is called."""
+
+    @staticmethod
+    def forward(ctx, kw, scale, *params):
+        ctx.kw, ctx.scale = kw, scale
+        ctx.save_for_backward(*params)
+        return sum((p * p).sum() for p in params) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        from trase_amd.renderer import chunk_ranges
+        params = ctx.saved_tensors
+        sink, hook = ctx.kw["sink"], ctx.kw["on_chunk"]
+        P = params[0].shape[0]
+        bufs = [sink[id(p)][1] for p in params]
+        for a, b in chunk_ranges(P, ctx.kw["chunks"]):
+            for p, buf in zip(params, bufs):
+                buf[a:b] = 2 * p.detach()[a:b] * ctx.scale * g
+            hook(a, b, P, {id(p) for p in params})
+        return (None, None) + tuple(buf.view(buf.shape) for buf in bufs)
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket
+    torch.manual_seed(0)
+    P = 300
+    gauss = [torch.randn(P, 3, requires_grad=True), torch.randn(P, 1, 32, requires_grad=True), torch.randn(P, requires_grad=True)]
+    mlp = [torch.randn(7, 5, requires_grad=True), torch.randn(P, requires_grad=True)]   # the second LOOKS per-Gaussian but
+    bucket = FlatGradBucket(gauss[:2] + [mlp[0]] + gauss[2:] + [mlp[1]])              # never goes through the sink
+    kw = bucket.overlapped(3)
+    ok = True
+    for step in range(2):
+        bucket.detach_grads()
+        scale = float(rank + 1 + step)
+        loss = _WritesIntoSinkInRanges.apply(kw, scale, *gauss) + sum((m * m).sum() for m in mlp) * scale
+        loss.backward()
+        ok = ok and len(bucket._pending) > 0 and not bucket._owns(mlp[0].grad)
+        bucket.allreduce()
+        tot = float(sum(r + 1 + step for r in range(world)))
+        for p in gauss + mlp:
+            ok = ok and torch.allclose(p.grad, 2 * p.detach() * tot) and bucket._owns(p.grad)
+        ok = ok and bucket._pending == []
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_overlapped_range_exchange_plus_the_rest_equals_one_allreduce():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

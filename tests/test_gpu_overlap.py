@@ -1,0 +1,102 @@
+"""The backward in two phases (trase_rast_backward_raw_compose + _gaussians over Gaussian-index ranges) and the overlapped
+gradient exchange built on it (trase_amd.dp.FlatGradBucket.overlapped; SURVEY.md 8e, the reference is single-process).
+On the one-GPU box: the ranges reproduce the one-call backward bit for bit, and the exchange runs through a one-rank RCCL
+process group (the collectives are issued for real; summing over one rank must leave the gradients untouched)."""
+import math
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n=20000, seed=3):
+    from trase_amd.synthetic import make_scene, SynthGaussianModel, SynthPipe, orbit_camera
+    dev = torch.device("cuda", 0)
+    pc = SynthGaussianModel(make_scene(n, feat_dim=32, seed=seed).to(dev))
+    cam = orbit_camera(320, 200, angle=0.4, fid=0.25).to(dev)
+    return pc, SynthPipe(), cam, dev
+
+
+def _backward(pc, pipe, cam, dev, seed=11):
+    from gaussian_renderer import render
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = render(cam, pc, pipe, torch.zeros(3, device=dev), 0.0, 0.0, 0.0)
+    gi = torch.randn(out["render"].shape, generator=g).to(dev)
+    gf = torch.randn(out["render_gaussian_features"].shape, generator=g).to(dev)
+    torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])
+
+
+def test_chunk_ranges_partition():
+    from trase_amd.renderer import chunk_ranges
+    for P in (1, 63, 64, 65, 1000, 300000):
+        for k in (1, 2, 4, 7, 100000):
+            r = chunk_ranges(P, k)
+            assert r[0][0] == 0 and r[-1][1] == P and len(r) <= k
+            assert all(a % 64 == 0 for a, _ in r)
+            assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
+            assert all(b > a for a, b in r)
+
+
+@pytest.mark.parametrize("chunks", [2, 4, 7])
+def test_ranged_tail_equals_the_single_call_bit_for_bit(chunks):
+    from trase_amd.dp import FlatGradBucket
+    from trase_amd.renderer import set_grad_sink
+    pc, pipe, cam, dev = _scene()
+    params = pc.parameters()
+    for p in params:
+        p.grad = None
+    _backward(pc, pipe, cam, dev)
+    ref = [p.grad.clone() for p in params]
+    bucket = FlatGradBucket(params)
+    calls = []
+    kw = bucket.overlapped(chunks)
+    hook = kw["on_chunk"]
+    kw["on_chunk"] = lambda a, b, P, ids: (calls.append((a, b, P, set(ids))), hook(a, b, P, ids))
+    try:
+        set_grad_sink(**kw)
+        bucket.detach_grads()
+        _backward(pc, pipe, cam, dev)
+        bucket.allreduce()
+    finally:
+        set_grad_sink(None)
+    P = params[0].shape[0]
+    assert [c[:2] for c in calls] == [tuple(x) for x in __import__("trase_amd.renderer", fromlist=["x"]).chunk_ranges(P, chunks)]
+    assert all(c[3] == {id(p) for p in params} for c in calls)          # every parameter's buffer came from the sink
+    assert bucket.adopted()
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r)
+
+
+def test_overlapped_exchange_through_a_one_rank_rccl_group():
+    import torch.distributed as dist
+    from trase_amd.dp import FlatGradBucket
+    from trase_amd.renderer import set_grad_sink
+    pc, pipe, cam, dev = _scene(n=30000, seed=5)
+    params = pc.parameters()
+    for p in params:
+        p.grad = None
+    _backward(pc, pipe, cam, dev)
+    ref = [p.grad.clone() for p in params]
+    extra = torch.nn.Parameter(torch.randn(1000, device=dev))          # stands in for the deformation MLP: never chunked
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        bucket = FlatGradBucket(list(params) + [extra])
+        set_grad_sink(**bucket.overlapped(4, force_collectives=True))
+        for _ in range(2):                                              # twice: the per-step state is reset properly
+            bucket.detach_grads()
+            _backward(pc, pipe, cam, dev)
+            extra.grad = torch.full_like(extra, 2.0)                     # a gradient that arrives outside the sink
+            assert len(bucket._pending) >= 1                             # the ranges' collectives are in flight
+            bucket.allreduce()
+            torch.cuda.synchronize()
+            for p, r in zip(params, ref):
+                assert torch.equal(p.grad, r)
+            assert torch.equal(extra.grad, torch.full_like(extra, 2.0)) and bucket.adopted()
+    finally:
+        set_grad_sink(None)
+        dist.destroy_process_group()

@@ -124,6 +124,11 @@ SYMBOLS = [
                                         C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_backward_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                           C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_void_p]),
+    ("trase_rast_backward_raw_compose", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                                  C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_void_p]),
+    ("trase_rast_backward_raw_gaussians", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                                    C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_int32, C.c_int32,
+                                                    C.c_void_p]),
     ("trase_knn_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     ("trase_knn_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_knn_points", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

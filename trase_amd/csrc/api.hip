@@ -99,7 +99,7 @@ static size_t sort_bytes_common(size_t n) {   // hist + digit_total
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 5 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2) + sort_bytes_common(p);
+  return align_up(sizeof(uint32_t) * p) * 6 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2) + sort_bytes_common(p);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -108,6 +108,7 @@ PreBuf carve_pre(void* ptr, int P) {
   for (int i = 0; i < 2; ++i) { t.sort.keys[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   for (int i = 0; i < 2; ++i) { t.sort.vals[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   t.offsets = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
+  t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2);
   t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
@@ -420,8 +421,11 @@ int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* 
   return trase_rast_render(s, &in, out, ws, stream);
 }
 
-int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
-                            const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream_) {
+// The raw backward in two phases (see include/trase_rast.h): phase & 1 = compositing backward over every sub-tile (one
+// gradient row per pair), phase & 2 = per-Gaussian tail over the ids [p_begin, p_end).
+static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                               const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream_, int phase,
+                               int p_begin, int p_end) {
   int rc = validate_raw(s, raw);
   if (rc) return rc;
   if (!gr || !out || (raw->P > 0 && !out->radii)) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
@@ -429,6 +433,11 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
   rc = check_ws(&in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG);
   if (rc) return rc;
   if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in.P, in.F, ws->capacity)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
+  const bool ranged = p_begin >= 0;
+  if (ranged && (p_begin % 64 != 0 || p_end > raw->P || p_end < p_begin || (p_end != raw->P && p_end % 64 != 0))) {
+    set_error("backward_raw_gaussians: [%d, %d) must start on a multiple of 64 and end on one or at P = %d", p_begin, p_end, raw->P);
+    return TRASE_ERR_INVALID;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(s->device));
   LaunchCtx c{stream, s->debug, s->variant};
@@ -447,22 +456,48 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
   g2.dL_dimage = gr->dL_dimage; g2.dL_dfeats = gr->dL_dfeats;
   g2.dL_ddepth = (s->variant & 0x100) ? gr->dL_ddepth : nullptr;
   float* d_feats = gr->dL_dgaussian_features;
-  if (!g2.dL_dfeats) {
-    if (d_feats && raw->F > 0) TRASE_CHECK(hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
+  const bool no_feat_cotangent = !g2.dL_dfeats;
+  if (no_feat_cotangent) {
     in.F = 0;
     d_feats = nullptr;
   }
-  if (in.F == 32 && !(s->variant & 0x40)) {
-    rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
-                              : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
-  } else {
-    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-    rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+  if (phase & 1) {
+    if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0)
+      TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
+    if (in.F == 32 && !(s->variant & 0x40)) {
+      rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
+                                : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+    } else {
+      TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+      rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+    }
+    if (rc) return rc;
   }
-  if (rc) return rc;
-  rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features);
-  if (rc) return rc;
-  return launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr);
+  if (phase & 2) {
+    const bool by_id_all = !ranged && (s->variant & 0x4000);       // experiment: id order in one launch
+    rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features,
+                            ranged ? p_begin : (by_id_all ? 0 : -1), ranged ? p_end : (by_id_all ? raw->P : -1));
+    if (rc) return rc;
+    rc = launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr, ranged ? p_begin : 0, ranged ? p_end : raw->P);
+  }
+  return rc;
+}
+
+int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                            const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream) {
+  return backward_raw_phases(s, raw, out, ws, gr, stream, 3, -1, -1);
+}
+
+int trase_rast_backward_raw_compose(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                                    const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream) {
+  return backward_raw_phases(s, raw, out, ws, gr, stream, 1, -1, -1);
+}
+
+int trase_rast_backward_raw_gaussians(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                                      const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, int32_t p_begin,
+                                      int32_t p_end, trase_stream_t stream) {
+  if (p_begin < 0) { set_error("backward_raw_gaussians: negative range start"); return TRASE_ERR_INVALID; }
+  return backward_raw_phases(s, raw, out, ws, gr, stream, 2, p_begin, p_end);
 }
 
 int trase_prof_enable(int enable) {

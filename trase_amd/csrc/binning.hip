@@ -16,7 +16,10 @@
 namespace trase {
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;
+#ifndef TRASE_RS_ITEMS
+#define TRASE_RS_ITEMS 8
+#endif
+constexpr int RS_ITEMS = TRASE_RS_ITEMS;
 constexpr int RS_WAVES = RS_THREADS / WAVE;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 2048 items per workgroup
 constexpr int RS_SEG = WAVE * RS_ITEMS;          // 512 contiguous items per wave
@@ -341,13 +344,19 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __restrict__ offsets, int P,
-                                                                const uint32_t* __restrict__ block_sums) {
+                                                                const uint32_t* __restrict__ block_sums,
+                                                                const uint32_t* __restrict__ ids,
+                                                                uint32_t* __restrict__ id_end) {
   const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
   const uint32_t add = block_sums[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int r = base + i;
-    if (r < P) offsets[r] += add;
+    if (r < P) {
+      const uint32_t e = offsets[r] + add;
+      offsets[r] = e;
+      id_end[ids[r]] = e;        // the per-Gaussian tail of the backward walks ids, not depth ranks
+    }
   }
 }
 
@@ -360,7 +369,8 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, sorted_ids, P,
                        t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums, sorted_ids,
+                       t.id_end);
   }
   TRASE_POST_LAUNCH("scan_tiles", c.stream, c.debug);
   return TRASE_OK;
@@ -511,10 +521,10 @@ int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint3
 // its rows (ROW/4 <= 11 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
 // of dependent loads (rank -> id -> pair range -> flags -> rows) is paid once per four Gaussians.  Writes every
 // Gaussian (zeros where it has no pairs), so neither output needs a memset and the sums are bit-reproducible.
-template <int ROW>
+template <int ROW, bool BY_ID>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ tiles, int P,
+                                                          const uint32_t* __restrict__ tiles, int p_begin, int P,
                                                           const uint32_t* __restrict__ hdr,
                                                           const float* __restrict__ rows,
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
@@ -523,9 +533,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
   constexpr int F = ROW - 12, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
-  const int r = (blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
+  // BY_ID: `offsets` is PreBuf::id_end and the groups walk the Gaussian ids [p_begin, P) -- the gradients of an id range
+  // are then complete (and can be exchanged) before the rest is reduced; otherwise depth ranks [0, P) through sorted_ids
+  const int r = p_begin + (blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
   const bool live = r < P;
-  const uint32_t id = live ? sorted_ids[r] : 0;
+  const uint32_t id = live ? (BY_ID ? (uint32_t)r : sorted_ids[r]) : 0;
   uint32_t k0 = 0, k1 = 0;
   if (live) {
     const uint32_t nt = tiles[id];
@@ -590,16 +602,32 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
 }
 
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
-                       const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats, int norm_features) {
-  const int blocks = (P + 15) / 16;                  // 4 waves x 4 Gaussians per block
+                       const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats, int norm_features,
+                       int id_begin, int id_end) {
+  // id_begin < 0: every Gaussian, in depth-rank order (its rows are then read front to back); otherwise the ids
+  // [id_begin, id_end) only
+  const bool by_id = id_begin >= 0;
+  const int first = by_id ? id_begin : 0, last = by_id ? id_end : P;
+  if (last <= first) return TRASE_OK;
+  const int blocks = (last - first + 15) / 16;       // 4 waves x 4 Gaussians per block
   {
     ProfScope ps("reduce_rows", c.stream);
+#define TRASE_RR(ROW)                                                                                                         \
+  do {                                                                                                                        \
+    if (by_id)                                                                                                                \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, true>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
+                         g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features);               \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
+                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features);  \
+  } while (0)
     switch (F) {
-      case 0: hipLaunchKernelGGL(reduce_rows_kernel<12>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
-      case 16: hipLaunchKernelGGL(reduce_rows_kernel<28>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
-      case 32: hipLaunchKernelGGL(reduce_rows_kernel<44>, dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.offsets, g.tiles, P, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features); break;
+      case 0: TRASE_RR(12); break;
+      case 16: TRASE_RR(28); break;
+      case 32: TRASE_RR(44); break;
       default: set_error("reduce_rows: feature width %d not compiled in", F); return TRASE_ERR_UNSUPPORTED;
     }
+#undef TRASE_RR
   }
   TRASE_POST_LAUNCH("reduce_rows", c.stream, c.debug);
   return TRASE_OK;

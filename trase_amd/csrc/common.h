@@ -268,6 +268,7 @@ struct SortBufs {          // ping-pong storage of one radix sort
 struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
   SortBufs sort;           // depth sort; sorted ids end in sort.vals[0]
   uint32_t* offsets;       // (P) inclusive scan of tiles in depth-rank order
+  uint32_t* id_end;        // (P) the same, indexed by Gaussian id: the pairs of Gaussian i are [id_end[i] - tiles[i], id_end[i])
   uint32_t* block_sums;    // scan partials: (P/1024 + 2) of the live sub-tile counts, then as many of the rect areas
 };
 struct PairBuf {           // stage-2 scratch (capacity-sized)
@@ -313,8 +314,10 @@ int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const 
 
 int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
                               const GeomBuf& g, uint32_t* depth_keys);
+// Gaussians [p_begin, p_end) only (p_begin a multiple of 64; p_end = P or a multiple of 64)
 int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
-                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr);
+                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr,
+                              int p_begin = 0, int p_end = -1);
 
 // stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
@@ -332,7 +335,7 @@ int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint3
 // raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
-                       int norm_features = 0);
+                       int norm_features = 0, int id_begin = -1, int id_end = -1);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg = nullptr, bool clear = true);
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,

@@ -22,6 +22,7 @@ struct RawFwdArgs {
   int P, F, deg, W, H, norm_features;
   float tanx, tany, mod;
   int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
+  int p_begin, p_end;        // backward only: the Gaussians [p_begin, p_end) (p_begin a multiple of 64)
 };
 
 __device__ __forceinline__ void raw_view(const RawFwdArgs& a, View& v) {
@@ -225,6 +226,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
   strip_subtile_rows(s, a.sy_lo, a.sy_hi);
+  a.p_begin = 0; a.p_end = raw.P;
   const dim3 grid((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), block(RAW_BLOCK);
   {
     ProfScope ps("preprocess_fwd", c.stream);
@@ -250,8 +252,8 @@ struct RawBwdOut {
 __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
                                                                        const uint32_t* __restrict__ clamped,
                                                                        const float* __restrict__ acc, RawBwdOut o) {
-  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = gidx < a.P;                               // no early return: the wave moves the f_rest rows together
+  const int gidx = a.p_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = gidx < a.p_end;                               // no early return: the wave moves the f_rest rows together
   const int i = active ? gidx : a.P - 1;
   const bool vis = active && radii[i] > 0;
   __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
@@ -322,13 +324,17 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArg
 #pragma unroll
     for (int k = 0; k < REST_W; ++k) row[k] = dsh[3 + k];
     wave_lds_sync();
-    rest_rows_store(o.d_f_rest, row0, a.P, (reinterpret_cast<uintptr_t>(o.d_f_rest) & 15) == 0, slab);
+    rest_rows_store(o.d_f_rest, row0, a.p_end, (reinterpret_cast<uintptr_t>(o.d_f_rest) & 15) == 0, slab);
   }
 }
 
 int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
-                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr) {
+                              const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr,
+                              int p_begin, int p_end) {
+  if (p_end < 0) p_end = raw.P;
+  if (p_end <= p_begin) return TRASE_OK;
   RawFwdArgs a;
+  a.p_begin = p_begin; a.p_end = p_end;
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
   a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
   a.features = raw.gaussian_features; a.featn = raw.featn;
@@ -342,7 +348,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, acc, o);
+    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, acc, o);
   }
   TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
   return TRASE_OK;

@@ -99,12 +99,84 @@ class FlatGradBucket:
                 fixed += 1
         return fixed
 
+    # ---- overlapped exchange -------------------------------------------------------------------------------------------
+    def overlapped(self, chunks: int = 4, force_collectives: bool = False):
+        """Keyword arguments for ``trase_amd.renderer.set_grad_sink``: the sink plus a per-range hook.  The fused backward
+        then finishes the gradients of one Gaussian-index range after the other (``trase_rast_backward_raw_gaussians``)
+        and this bucket starts the all-reduce of a range -- the matching rows of every per-Gaussian tensor that was
+        written through the sink, one coalesced collective per range -- as soon as the range is in the stream: the
+        exchange of the first ranges runs (on the process group's own stream) while the tail of the backward is still
+        computing the last ones.  ``allreduce()`` afterwards waits for the ranges and reduces only what was NOT exchanged
+        that way (e.g. the deformation MLP's parameters).  One fused backward per ``allreduce()``.
+        ``force_collectives``: issue the collectives even in a world of one rank (tests)."""
+        self._force = bool(force_collectives)
+        self._pending: list = []
+        self._exchanged: set = set()
+        return dict(sink=self.sink(), chunks=int(chunks), on_chunk=self._on_chunk)
+
+    def _collectives_on(self) -> bool:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or getattr(self, "_force", False)
+
+    @staticmethod
+    def _reduce_many(tensors):
+        """One grouped all-reduce (SUM) of several tensors, asynchronous; returns the handles to wait on."""
+        import torch.distributed as dist
+        if not tensors:
+            return []
+        if dist.get_backend() == "nccl" and hasattr(dist, "_coalescing_manager"):
+            with dist._coalescing_manager(device=tensors[0].device, async_ops=True) as cm:      # one ncclGroup
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [cm]
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in tensors]
+
+    def _on_chunk(self, p_begin: int, p_end: int, P: int, used_ids):
+        """Hook of the fused backward: the entries [p_begin, p_end) of every sink buffer in ``used_ids`` are final in
+        stream order."""
+        if p_begin == 0:
+            self._exchanged = set()
+        if not self._collectives_on():
+            return
+        slices = []
+        for p, v in zip(self.params, self._views):
+            if id(p) in used_ids and p.dim() >= 1 and p.shape[0] == P:
+                slices.append(v[p_begin:p_end])              # rows of a contiguous tensor: contiguous
+                if p_end == P:
+                    self._exchanged.add(id(p))
+        self._pending.extend(self._reduce_many(slices))
+
     def allreduce(self, average: bool = False):
         import torch.distributed as dist
+        pending, exchanged = getattr(self, "_pending", []), getattr(self, "_exchanged", set())
+        for w in pending:
+            w.wait()                                         # the current stream waits for the ranges' collectives
+        self._pending, self._exchanged = [], set()
+        # a range exchange only counts for a parameter whose gradient still IS the bucket view it was written to
+        done = {id(p) for p, v in zip(self.params, self._views)
+                if id(p) in exchanged and p.grad is not None and p.grad.data_ptr() == v.data_ptr()}
         self.gather_grads()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._collectives_on():
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if not done:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        else:
+            # what the ranges did not cover, as maximal contiguous runs of the flat buffer
+            runs, off, start = [], 0, None
+            for p in self.params:
+                if id(p) in done:
+                    if start is not None:
+                        runs.append(self.flat[start:off])
+                        start = None
+                elif start is None:
+                    start = off
+                off += p.numel()
+            if start is not None:
+                runs.append(self.flat[start:off])
+            for w in self._reduce_many(runs):
+                w.wait()
         if average:
             self.flat.div_(dist.get_world_size())
 

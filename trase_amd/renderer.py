@@ -37,16 +37,39 @@ def set_backward_scope(scope: str = "all") -> None:
 
 
 _GRAD_SINK: dict = {}
+_GRAD_CHUNKS = None        # (number of Gaussian-index chunks, callback(p_begin, p_end, P)) of the overlapped exchange
 
 
-def set_grad_sink(sink=None) -> None:
+def set_grad_sink(sink=None, chunks: int = 1, on_chunk=None) -> None:
     """``sink``: {id(parameter): (weakref(parameter), preallocated gradient buffer of the parameter's shape)} or None
     (``trase_amd.dp.FlatGradBucket.sink()``).  The fused backward then writes the gradients of those parameters directly
     into the given buffers (and autograd adopts them as ``.grad`` when ``.grad`` is None) instead of allocating fresh
     tensors, so that the view-parallel all-reduce bucket is filled without a zero-fill and an accumulation pass.  A
-    parameter is recognised by object identity (checked through the weak reference), never by its address."""
-    global _GRAD_SINK
+    parameter is recognised by object identity (checked through the weak reference), never by its address.
+
+    ``chunks`` > 1 with ``on_chunk``: the per-Gaussian tail of the backward (row reduction + activation chain) runs in
+    that many Gaussian-index ranges and ``on_chunk(p_begin, p_end, P, ids)`` (``ids`` = the parameters whose sink buffers this
+    backward writes) is called after each range has been ENQUEUED on
+    the current stream -- every gradient entry of the Gaussians [p_begin, p_end) is final in stream order at that point,
+    so the caller can start exchanging them while the remaining ranges are still being computed
+    (``trase_amd.dp.FlatGradBucket.overlapped``)."""
+    global _GRAD_SINK, _GRAD_CHUNKS
     _GRAD_SINK = dict(sink) if sink else {}
+    _GRAD_CHUNKS = (int(chunks), on_chunk) if (sink and on_chunk is not None and int(chunks) > 1) else None
+
+
+def chunk_ranges(P: int, chunks: int):
+    """[(begin, end)] partition of [0, P) into at most ``chunks`` ranges whose starts are multiples of 64 (what
+    ``trase_rast_backward_raw_gaussians`` accepts), sizes within 64 of each other."""
+    blocks = (int(P) + 63) // 64
+    k = max(1, min(int(chunks), blocks))
+    base, extra = divmod(blocks, k)
+    out, b = [], 0
+    for c in range(k):
+        e = b + base + (1 if c < extra else 0)
+        out.append((b * 64, min(e * 64, int(P))))
+        b = e
+    return out
 
 
 class _RenderRaw(torch.autograd.Function):
@@ -157,6 +180,7 @@ class _RenderRaw(torch.autograd.Function):
         need = ctx.needs_input_grad   # xyz0 d_xyz1 f_dc2 f_rest3 opacity4 scaling5 d_scaling6 rotation7 d_rotation8 gfeat9 means2D10
 
         pid = ctx.param_ids
+        used_sink: set = set()
 
         def alloc(flag, like, name=None):
             if not flag:
@@ -166,6 +190,7 @@ class _RenderRaw(torch.autograd.Function):
                 ref, buf = ent
                 p = ref()
                 if p is not None and id(p) == pid[name] and buf.shape == like.shape and buf.device == like.device:
+                    used_sink.add(pid[name])
                     # a FRESH view object: autograd's AccumulateGrad then adopts it as .grad without a copy (it clones a
                     # gradient that somebody else still references), so the gradient is written once, in place, into the
                     # caller's buffer (trase_amd.dp.FlatGradBucket: the all-reduce bucket)
@@ -190,8 +215,20 @@ class _RenderRaw(torch.autograd.Function):
         g.dL_dscaling, g.dL_dd_scaling = _lib.ptr(g_sc), _lib.ptr(g_dsc)
         g.dL_drotation, g.dL_dd_rotation = _lib.ptr(g_rot), _lib.ptr(g_drot)
         g.dL_dgaussian_features = _lib.ptr(g_feat)
-        _lib.check(lib.trase_rast_backward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), C.byref(g),
-                                               _stream(device)), "trase_rast_backward_raw")
+        if _GRAD_CHUNKS is not None and P > 0:
+            # compositing backward once, then the per-Gaussian tail range by range: the caller's hook sees every range as
+            # soon as it is in the stream (the view-parallel exchange of that range overlaps the rest of the tail)
+            n_chunks, hook = _GRAD_CHUNKS
+            _lib.check(lib.trase_rast_backward_raw_compose(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), C.byref(g),
+                                                           _stream(device)), "trase_rast_backward_raw_compose")
+            for (pb, pe) in chunk_ranges(P, n_chunks):
+                _lib.check(lib.trase_rast_backward_raw_gaussians(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws),
+                                                                 C.byref(g), pb, pe, _stream(device)),
+                           "trase_rast_backward_raw_gaussians")
+                hook(pb, pe, P, used_sink)
+        else:
+            _lib.check(lib.trase_rast_backward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), C.byref(g),
+                                                   _stream(device)), "trase_rast_backward_raw")
         if P == 0:
             for t in (g_xyz, g_dxyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat):
                 if t is not None:
