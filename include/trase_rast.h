@@ -14,8 +14,12 @@
  * types.  All pointers named "device" are HIP device pointers valid on
  * `settings.device`; every call enqueues work on the caller's `stream` and
  * returns without synchronising unless stated.  The library allocates nothing
- * persistent and keeps no global state; it is re-entrant (PyTorch calls the
- * backward entry point from an autograd worker thread).
+ * persistent; every call works on the caller's workspaces only and the entry
+ * points are re-entrant (PyTorch calls the backward from an autograd worker
+ * thread).  Process-wide state is limited to the last-error string (thread-local)
+ * and the opt-in profiler (trase_prof_enable; mutex-guarded event records).  The
+ * Python wrapper's policy (capacity, variant, strip: trase_amd/rasterizer.py) is
+ * per process; a backward always uses what its forward captured.
  *
  * Return codes: 0 ok; <0 invalid argument / HIP error (see trase_strerror);
  * >0 is never returned by enqueue calls (capacity overflow is reported through
