@@ -100,3 +100,38 @@ def test_overlapped_exchange_through_a_one_rank_rccl_group():
     finally:
         set_grad_sink(None)
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [777, 4096 + 13])
+def test_unaligned_parameter_storage_gives_identical_results(n):
+    """The wave-cooperative row moves of the per-Gaussian kernels use 16-byte accesses when the base pointers allow it and
+    fall back otherwise: parameters that are views at a 4-byte offset into a larger buffer (P not a multiple of 64) must
+    give bit-identical maps and gradients."""
+    from trase_amd.synthetic import make_scene, SynthGaussianModel, SynthPipe, orbit_camera
+    dev = torch.device("cuda", 0)
+    cam = orbit_camera(200, 136, angle=1.1, fid=0.5).to(dev)
+    pipe = SynthPipe()
+    results = []
+    for shifted in (False, True):
+        pc = SynthGaussianModel(make_scene(n, feat_dim=32, seed=9).to(dev))
+        if shifted:
+            for name in ("_features_rest", "_gaussian_features", "_features_dc", "_xyz", "_scaling", "_rotation", "_opacity"):
+                p = getattr(pc, name)
+                buf = torch.empty(p.numel() + 1, device=dev)
+                view = buf[1:].view(p.shape)
+                view.copy_(p.detach())
+                assert view.data_ptr() % 16 == 4 and view.is_contiguous()
+                setattr(pc, name, torch.nn.Parameter(view))
+        for p in pc.parameters():
+            p.grad = None
+        from gaussian_renderer import render
+        g = torch.Generator(device="cpu").manual_seed(2)
+        out = render(cam, pc, pipe, torch.zeros(3, device=dev), 0.0, 0.0, 0.0)
+        gi = torch.randn(out["render"].shape, generator=g).to(dev)
+        gf = torch.randn(out["render_gaussian_features"].shape, generator=g).to(dev)
+        torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])
+        results.append(([out["render"].detach().clone(), out["render_gaussian_features"].detach().clone(),
+                         out["radii"].clone()], [p.grad.clone() for p in pc.parameters()]))
+    (m0, g0), (m1, g1) = results
+    for a, b in zip(m0 + g0, m1 + g1):
+        assert torch.equal(a, b)
