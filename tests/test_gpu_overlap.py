@@ -135,3 +135,35 @@ def test_unaligned_parameter_storage_gives_identical_results(n):
     (m0, g0), (m1, g1) = results
     for a, b in zip(m0 + g0, m1 + g1):
         assert torch.equal(a, b)
+
+
+def test_forward_scope_image_matches_the_full_render():
+    """set_forward_scope("image"): same image / depth / radii (the colour-only kernels blend in a different instruction
+    order: 2e-5) and the same gradients as an image-only cotangent through the full render."""
+    from gaussian_renderer import render
+    from trase_amd.renderer import set_forward_scope
+    pc, pipe, cam, dev = _scene(n=15000, seed=21)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    outs = []
+    for scope in ("all", "image"):
+        set_forward_scope(scope)
+        try:
+            for p in pc.parameters():
+                p.grad = None
+            out = render(cam, pc, pipe, bg, 0.0, 0.0, 0.0)
+            if scope == "all":
+                gi = torch.randn(out["render"].shape, generator=g).to(dev)
+            out["render"].backward(gi)
+            outs.append((out, [None if p.grad is None else p.grad.clone() for p in pc.parameters()]))
+        finally:
+            set_forward_scope("all")
+    (a, ga), (b, gb) = outs
+    assert b["render_gaussian_features"].shape[0] == 0 and a["render_gaussian_features"].shape[0] == 32
+    assert torch.equal(a["radii"], b["radii"])
+    assert (a["render"] - b["render"]).abs().max() < 2e-5 and (a["depth"] - b["depth"]).abs().max() < 2e-4
+    for x, y in zip(ga, gb):
+        if x is None or y is None:
+            assert (x is None or float(x.abs().max()) == 0.0) and (y is None or float(y.abs().max()) == 0.0)
+            continue
+        assert (x - y).abs().max() <= 2e-4 * max(float(x.abs().max()), 1e-12)

@@ -36,6 +36,21 @@ def set_backward_scope(scope: str = "all") -> None:
     _r.set_variant(v | (0x400 if scope == "features" else 0))
 
 
+_FORWARD_SCOPE = "all"
+
+
+def set_forward_scope(scope: str = "all") -> None:
+    """``"image"``: the fused ``render()`` composites colour and depth only -- ``render_gaussian_features`` comes back as an
+    empty (0, H, W) tensor.  For GAUSSIAN-state iterations: train.py:211 reads ``render``, ``viewspace_points``,
+    ``visibility_filter`` and ``radii`` of the returned dict and nothing else, while the rasterizer still blends the 32
+    feature channels per pixel (0.28 -> 0.16 ms forward at 300k Gaussians / 1080p).  ``"all"`` (default) restores the
+    reference's behaviour.  Opt-in, like ``set_backward_scope``; the operator-level ``GaussianRasterizer`` is unaffected."""
+    global _FORWARD_SCOPE
+    if scope not in ("all", "image"):
+        raise ValueError("scope must be 'all' or 'image'")
+    _FORWARD_SCOPE = scope
+
+
 _GRAD_SINK: dict = {}
 _GRAD_CHUNKS = None        # (number of Gaussian-index chunks, callback(p_begin, p_end, P)) of the overlapped exchange
 
@@ -272,8 +287,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
     if _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth_gaussian_features):
         T = lambda d: d if torch.is_tensor(d) else None
         # KNN-smoothed features (FEATURE state, gaussian_renderer/__init__.py:118): one HIP gather, then the fused path
-        gfeat = smoothed_gaussian_features(pc, K=smooth_K, dropout=0.5) if is_smooth_gaussian_features \
-            else pc._gaussian_features
+        if _FORWARD_SCOPE == "image":
+            gfeat = None                       # colour + depth only (set_forward_scope)
+        else:
+            gfeat = smoothed_gaussian_features(pc, K=smooth_K, dropout=0.5) if is_smooth_gaussian_features \
+                else pc._gaussian_features
         rendered_image, radii, rendered_feats, depth = _RenderRaw.apply(
             pc._xyz, T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, T(d_scaling),
             pc._rotation, T(d_rotation), gfeat, screenspace_points, raster_settings,
