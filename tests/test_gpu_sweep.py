@@ -12,6 +12,7 @@ The oracle sees the device's own float32 depth keys / radii / centres only to se
 ambiguous between float32 and float64 (oracle/raster_oracle.py `device_view`); what remains excluded is the
 per-pixel "gate within rounding of its threshold" set, budgeted at <= 1 % per scene and < 0.5 % overall."""
 import math
+import os
 import random
 
 import pytest
@@ -25,7 +26,11 @@ pytestmark = pytest.mark.gpu
 ROUND1_FAILURES = [(3500, 160, 136, 9650, 0.3), (2000, 64, 136, 6788, 0.6), (3500, 64, 17, 3268, 3.0)]
 
 
-def _sweep_configs(count=104, seed=20260928):
+def _sweep_configs(count=None, seed=None):
+    # TRASE_SWEEP_COUNT / TRASE_SWEEP_SEED widen the sweep without editing the test (a 450-configuration run with seed 4242:
+    # 0 failures, 0.15 % fragile pixels -- round 2)
+    count = int(os.environ.get("TRASE_SWEEP_COUNT", 104)) if count is None else count
+    seed = int(os.environ.get("TRASE_SWEEP_SEED", 20260928)) if seed is None else seed
     rnd = random.Random(seed)
     cfgs = list(ROUND1_FAILURES)
     while len(cfgs) < count:
