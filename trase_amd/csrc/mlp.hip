@@ -271,11 +271,18 @@ __device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0
 }
 
 // ---- saved state of the training forward ---------------------------------------------------------------
-// "Transposed image" of an [N][M] bf16 matrix: [tile = row/32][column][row%32].  A 32x32x16 MFMA whose reduction
-// index is the ROW (the weight-gradient GEMMs dZ^T . input) then reads its operand fragments -- one column, 8
-// consecutive rows per lane -- as contiguous 16-byte loads.  The chain kernels hold lane = row, registers =
-// columns: a 4x4 transpose inside every lane quad (two DPP exchange rounds) turns "4 columns of my row" into
-// "4 rows of my column", and one store instruction of the wave covers 8 columns x 32 rows = 512 contiguous bytes.
+// "Transposed image" of an [N][M] bf16 matrix: [tile = row/32][half = (row%32)/16][column][row%16].  A 32x32x16 MFMA
+// whose reduction index is the ROW (the weight-gradient GEMMs dZ^T . input) reads its operand fragments -- one column, 8
+// consecutive rows per lane -- as 16-byte loads, and the 64 lanes of a fragment load (32 columns x 2 row groups of one
+// K-step) cover ONE CONTIGUOUS KILOBYTE.  (Round 1 kept the 32 rows of a column together: a fragment load then took 32
+// bytes out of every 64 -- the texture-data unit spent ~87 cycles per load instruction instead of 16 and was 89 % busy
+// while the matrix cores idled at 18 %, and half-used lines were fetched again: 3.2 GB of HBM reads for 2.15 GB of
+// operands.)  The chain kernels hold lane = row, registers = columns: a 4x4 transpose inside every lane quad (two DPP
+// exchange rounds) turns "4 columns of my row" into "4 rows of my column"; one store instruction of the wave covers
+// 8 columns x 32 rows = two contiguous runs of 256 bytes.
+__device__ __forceinline__ size_t timg_off(int M, int col, int row) {
+  return (size_t)(row >> 4) * (size_t)(M * 16) + (size_t)col * 16 + (size_t)(row & 15);
+}
 __device__ __forceinline__ void store_transposed(__bf16* __restrict__ img_tile, int f0, int m, s16x4 pk) {
   const bool odd = m & 1, hi = m & 2;
   unsigned d[2];
@@ -294,7 +301,7 @@ __device__ __forceinline__ void store_transposed(__bf16* __restrict__ img_tile, 
   out.y = hi ? d[1] : recv2;
   // quad position q = m&3 owns column f0 + (q&1) + 2*(q>>1)... round 1 gave odd lanes the odd columns, round 2 the
   // upper lane pair the columns +2: column = f0 + (m&1) + (m&2)
-  *reinterpret_cast<uint2*>(img_tile + (size_t)(f0 + (m & 3)) * 32 + (m & ~3)) = out;
+  *reinterpret_cast<uint2*>(img_tile + timg_off(MW, f0 + (m & 3), m & ~3)) = out;
 }
 
 // SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations
@@ -694,14 +701,15 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
   }
 }
 
-// transposed image of the bf16 positional encoding, [tile][96][32] (columns 84..95 and padding rows zero):
+// transposed image of the bf16 positional encoding, [tile][2][96][16] (columns 84..95 and padding rows zero):
 // the GEMM input of layers 0 and 5
 __global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
                                                      const float* __restrict__ temb, int N, __bf16* __restrict__ peT) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)((N + 31) >> 5) * EMBP * 32;
   if (idx >= total) return;
-  const int r = (int)(idx & 31), c = (int)((idx >> 5) % EMBP);
+  // idx IS the image offset: [tile][half][column][16 rows]
+  const int r = (int)(idx & 15) + 16 * (int)((idx / (16 * EMBP)) & 1), c = (int)((idx >> 4) % EMBP);
   const int row = (int)(idx / (EMBP * 32)) * 32 + r;
   float v = 0.f;
   if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride], temb);
@@ -753,13 +761,13 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) g8[gi][j] = (__bf16)g[j];
-    // transposed image of the cotangent, [tile][32 columns][32 rows] (columns 10..31 zero): operand of the head GEMM
+    // transposed image of the cotangent, [tile][2][32 columns][16 rows] (columns 10..31 zero): operand of the head GEMM
     if (wc == 0 && row0 + 32 * gi < N) {
       __bf16* gt = gT + (size_t)((row0 + 32 * gi) >> 5) * (HEADP * 32);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        gt[(8 * h + j) * 32 + m] = g8[gi][j];
-        gt[(16 + 8 * h + j) * 32 + m] = (__bf16)0.f;
+        gt[timg_off(HEADP, 8 * h + j, m)] = g8[gi][j];
+        gt[timg_off(HEADP, 16 + 8 * h + j, m)] = (__bf16)0.f;
       }
     }
   }
@@ -871,12 +879,12 @@ __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2,
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) g8[j] = (__bf16)g[j];
-    // transposed image of the cotangent, [tile][32 columns][32 rows] (columns 10..31 zero): operand of the head GEMM
+    // transposed image of the cotangent, [tile][2][32 columns][16 rows] (columns 10..31 zero): operand of the head GEMM
     __bf16* gt = gT + (size_t)tile * (HEADP * 32);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      gt[(8 * h + j) * 32 + m] = g8[j];
-      gt[(16 + 8 * h + j) * 32 + m] = (__bf16)0.f;
+      gt[timg_off(HEADP, 8 * h + j, m)] = g8[j];
+      gt[timg_off(HEADP, 16 + 8 * h + j, m)] = (__bf16)0.f;
     }
   }
   for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
@@ -948,6 +956,9 @@ struct WgradJob {
 constexpr int WG_MAX_JOBS = 8;
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
+#ifndef WGRAD_NBUF
+#define WGRAD_NBUF 4
+#endif
 // WM x WN waves, each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
 template <int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, int tiles, int G) {
@@ -972,17 +983,21 @@ __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, 
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  // fragment (tile, K-step s): 8 consecutive rows 16s + 8h .. of column f
-  const __bf16* pa = job.A + (size_t)(wm * MB * 32 + i) * 32 + 8 * h;
-  const __bf16* pb = job.B + (size_t)(wn * NB * 32 + i) * 32 + 8 * h;
-  bf16x8 fa[2][MB], fb[2][NB];
+  // fragment (tile, K-step s): 8 consecutive rows 16s + 8h .. of column f; the lanes of one load are 1 KB contiguous
+  const __bf16* pa = job.A + (size_t)(wm * MB * 32 + i) * 16 + 8 * h;
+  const __bf16* pb = job.B + (size_t)(wn * NB * 32 + i) * 16 + 8 * h;
+  // fragment ring: NBUF - 1 K-steps are requested ahead of the one being multiplied.  One wave per SIMD is all the
+  // accumulators leave room for, so the only latency cover is this wave's own queue: with one step ahead a K-step took
+  // ~3000 cycles for 512 cycles of MFMA work.
+  constexpr int NBUF = WGRAD_NBUF;
+  bf16x8 fa[NBUF][MB], fb[NBUF][NB];
   auto load = [&](int buf, int step) {      // step = tile * 2 + s
-    const size_t ta = (size_t)(step >> 1) * (M * 32) + (step & 1) * 16;
-    const size_t tb = (size_t)(step >> 1) * (NK * 32) + (step & 1) * 16;
+    const size_t ta = (size_t)(step >> 1) * (M * 32) + (size_t)(step & 1) * (M * 16);
+    const size_t tb = (size_t)(step >> 1) * (NK * 32) + (size_t)(step & 1) * (NK * 16);
 #pragma unroll
-    for (int a = 0; a < MB; ++a) fa[buf][a] = *reinterpret_cast<const bf16x8*>(pa + ta + (size_t)a * 32 * 32);
+    for (int a = 0; a < MB; ++a) fa[buf][a] = *reinterpret_cast<const bf16x8*>(pa + ta + (size_t)a * 32 * 16);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) fb[buf][b] = *reinterpret_cast<const bf16x8*>(pb + tb + (size_t)b * 32 * 32);
+    for (int b = 0; b < NB; ++b) fb[buf][b] = *reinterpret_cast<const bf16x8*>(pb + tb + (size_t)b * 32 * 16);
   };
   auto mma = [&](int buf) {
 #pragma unroll
@@ -994,12 +1009,41 @@ __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, 
       for (int a = 0; a < MB; ++a) accb[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][a], ones, accb[a], 0, 0, 0);
   };
   const int s_begin = 2 * t_begin, s_end = 2 * t_end;     // always an even number of steps
-  if (s_begin < s_end) load(0, s_begin);
-  for (int s = s_begin; s < s_end; s += 2) {
-    load(1, s + 1);
-    mma(0);
-    if (s + 2 < s_end) load(0, s + 2);
-    mma(1);
+  if (s_begin >= s_end) {                                  // (an empty group still writes its zero partials below)
+  } else {
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k) {                   // every buffer of the ring holds something finite
+      const bool real = s_begin + k < s_end;
+      load(k, real ? s_begin + k : s_end - 2 + (k & 1));
+      if (!real) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fa[k][a][e] = (__bf16)0.0f;
+      }
+    }
+  }
+  // (s_end - s_begin is even and NBUF is even: the parity of step s + j is that of j, so every fragment address of the
+  // unrolled body is base + tile * stride + a compile-time constant.  The last group may run past the end: those steps
+  // re-read the last tile and multiply a ZERO A fragment -- the MFMAs stay unconditional, which keeps the accumulators
+  // out of control-flow merges: guarded MFMA blocks made the allocator spill.)
+  for (int s = s_begin; s < s_end; s += NBUF) {
+    // keep the waves of the workgroup on the same tiles: two of them read every A fragment and two every B fragment; once
+    // they drift apart the second reader misses L1 and often L2 (measured: 3.2 GB fetched from HBM for 2.15 GB of operands)
+    if (WM * WN > 1 && MB * NB >= 16) __builtin_amdgcn_s_barrier();   // (the narrow jobs lose more at the barrier than they gain)
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) {
+      const int nx = s + j + NBUF - 1, nb_ = (j + NBUF - 1) % NBUF;
+      const bool real = nx < s_end;
+      load(nb_, real ? nx : s_end - 2 + (nb_ & 1));
+      if (!real) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fa[nb_][a][e] = (__bf16)0.0f;
+      }
+      mma(j);
+    }
   }
   // D[f_local][k_local]: lane = k_local (+32 for the odd f quads), register r = f_local%4 + 4*(f_local/8)
   float* out = job.partial + (size_t)g * M * NK;
@@ -1103,7 +1147,9 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   p.dzT = (__bf16*)c; c += align_up(sizeof(__bf16) * MD * tiles * MW * 32);
   p.gT = (__bf16*)c;  c += align_up(sizeof(__bf16) * tiles * HEADP * 32);
   // one workgroup per CU for the big GEMMs (252 = 7 x 36), more and shorter ones for the narrow jobs
-  p.Gh = (int)(tiles < 36 ? tiles : 36); p.Gp = (int)(tiles < 128 ? tiles : 128); p.Gd = p.Gp;
+  static const int gh_env = [] { const char* e = getenv("TRASE_MLP_GH"); return e ? atoi(e) : 0; }();
+  const int gh_max = gh_env > 0 ? gh_env : 36;
+  p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128); p.Gd = p.Gp;
   if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
   p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW * MW);
   p.bias_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW);
