@@ -954,6 +954,12 @@ struct WgradJob {
   float* bias_partial; // [G][M] or null
 };
 constexpr int WG_MAX_JOBS = 8;
+// distance between the partial planes of consecutive row groups, in floats: NOT the bare M * NK -- the reduction reads the
+// same offset of every plane, and planes a power of two apart put all of those reads on the same memory channels
+#ifndef WG_PLANE_PAD
+#define WG_PLANE_PAD 1088
+#endif
+__host__ __device__ constexpr size_t wg_plane(int M, int NK) { return (size_t)M * NK + WG_PLANE_PAD; }
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
 #ifndef WGRAD_NBUF
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, 
     }
   }
   // D[f_local][k_local]: lane = k_local (+32 for the odd f quads), register r = f_local%4 + 4*(f_local/8)
-  float* out = job.partial + (size_t)g * M * NK;
+  float* out = job.partial + (size_t)g * wg_plane(M, NK);
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -1076,32 +1082,67 @@ struct WreduceJobs { WreduceJob j[WR_MAX_JOBS]; };
 
 __global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
   const WreduceJob job = jobs.j[blockIdx.y];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = job.M * job.NK;
-  if (idx < total) {
-    const int f = idx / job.NK, k = idx % job.NK;
-    if (f < job.m_valid && k < job.k_valid) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed summation order, four loads in flight
-      int g = 0;
-      for (; g + 4 <= job.G; g += 4) {
-        s0 += job.partial[(size_t)g * total + idx];       s1 += job.partial[(size_t)(g + 1) * total + idx];
-        s2 += job.partial[(size_t)(g + 2) * total + idx]; s3 += job.partial[(size_t)(g + 3) * total + idx];
-      }
-      for (; g < job.G; ++g) s0 += job.partial[(size_t)g * total + idx];
-      const float s = (s0 + s1) + (s2 + s3);
+  const int total = job.M * job.NK;                      // a multiple of 4 (NK is a multiple of 32)
+  const size_t plane = wg_plane(job.M, job.NK);
+  // lane = four consecutive outputs (one 16-byte load per partial plane), wave w = the planes g = w (mod 4): the narrow jobs
+  // have 128 planes and few outputs -- with one thread walking all planes of an output the kernel's run time was that chain
+  // of dependent round trips.  Up to twelve planes in flight per thread; the four waves' sums meet in LDS and are added in a
+  // fixed order -> bit-reproducible.
+  __shared__ float4 sh[3][64];
+  const int q = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int idx = (blockIdx.x * 64 + q) * 4;
+  const int f = idx / job.NK, k = idx % job.NK;
+  const bool mine = idx < total && f < job.m_valid && k < job.k_valid;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mine) {
+    int g = seg;
+    for (; g + 44 < job.G; g += 48) {
+      float4 v[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) v[u] = *reinterpret_cast<const float4*>(job.partial + (size_t)(g + 4 * u) * plane + idx);
+#pragma unroll
+      for (int u = 0; u < 12; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    float4 v[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u)
+      v[u] = (g + 4 * u < job.G) ? *reinterpret_cast<const float4*>(job.partial + (size_t)(g + 4 * u) * plane + idx)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  if (seg > 0) sh[seg - 1][q] = s;
+  __syncthreads();
+  if (seg == 0 && mine) {
+    const float4 s1 = sh[0][q], s2 = sh[1][q], s3 = sh[2][q];
+    const float o[4] = {(s.x + s1.x) + (s2.x + s3.x), (s.y + s1.y) + (s2.y + s3.y),
+                        (s.z + s1.z) + (s2.z + s3.z), (s.w + s1.w) + (s2.w + s3.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (k + e >= job.k_valid) break;
       if (job.head) {
-        const int seg = f < 3 ? 0 : (f < 7 ? 1 : 2), base = f < 3 ? 0 : (f < 7 ? 3 : 7);
-        if (job.head_w[seg]) job.head_w[seg][(f - base) * job.stride + k] = s;
-      } else if (job.out) job.out[(size_t)f * job.stride + job.col_off + k] = s;
+        const int sg = f < 3 ? 0 : (f < 7 ? 1 : 2), base = f < 3 ? 0 : (f < 7 ? 3 : 7);
+        if (job.head_w[sg]) job.head_w[sg][(f - base) * job.stride + k + e] = o[e];
+      } else if (job.out) job.out[(size_t)f * job.stride + job.col_off + k + e] = o[e];
     }
   }
-  if (job.bias_partial && idx < job.m_valid) {
-    float s = 0.f;
-    for (int g = 0; g < job.G; ++g) s += job.bias_partial[(size_t)g * job.M + idx];
+  const int bidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job.bias_partial && bidx < job.m_valid) {
+    // sixteen partials in flight (one thread walking up to 128 planes one dependent load at a time WAS this kernel's run
+    // time: 90 us); four interleaved sums, fixed order
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < job.G; g += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (g + u < job.G) ? job.bias_partial[(size_t)(g + u) * job.M + bidx] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a4[u & 3] += v[u];
+    }
+    const float b = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (job.head) {
-      const int seg = idx < 3 ? 0 : (idx < 7 ? 1 : 2), base = idx < 3 ? 0 : (idx < 7 ? 3 : 7);
-      if (job.head_b[seg]) job.head_b[seg][idx - base] = s;
-    } else if (job.bias_out) job.bias_out[idx] = s;
+      const int sg = bidx < 3 ? 0 : (bidx < 7 ? 1 : 2), base = bidx < 3 ? 0 : (bidx < 7 ? 3 : 7);
+      if (job.head_b[sg]) job.head_b[sg][bidx - base] = b;
+    } else if (job.bias_out) job.bias_out[bidx] = b;
   }
 }
 
@@ -1151,11 +1192,11 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   const int gh_max = gh_env > 0 ? gh_env : 36;
   p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128); p.Gd = p.Gp;
   if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
-  p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW * MW);
+  p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * wg_plane(MW, MW));
   p.bias_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW);
-  p.part_pe = (float*)c;     c += align_up(sizeof(float) * 2 * (size_t)p.Gp * MW * EMBP);
+  p.part_pe = (float*)c;     c += align_up(sizeof(float) * 2 * (size_t)p.Gp * wg_plane(MW, EMBP));
   p.bias_pe = (float*)c;     c += align_up(sizeof(float) * (size_t)p.Gp * MW);
-  p.part_head = (float*)c;   c += align_up(sizeof(float) * (size_t)p.Gd * HEADP * MW);
+  p.part_head = (float*)c;   c += align_up(sizeof(float) * (size_t)p.Gd * wg_plane(HEADP, MW));
   p.bias_head = (float*)c;   c += align_up(sizeof(float) * (size_t)p.Gd * HEADP);
   p.bytes = (size_t)(c - (char*)base);
   return p;
@@ -1345,7 +1386,7 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
     for (int l = 1; l < MD; ++l) {
       WgradJob& j = jobs.j[l - 1];
       j.A = bp.dzT + (size_t)l * img; j.B = sv.actsT + (size_t)(l - 1) * img;
-      j.partial = bp.part_hidden + (size_t)(l - 1) * bp.Gh * MW * MW;
+      j.partial = bp.part_hidden + (size_t)(l - 1) * bp.Gh * wg_plane(MW, MW);
       j.bias_partial = bp.bias_hidden + (size_t)(l - 1) * bp.Gh * MW;
       const int kin = l == SKIP ? EMB + MW : MW;
       reduce_job(j.partial, j.bias_partial, grads->weight[l], grads->bias[l], MW, MW, kin, l == SKIP ? EMB : 0, MW, MW, bp.Gh);
@@ -1360,7 +1401,7 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
     for (int k = 0; k < 2; ++k) {
       WgradJob& j = jobs.j[k];
       j.A = bp.dzT + (size_t)ls[k] * img; j.B = sv.peT;
-      j.partial = bp.part_pe + (size_t)k * bp.Gp * MW * EMBP;
+      j.partial = bp.part_pe + (size_t)k * bp.Gp * wg_plane(MW, EMBP);
       j.bias_partial = k == 0 ? bp.bias_pe : nullptr;
       reduce_job(j.partial, j.bias_partial, grads->weight[ls[k]], k == 0 ? grads->bias[0] : nullptr, MW, EMBP,
                  k == 0 ? EMB : EMB + MW, 0, EMB, MW, bp.Gp);
