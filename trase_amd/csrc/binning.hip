@@ -99,11 +99,29 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
   // every thread owns a contiguous piece of the row: serial sum, one block-wide scan of the 256 sums, serial rewrite
   const int per = (nb + 255) / 256;
   const int b_lo = threadIdx.x * per, b_hi = min(b_lo + per, nb);
-  uint32_t mine = 0;
-  for (int b = b_lo; b < b_hi; ++b) mine += row[b];
-  const uint32_t incl = block256_incl_scan(mine, sh);
-  uint32_t run = incl - mine;
-  for (int b = b_lo; b < b_hi; ++b) { const uint32_t v = row[b]; row[b] = run; run += v; }
+  uint32_t mine = 0, run;
+  uint32_t incl;
+  if (per <= 16) {
+    // the thread's piece in registers, every load in flight at once (two loops of `per` dependent round trips were most of
+    // this kernel's 12 us on the 6 M-pair sort)
+    uint32_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (b_lo + u < b_hi) ? row[b_lo + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) mine += v[u];
+    incl = block256_incl_scan(mine, sh);
+    run = incl - mine;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (b_lo + u < b_hi) row[b_lo + u] = run;
+      run += v[u];
+    }
+  } else {
+    for (int b = b_lo; b < b_hi; ++b) mine += row[b];
+    incl = block256_incl_scan(mine, sh);
+    run = incl - mine;
+    for (int b = b_lo; b < b_hi; ++b) { const uint32_t v = row[b]; row[b] = run; run += v; }
+  }
   if (threadIdx.x == 255) carry = incl;
   __syncthreads();
   if (threadIdx.x == 0) digit_total[d] = carry;
@@ -660,6 +678,36 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
   }
 }
 
+// The default path (ids are gathered by the forward kernel): four consecutive list entries per thread, one 16-byte load
+// plus the two neighbours -- a single pass with every load in flight at once (the grid-stride form above took six
+// dependent trips per thread for 6 M entries).
+__global__ __launch_bounds__(256) void tile_ranges4_kernel(const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                           uint2* __restrict__ ranges, uint32_t T,
+                                                           uint32_t* __restrict__ dbg) {
+  const uint32_t n = dev_n(n_ptr, cap);
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  if (i0 >= n) return;
+  uint32_t k[6];                                    // keys[i0 - 1 .. i0 + 4]
+  const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);     // the key buffers are capacity-sized and 16-byte aligned
+  k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
+  k[0] = (i0 > 0) ? keys[i0 - 1] : 0xffffffffu;
+  k[5] = (i0 + 4 < n) ? keys[i0 + 4] : 0xffffffffu;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t i = i0 + e;
+    if (i >= n) break;
+    uint32_t t = k[1 + e];
+    if (t >= T) {                                   // cannot happen unless the sort is broken: record, stay in bounds
+      if (dbg) { dbg[0] = 1; dbg[1] = i; dbg[2] = t; }
+      t = T - 1;
+    }
+    const uint32_t prev = k[e], next = (i + 1 < n) ? k[2 + e] : 0xffffffffu;
+    if (i == 0 || prev != k[1 + e]) ranges[t].x = i;
+    if (i == n - 1 || next != k[1 + e]) ranges[t].y = i + 1;
+  }
+}
+
 int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
                               int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
                               uint32_t* dbg) {
@@ -679,13 +727,15 @@ int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const ui
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg, bool clear) {
   if (clear) TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
-  int blocks = (int)((cap + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((cap + 1023) / 1024);
   if (blocks < 1) blocks = 1;
   {
     ProfScope ps("tile_ranges", c.stream);
-    hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, nullptr,
-                       nullptr, nullptr, (uint32_t)T, dbg);
+    if ((reinterpret_cast<uintptr_t>(keys) & 15) == 0)
+      hipLaunchKernelGGL(tile_ranges4_kernel, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, (uint32_t)T, dbg);
+    else
+      hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, c.stream, keys, n_ptr, cap,
+                         ranges, nullptr, nullptr, nullptr, (uint32_t)T, dbg);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;
