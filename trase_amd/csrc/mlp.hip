@@ -705,15 +705,31 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
 // the GEMM input of layers 0 and 5
 __global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
                                                      const float* __restrict__ temb, int N, __bf16* __restrict__ peT) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)((N + 31) >> 5) * EMBP * 32;
-  if (idx >= total) return;
-  // idx IS the image offset: [tile][half][column][16 rows]
-  const int r = (int)(idx & 15) + 16 * (int)((idx / (16 * EMBP)) & 1), c = (int)((idx >> 4) % EMBP);
-  const int row = (int)(idx / (EMBP * 32)) * 32 + r;
-  float v = 0.f;
-  if (row < N) v = pe_value(c, x[3 * (size_t)row], x[3 * (size_t)row + 1], x[3 * (size_t)row + 2], t[(size_t)row * t_stride], temb);
-  peT[idx] = (__bf16)v;
+  // one thread per (tile, half, column): its 16 rows are 32 contiguous bytes of the image.  A column reads ONE input per
+  // row (its coordinate, or t) -- one thread per element issued four loads and a 2-byte store per value.
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)((N + 31) >> 5) * 2 * EMBP;
+  if (tid >= total) return;
+  const int c = (int)(tid % EMBP), half = (int)((tid / EMBP) & 1);
+  const int row0 = (int)(tid / (2 * EMBP)) * 32 + 16 * half;
+  // which input the column depends on: 0..2 = coordinate, 3 = t, -1 = none (padding / timenet columns)
+  int src = -1;
+  if (c < 3) src = c;
+  else if (c < 63) src = ((c - 3) % 6) % 3;
+  else if (!temb && c < EMB_T) src = 3;
+  bf16x8 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + r;
+    float v = 0.f;
+    if (row < N) {
+      const float in = src < 0 ? 0.f : (src == 3 ? t[(size_t)row * t_stride] : x[3 * (size_t)row + src]);
+      v = pe_value(c, in, in, in, in, temb);               // the column picks the one argument it uses
+    }
+    o[r >> 3][r & 7] = (__bf16)v;
+  }
+  bf16x8* dst = reinterpret_cast<bf16x8*>(peT + tid * 16);
+  dst[0] = o[0]; dst[1] = o[1];
 }
 
 // backward data chain on the block-GEMM organisation of mlp_fwd_blk_body: the workgroup owns 128 rows and stages every
@@ -1313,7 +1329,7 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
   }
   {
     ProfScope ps("mlp_pe", stream);
-    const size_t n = (size_t)((N + 31) / 32) * EMBP * 32;
+    const size_t n = (size_t)((N + 31) / 32) * 2 * EMBP;
     hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT);
   }
   TRASE_POST_LAUNCH("mlp_pe", stream, 0);
