@@ -33,10 +33,23 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   const float* X = img + c * plane;
   const float* Y = gt + c * plane;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-  for (int i = threadIdx.x; i < LH * LH; i += 256) {
-    const int r = i / LH, q = i % LH;
-    sx[r][q] = tile_load(X, H, W, y0 + r - LR, x0 + q - LR);
-    sy[r][q] = tile_load(Y, H, W, y0 + r - LR, x0 + q - LR);
+  {
+    // the tile + halo in registers first: all of a thread's loads in flight at once (as a loop of load -> LDS store the
+    // seven round trips per thread were most of this kernel's run time at three workgroups per CU)
+    constexpr int NL = (LH * LH + 255) / 256;
+    float vx[NL], vy[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k, r = i / LH, q = i % LH;
+      const bool in = i < LH * LH;
+      vx[k] = in ? tile_load(X, H, W, y0 + r - LR, x0 + q - LR) : 0.f;
+      vy[k] = in ? tile_load(Y, H, W, y0 + r - LR, x0 + q - LR) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k, r = i / LH, q = i % LH;
+      if (i < LH * LH) { sx[r][q] = vx[k]; sy[r][q] = vy[k]; }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < LH * LT; i += 256) {       // horizontal pass: 42 rows x 32 columns
@@ -109,10 +122,24 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
   const int c = blockIdx.z;
   const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-  for (int i = threadIdx.x; i < LH * LH; i += 256) {
-    const int r = i / LH, q = i % LH;
+  {
+    constexpr int NL = (LH * LH + 255) / 256;            // every load of the thread in flight at once (see ssim_fwd_kernel)
+    float v[NL][3];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) sd[m][r][q] = tile_load(dmaps + m * cp + c * plane, H, W, y0 + r - LR, x0 + q - LR);
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k, r = i / LH, q = i % LH;
+      const bool in = i < LH * LH;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) v[k][m] = in ? tile_load(dmaps + m * cp + c * plane, H, W, y0 + r - LR, x0 + q - LR) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k, r = i / LH, q = i % LH;
+      if (i < LH * LH) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sd[m][r][q] = v[k][m];
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < LH * LT; i += 256) {
