@@ -103,7 +103,16 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
                                                           float* __restrict__ out2) {
   __shared__ double sh[2][256];
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * 256) {   // eight pairs in flight; same summation order as one by one
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      v[u] = (i < nblocks) ? *reinterpret_cast<const float2*>(partial + 2 * (size_t)i) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += (double)v[u].x; b += (double)v[u].y; }
+  }
   sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
