@@ -54,13 +54,21 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict
   if (g >= P) return;
   float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
   const int e1 = rev_ptr[g + 1];
-  for (int e = rev_ptr[g]; e < e1; ++e) {
-    const int src = rev_src[e];                   // i * K + k, ascending: fixed summation order
-    const int i = src / K, k = src - i * K;
-    if ((sel_mask >> k) & 1u) {
-      const float4 v = *reinterpret_cast<const float4*>(g_out + (size_t)i * SM_F + 4 * t);
-      G.x += v.x; G.y += v.y; G.z += v.z; G.w += v.w;
+  for (int e = rev_ptr[g]; e < e1; e += 4) {      // four edges at a time: their two-level loads (edge -> row) overlap
+    int src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) src[u] = (e + u < e1) ? rev_src[e + u] : -1;   // i * K + k, ascending: fixed summation order
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = src[u] >= 0 ? src[u] / K : 0, k = src[u] >= 0 ? src[u] - i * K : 0;
+      const bool on = src[u] >= 0 && ((sel_mask >> k) & 1u);
+      v[u] = on ? *reinterpret_cast<const float4*>(g_out + (size_t)i * SM_F + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!on) src[u] = -1;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (src[u] >= 0) { G.x += v[u].x; G.y += v[u].y; G.z += v[u].z; G.w += v[u].w; }
   }
   const float r = 1.0f / (float)S;
   G.x *= r; G.y *= r; G.z *= r; G.w *= r;
