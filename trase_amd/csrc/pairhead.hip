@@ -71,20 +71,35 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restri
   const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   const bool vec = (HW & 3) == 0 && p0 + 3 < HW;
   uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  for (int n = 0; n < N; ++n) {
-    uint32_t w = 0;
-    const uint8_t* row = masks + (size_t)n * HW;
-    if (vec) w = *reinterpret_cast<const uint32_t*>(row + p0);
-    else {
+  for (int n0 = 0; n0 < N; n0 += 8) {
+   // eight masks' words requested together: every resident wave walks the N masks in step, so with one load per trip the
+   // kernel took N memory round trips (0.098 ms for 100 masks)
+   uint32_t wv[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (p0 + e < HW) w |= (row[p0 + e] ? 1u : 0u) << (8 * e);
-    }
+   for (int u = 0; u < 8; ++u) {
+     uint32_t w = 0;
+     if (n0 + u < N) {
+       const uint8_t* row = masks + (size_t)(n0 + u) * HW;
+       if (vec) w = *reinterpret_cast<const uint32_t*>(row + p0);
+       else {
+#pragma unroll
+         for (int e = 0; e < 4; ++e) if (p0 + e < HW) w |= (row[p0 + e] ? 1u : 0u) << (8 * e);
+       }
+     }
+     wv[u] = w;
+   }
+#pragma unroll
+   for (int u = 0; u < 8; ++u) {
+    const int n = n0 + u;
+    if (n >= N) break;
+    uint32_t w = wv[u];
     w = (w | (w >> 1) | (w >> 2) | (w >> 3) | (w >> 4) | (w >> 5) | (w >> 6) | (w >> 7)) & 0x01010101u;   // any non-zero byte -> 1
     c0 += w & 1u; c1 += (w >> 8) & 1u; c2 += (w >> 16) & 1u; c3 += w >> 24;
     // wave total of the four byte flags: four ballots + scalar popcounts instead of a six-step shuffle reduction
     const uint32_t cnt = (uint32_t)(__popcll(__ballot(w & 1u)) + __popcll(__ballot(w & 0x100u)) + __popcll(__ballot(w & 0x10000u)) +
                                     __popcll(__ballot(w & 0x1000000u)));
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&lsize[n], cnt);
+   }
   }
   if (p0 < HW) cover[p0] = (int32_t)c0;
   if (p0 + 1 < HW) cover[p0 + 1] = (int32_t)c1;
