@@ -572,9 +572,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
 #pragma unroll
   for (int u = 0; u < U; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool col = t < Q;
+  // the flags of the NEXT sixteen pairs are requested before the rows of the current ones (one dependent level less per trip)
+  uint8_t f_cur = (k0 + t < k1) ? flags[k0 + t] : (uint8_t)0;
   for (uint32_t kb = k0; __any(kb < k1); kb += 16) {
-    const uint32_t kk = kb + t;
-    const unsigned long long wm = __ballot(kk < k1 && flags[kk] != 0);
+    const unsigned long long wm = __ballot(f_cur != 0);
+    const uint32_t kn = kb + 16 + t;
+    const uint8_t f_next = (kn < k1) ? flags[kn] : (uint8_t)0;
     uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
     const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * bwd_row_stride(F)) + t;
     while (__any(m != 0)) {
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
 #pragma unroll
       for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
     }
+    f_cur = f_next;
   }
   float4 tot;
   tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x); tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
