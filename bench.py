@@ -253,6 +253,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if world > 1 or args.force_collectives:
+        # RCCL prints its version banner through C stdio when the first communicator is created: push it out of EVERY rank's
+        # buffer now, so that rank 0's JSON line is the last thing on the job's stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     R.profile_enable(2)          # HIP events around the compositing kernels only, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
