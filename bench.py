@@ -187,6 +187,8 @@ def main():
     # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
     bucket = FlatGradBucket(params) if (world > 1 or args.bucket != "auto") else None
+    if bucket is not None:
+        bucket._force = bool(args.force_collectives)      # one-rank RCCL group: issue the collectives anyway
     use_sink = bucket is not None and not args.unfused and args.bucket != "accumulate"
     if use_sink:
         # the fused backward writes every gradient once, straight into the bucket: no zero-fill, no accumulation pass
