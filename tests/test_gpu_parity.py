@@ -13,6 +13,13 @@ from tests.util import settings_for, small_case
 pytestmark = pytest.mark.gpu
 
 MAP_ATOL = 1e-4
+DEPTH_RTOL = 4e-6      # the depth map is the one output that is not O(1): its bar is max(1e-4, 4e-6 * largest depth) --
+                       # float32 compositing itself (weights known to ~1e-6 after a hundred products) moves a depth of 50
+                       # by ~7e-5; the kernel accumulates depth in fp32, outside the bf16-split GEMM
+
+
+def depth_atol(o):
+    return max(MAP_ATOL, DEPTH_RTOL * float(o.depth.detach().abs().max()))
 
 
 def _dev():
@@ -122,7 +129,8 @@ def _check_maps(gpu_out, o, frag_budget=FRAG_BUDGET):
         if a.numel() == 0 or not bool(ok.any()):
             continue
         err = (a.double() - b.detach()).abs()
-        assert err[:, ok].max().item() < MAP_ATOL, f"{name}: max abs err {err[:, ok].max().item():.3e}"
+        atol = depth_atol(o) if name == "depth" else MAP_ATOL
+        assert err[:, ok].max().item() < atol, f"{name}: max abs err {err[:, ok].max().item():.3e} (bar {atol:.1e})"
         # even where a discrete gate may flip the damage is bounded by one alpha_min-sized contribution
         scale = max(1.0, b.detach().abs().max().item())
         assert err[:, region].max().item() < 0.05 * scale, f"{name}: fragile-pixel error {err[:, region].max().item():.3e}"
@@ -135,7 +143,7 @@ def _masked(cot, o):
     return cot * (~o.fragile & o.tile_mask).to(cot.dtype)[None]
 
 
-def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5):
+def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5, report=None):
     """Per entry: |a - b| <= rtol max(|b|, 0.1 rowmax|b|) + atol_rel * max|b| * sqrt(footprint / 64).  A gradient entry is a sum over the
     Gaussian's pixels; float32 (and bf16-split MFMA) rounding noise of such a sum grows like the square root of the
     number of terms, and for a screen-filling Gaussian under a random-sign cotangent the sum itself cancels to a small
@@ -157,6 +165,17 @@ def _check_grads(gl, ol, o, names, rtol=1e-3, atol_rel=1e-5):
         b_eff = torch.maximum(b.abs(), 0.1 * b.abs().amax(dim=1, keepdim=True))
         tol = rtol * b_eff + atol_rel * max(b.abs().max().item(), 1e-12) * grow + 1e-9
         bad = (a - b).abs() > tol
+        if report is not None:
+            # how many entries the ORIGINAL per-entry rule (rtol |b| + atol_rel max|b|, no row scale, no footprint growth)
+            # would reject, and how small those entries are against their own row: BASELINE.md section 5 quotes both rules
+            tol0 = rtol * b.abs() + atol_rel * max(b.abs().max().item(), 1e-12)
+            bad0 = (a - b).abs() > tol0
+            rowmax = b.abs().amax(dim=1, keepdim=True).expand_as(b)
+            report[k] = {"entries": int(b.numel()), "fail_original_rule": int(bad0.sum()), "fail_current_rule": int(bad.sum()),
+                         "worst_abs_err_over_max": float(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()),
+                         "failing_entry_over_rowmax_median": float((b.abs()[bad0] / rowmax[bad0].clamp_min(1e-30)).median().item()) if bool(bad0.any()) else None,
+                         "failing_entry_over_rowmax_max": float((b.abs()[bad0] / rowmax[bad0].clamp_min(1e-30)).max().item()) if bool(bad0.any()) else None,
+                         "rel_l2": float(((a - b).norm() / b.norm().clamp_min(1e-30)).item())}
         if bad.any():
             w = int(torch.nonzero(bad.any(dim=1))[0])
             gi = int(torch.nonzero(keep).reshape(-1)[w])

@@ -39,12 +39,21 @@ def _sweep_configs(count=None, seed=None):
     return cfgs
 
 
-def _one(n, w, h, seed, scale, feat=32):
-    act, cam = small_case(n=n, w=w, h=h, feat=feat, seed=seed, scale_mult=scale, d_rot=0.05)
+def _one(n, w, h, seed, scale, feat=32, stats=None, **scene_kw):
+    act, cam = small_case(n=n, w=w, h=h, feat=feat, seed=seed, scale_mult=scale, d_rot=0.05, **scene_kw)
     st = settings_for(cam, bg=(0.1, 0.25, 0.4))
     g, gl = T._gpu_call(act, st)
     o, ol = T._oracle_call(act, st, gpu=g)
     n_frag, n_reg = T._check_maps(g, o)
+    if stats is not None:
+        ok = ~o.fragile
+        stats["z_max"] = max(stats.get("z_max", 0.0), float(o.depth.max()))
+        stats["depth_err"] = max(stats.get("depth_err", 0.0), float((g[3].detach().cpu().double() - o.depth).abs()[:, ok].max()))
+        stats["map_err"] = max(stats.get("map_err", 0.0), float((g[0].detach().cpu().double() - o.image).abs()[:, ok].max()),
+                               float((g[2].detach().cpu().double() - o.feats).abs()[:, ok].max()))
+        stats["culled"] = stats.get("culled", 0) + int((o.radii == 0).sum())
+        stats["gaussians"] = stats.get("gaussians", 0) + n
+        stats["max_radius"] = max(stats.get("max_radius", 0), int(o.radii.max()))
     gen = torch.Generator().manual_seed(seed)
     gi = T._masked(torch.randn(3, h, w, generator=gen), o)
     gf = T._masked(torch.randn(feat, h, w, generator=gen), o)
@@ -71,6 +80,61 @@ def test_random_parity_sweep():
     assert share < 0.005, f"fragile-pixel share of the sweep {share:.4f} >= 0.5 %"
 
 
+# Camera / scene families beyond the orbit-at-radius-4 view of a uniform cube (VERDICT r2 "missing 1"): the reference's
+# cameras come from COLMAP / Nerfies with znear 0.01, zfar 100 (scene/cameras.py:70-71) and its GUIs fly through the scene.
+#   inside    -- camera INSIDE the cloud (radius 0.5-1.2 of a +-1.3 cube): mass near culls (z <= 0.2), many clamped
+#                tx/tz (1.3 tanfov), screen-filling splats
+#   far       -- the cloud scaled x5..x20, camera moved out alike: z in [14, 106] (the depth map's magnitude)
+#   clusters  -- blobs of different density over a sparse background: empty and very deep tile lists in one image
+#   longfocal -- focal 3-5 W from radius 6-10: large splats, small field of view
+def _family_configs(per_family=12, seed=20260929):
+    rnd = random.Random(seed)
+    out = []
+    for fam in ("inside", "far", "clusters", "longfocal"):
+        for _ in range(per_family):
+            n = rnd.choice([333, 777, 2000, 3500])
+            w, h = rnd.choice([64, 100, 160, 250]), rnd.choice([17, 64, 90, 136])
+            sd, sc = rnd.randrange(10_000), rnd.choice([0.3, 0.6, 1.0, 1.8])
+            if fam == "inside":
+                kw = dict(radius=rnd.choice([0.5, 0.7, 0.9, 1.2]), focal_mult=rnd.choice([0.6, 0.9, 1.2]), angle=rnd.uniform(0, 6.28),
+                          elevation=rnd.uniform(-0.6, 0.6))
+                sc = min(sc, 1.0)
+            elif fam == "far":
+                kw = dict(world_scale=rnd.choice([5.0, 10.0, 12.5, 20.0]), angle=rnd.uniform(0, 6.28))
+            elif fam == "clusters":
+                kw = dict(layout="clusters", angle=rnd.uniform(0, 6.28), elevation=rnd.uniform(-0.4, 0.8))
+            else:
+                kw = dict(focal_mult=rnd.choice([3.0, 4.0, 5.0]), radius=rnd.choice([6.0, 8.0, 10.0]), angle=rnd.uniform(0, 6.28))
+            out.append((fam, (n, w, h, sd, sc), kw))
+    return out
+
+
+def test_camera_and_scene_families():
+    """48 configurations of the four families, forward maps + every gradient against the oracle; per family the largest
+    depth seen and the largest depth / map error are reported (and written to gpurun_out/ when it exists)."""
+    import json
+    torch.set_num_threads(max(1, min(32, (torch.get_num_threads() or 1))))
+    per = {}
+    failures = []
+    tot_frag = tot_pix = 0
+    for fam, cfg, kw in _family_configs():
+        st = per.setdefault(fam, {"configs": 0})
+        try:
+            a, b, _ = _one(*cfg, stats=st, **kw)
+            st["configs"] += 1
+            tot_frag, tot_pix = tot_frag + a, tot_pix + b
+        except AssertionError as e:
+            failures.append((fam, cfg, kw, str(e)[:300]))
+    for fam, st in per.items():
+        print(f"family {fam}: {st}")
+    if os.path.isdir("gpurun_out"):
+        json.dump(per, open("gpurun_out/parity_families.json", "w"), indent=1)
+    assert not failures, f"{len(failures)} family configurations fail: {failures[:6]}"
+    assert tot_frag / max(tot_pix, 1) < 0.01
+    assert per["far"]["z_max"] > 50 and per["far"]["depth_err"] < max(1e-4, T.DEPTH_RTOL * per["far"]["z_max"])
+    assert per["inside"]["culled"] > 0.3 * per["inside"]["gaussians"]
+
+
 def _sample_tiles(w, h, share, seed):
     gx, gy = (w + 15) // 16, (h + 15) // 16
     rnd = random.Random(seed)
@@ -82,17 +146,19 @@ def _sample_tiles(w, h, share, seed):
 
 
 FULL_SIZE = [
-    ("S2 NeRF-DS size", 150_000, 480, 270, 0.05),
-    ("S4 headline", 300_000, 1920, 1080, 0.01),
-    ("S3 Neu3D size", 1_000_000, 1352, 1014, 0.01),
-    ("S5 Immersive size (one rank's share)", 2_500_000, 1280, 960, 0.006),
+    ("S2 NeRF-DS size", 150_000, 480, 270, 0.05, {}),
+    ("S4 headline", 300_000, 1920, 1080, 0.01, {}),
+    ("S3 Neu3D size", 1_000_000, 1352, 1014, 0.01, {}),
+    ("S5 Immersive size (one rank's share)", 2_500_000, 1280, 960, 0.006, {}),
+    ("S4-inside: S4 size, camera inside the cloud", 300_000, 1920, 1080, 0.004, dict(radius=0.9)),
+    ("S4-far: S4 size, cloud x12.5 (z in 28..72)", 300_000, 1920, 1080, 0.01, dict(world_scale=12.5)),
 ]
 
 
-@pytest.mark.parametrize("name,n,w,h,share", FULL_SIZE, ids=[c[0].split()[0] for c in FULL_SIZE])
-def test_fullsize_sampled_tile_parity(name, n, w, h, share):
+@pytest.mark.parametrize("name,n,w,h,share,scene_kw", FULL_SIZE, ids=[c[0].split()[0].rstrip(":") for c in FULL_SIZE])
+def test_fullsize_sampled_tile_parity(name, n, w, h, share, scene_kw):
     """Full-size forward + backward on the GPU; the float64 oracle composites a seeded sample of tiles."""
-    act, cam = small_case(n=n, w=w, h=h, feat=32, seed=0, scale_mult=0.27, angle=0.3)
+    act, cam = small_case(n=n, w=w, h=h, feat=32, seed=0, scale_mult=0.27, angle=0.3, **scene_kw)
     st = settings_for(cam, bg=(0.1, 0.25, 0.4))
     tiles = _sample_tiles(w, h, share, seed=n)
     g, gl = T._gpu_call(act, st)
@@ -104,7 +170,17 @@ def test_fullsize_sampled_tile_parity(name, n, w, h, share):
     gf = T._masked(torch.randn(32, h, w, generator=gen), o)
     (o.image * gi.double()).sum().add((o.feats * gf.double()).sum()).backward()
     torch.autograd.backward([g[0], g[2]], [gi.cuda(), gf.cuda()])
-    T._check_grads(gl, ol, o, ["means3D", "means2D", "opacities", "scales", "rotations", "shs", "sh_objs"])
+    report = {}
+    T._check_grads(gl, ol, o, ["means3D", "means2D", "opacities", "scales", "rotations", "shs", "sh_objs"], report=report)
+    print(f"{name}: gradient entries failing the original per-entry rule (rtol 1e-3 |b| + 1e-5 max|b|): "
+          + ", ".join(f"{k} {v['fail_original_rule']}/{v['entries']}" for k, v in report.items()))
+    if os.path.isdir("gpurun_out"):
+        import json
+        path = "gpurun_out/grad_tolerance.json"
+        allrep = json.load(open(path)) if os.path.exists(path) else {}
+        allrep[name] = {"depth_err_max": float((g[3].detach().cpu().double() - o.depth).abs()[:, ~o.fragile & o.tile_mask].max()),
+                        "z_max": float(o.depth.max()), "gradients": report}
+        json.dump(allrep, open(path, "w"), indent=1)
     touched = int((ol["opacities"].grad.abs().reshape(-1) > 0).sum())
     print(f"{name}: {len(tiles)} tiles, {n_reg} pixels compared, {n_frag} fragile ({100 * n_frag / n_reg:.3f} %), "
           f"{o.pairs_done} (tile,Gaussian) pairs composited of R = {o.num_rendered}, {touched} Gaussians with gradient")

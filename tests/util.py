@@ -25,10 +25,13 @@ def settings_for(cam, sh_degree=3, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, devic
         sh_degree=sh_degree, campos=cam.camera_center.to(device), prefiltered=False, debug=debug)
 
 
-def small_case(n=400, w=96, h=64, feat=32, seed=0, scale_mult=0.9, angle=0.4, d_rot=0.0, opacity_mode="trained"):
-    """Activated inputs of one rasterizer call (CPU tensors)."""
-    scene = make_scene(n, feat_dim=max(feat, 1), seed=seed, scale_mult=scale_mult, opacity_mode=opacity_mode)
-    cam = orbit_camera(w, h, angle=angle)
+def small_case(n=400, w=96, h=64, feat=32, seed=0, scale_mult=0.9, angle=0.4, d_rot=0.0, opacity_mode="trained",
+               layout="cube", world_scale=1.0, radius=4.0, elevation=0.15, focal_mult=1.2):
+    """Activated inputs of one rasterizer call (CPU tensors).  radius is given in units of the UNSCALED scene (the
+    camera moves out with world_scale, so the image stays the same and only the view depth grows)."""
+    scene = make_scene(n, feat_dim=max(feat, 1), seed=seed, scale_mult=scale_mult, opacity_mode=opacity_mode,
+                       layout=layout, world_scale=world_scale)
+    cam = orbit_camera(w, h, angle=angle, radius=radius * world_scale, elevation=elevation, focal_mult=focal_mult)
     act = scene.activated()
     if d_rot:
         g = torch.Generator().manual_seed(seed + 7)

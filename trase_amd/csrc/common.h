@@ -132,7 +132,8 @@ __device__ __forceinline__ void wave_scan_add2_asm(float& a, float& b) {
 //   e(j,i) = log2(e) * power + log2(opacity),   (j,i) = pixel coordinates inside the 8x8 sub-tile,
 // expanded once per pair into a polynomial in (j,i) around the sub-tile origin.  Forward and
 // backward evaluate the SAME expression tree (explicit fmaf), so their gate decisions agree bit
-// for bit:   power <= 0  <=>  e <= thr (= log2 opacity);   alpha >= 1/255  <=>  e >= LOG2_ALPHA_MIN.
+// for bit:   power <= 0  <=>  e <= thr (= log2 opacity + the polynomial's own rounding allowance, see pair_poly);
+// alpha >= 1/255  <=>  e >= LOG2_ALPHA_MIN.
 constexpr float LOG2_ALPHA_MIN = -7.994353436858858f;   // log2(1/255)
 struct PairPoly { float k0, kj, ki, kjj, kii, kij, thr; };
 
@@ -141,13 +142,21 @@ __device__ __forceinline__ PairPoly pair_poly(float2 gxy, float4 co, float bx, f
   const float rx = gxy.x - bx, ry = gxy.y - by;
   const float A = co.x, B = co.y, C = co.z;
   PairPoly k;
-  k.thr = __log2f(co.w);
-  k.k0 = fmaf(L, fmaf(-0.5f, fmaf(A * rx, rx, C * ry * ry), -(B * rx) * ry), k.thr);
+  const float lo = __log2f(co.w);
+  k.k0 = fmaf(L, fmaf(-0.5f, fmaf(A * rx, rx, C * ry * ry), -(B * rx) * ry), lo);
   k.kj = L * fmaf(A, rx, B * ry);
   k.ki = L * fmaf(C, ry, B * rx);
   k.kjj = -0.5f * L * A;
   k.kii = -0.5f * L * C;
   k.kij = -L * B;
+  // The lineage's "power > 0 -> skip" guard: for a positive-definite conic power <= 0 holds exactly, and the lineage's
+  // direct evaluation of the quadratic form in (pixel - centre) keeps that sign at the splat's centre.  The polynomial
+  // about the sub-tile origin cancels terms of size M = sum |k| * (monomial bound), so its value carries ~1e-6 M of
+  // rounding and would trip the guard spuriously at the centre pixel of a large flat splat (sigma > 100 px: long-focal
+  // cameras, the camera inside the cloud).  The guard therefore allows exactly that evaluation error; a genuinely positive
+  // power (a non-positive-definite conic from a caller-supplied covariance) is still skipped.
+  const float M = fabsf(k.k0) + 7.0f * (fabsf(k.kj) + fabsf(k.ki)) + 49.0f * (fabsf(k.kjj) + fabsf(k.kii) + fabsf(k.kij));
+  k.thr = fmaf(9.5e-7f, M, lo);
   return k;
 }
 // row part (pixel row i) and full exponent (pixel column j)

@@ -101,7 +101,13 @@ __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ co
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool FEAT_ONLY, bool TIMING>
+// COUNT (variant 0x8000, diagnostic): lane utilisation.  Header words 40..47 receive, summed over the launch:
+//   40 list entries walked (sum of chunk lengths)      41 chunks
+//   42 pixel-pair steps executed (of 16 per chunk)     43 steps skipped by the 4-pixel last-contributor test
+//   44 (pixel, Gaussian) lane slots of executed steps that hold a real list entry
+//   45 ... of those, slots that pass the two exponent gates (power <= 0, alpha >= 1/255)
+//   46 ... of those, slots that are blended (also in front of the pixel's last contributor)
+template <bool FEAT_ONLY, bool TIMING, bool COUNT = false>
 #ifndef HW_OCC
 #define HW_OCC 4
 #endif
@@ -121,6 +127,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   uint64_t t_mark = 0, t_acc[5] = {0, 0, 0, 0, 0};
   auto tick = [&](int k) { if constexpr (TIMING) { const uint64_t t = __builtin_readcyclecounter(); t_acc[k] += t - t_mark; t_mark = t; } };
   if constexpr (TIMING) t_mark = __builtin_readcyclecounter();
+  uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};
   // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
   uint32_t last;
   {
@@ -192,6 +199,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const uint32_t c0 = (c1 > HW_G) ? c1 - HW_G : 0;
     const uint32_t n = c1 - c0;
     const bool lane_valid = (uint32_t)g < n;
+    if constexpr (COUNT) { cnt[0] += n; cnt[1] += 1; }
     const uint32_t pos = lane_valid ? (c1 - 1 - g) : 0;        // g = 0: farthest entry of the chunk
     const uint32_t id = id_n;
     const uint32_t slot = slot_n;
@@ -254,6 +262,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           // last-contributor indices of the four pixels of this step (lane = pixel register, wave-uniform reads)
           const int p0 = i * SUB + r;                      // half 0: p0, p0+1; half 1: p0+4, p0+5
           float wa = 0.f, wb = 0.f;
+          if constexpr (COUNT) { if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) cnt[2] += 1; else cnt[3] += 1; }
           if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) {
             const int pl = p0 + 4 * h;                     // this lane's first pixel of the step
             const float4 pa = L.pix[pl], pb = L.pix[pl + 1];
@@ -262,6 +271,12 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             const float eb = poly_eval(k, base, slope, jv[r + 1]);
             const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
             const bool okb = (eb <= k.thr) && (eb >= LOG2_ALPHA_MIN) && (pos_cmp < lastb);
+            if constexpr (COUNT) {
+              cnt[4] += 2 * (uint32_t)__builtin_popcountll(__ballot(lane_valid));
+              cnt[5] += (uint32_t)__builtin_popcountll(__ballot(lane_valid && (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN))) +
+                        (uint32_t)__builtin_popcountll(__ballot(lane_valid && (eb <= k.thr) && (eb >= LOG2_ALPHA_MIN)));
+              cnt[6] += (uint32_t)__builtin_popcountll(__ballot(oka)) + (uint32_t)__builtin_popcountll(__ballot(okb));
+            }
             const float ra = __builtin_amdgcn_exp2f(oka ? ea : -INFINITY);   // opacity * exp(power); closed gate = 0
             const float rb = __builtin_amdgcn_exp2f(okb ? eb : -INFINITY);
             const float ala = fminf(ALPHA_MAX, ra), alb = fminf(ALPHA_MAX, rb);
@@ -359,6 +374,12 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     wave_lds_sync_hw();                                   // carries written by lanes 31 / 63 are read by the next chunk
     tick(0);
   }
+  if constexpr (COUNT) {
+    if (lane == 0 && a.prof) {
+#pragma unroll
+      for (int k2 = 0; k2 < 7; ++k2) atomicAdd(a.prof + 8 + k2, cnt[k2]);
+    }
+  }
   if constexpr (TIMING) {
     if (lane == 0 && a.prof) {
 #pragma unroll
@@ -388,6 +409,7 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
     const dim3 grid((a.ntiles + HW_WPB - 1) / HW_WPB), block(HW_WPB * WAVE);
     if (c.variant & 0x400) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);   // feature gradients only
     else if (c.variant & 0x1000) hipLaunchKernelGGL((render_bwd_hw_kernel<false, true>), grid, block, 0, c.stream, a);   // phase timing
+    else if (c.variant & 0x8000) hipLaunchKernelGGL((render_bwd_hw_kernel<false, false, true>), grid, block, 0, c.stream, a);   // lane-utilisation counters
     else hipLaunchKernelGGL((render_bwd_hw_kernel<false, false>), grid, block, 0, c.stream, a);
   }
   TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);

@@ -21,6 +21,10 @@
 //     lines per instruction instead of one per lane), split to bf16 hi / lo and written TRANSPOSED into a
 //     [channel][entry] tile in LDS, so that a B fragment (eight consecutive entries of one channel) is one ds_read_b128.
 //     r, g, b, depth are channels 32..35 of the same tile.
+//   * the DEPTH map is the one output whose magnitude is not O(1) (view depth up to zfar = 100, scene/cameras.py:70): the
+//     bf16-split product carries ~1e-5 RELATIVE, i.e. 5e-4 abs at z = 50.  Depth is therefore accumulated by each lane in
+//     fp32 from the weights it already holds (8 FMAs per K-step; the two lanes of a pixel add their halves in the epilogue)
+//     and holds the 1e-4 abs bar at any depth; channel 35 of the GEMM is left in place, unused.
 //   * the background term T_final * bg is added in fp32 in the epilogue (final_T reaches the accumulator layout
 //     through LDS): an empty pixel shows the background exactly.
 // Semantics: SURVEY.md Appendix A "Render fwd"; gates evaluated on the same exponent polynomial as every backward
@@ -46,6 +50,7 @@ struct FmLds {
   __bf16 lo[FM_CH * FM_LD];
   float4 k0[FM_G];                // k0, kj, ki, kjj
   float4 k1[FM_G];                // kii, kij, thr, -
+  float zs[FM_G];                 // view depth of the chunk's entries: the depth map is accumulated in fp32 (see below)
   float tfin[2][32];              // final_T of the two pixel blocks (epilogue)
   int live[2];                    // "some pixel of wave w is still live"
 };
@@ -71,7 +76,7 @@ __device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigne
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
 }
 
-__global__ __launch_bounds__(FM_WAVES* WAVE) __attribute__((amdgpu_waves_per_eu(4, 5)))
+__global__ __launch_bounds__(FM_WAVES* WAVE) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void render_fwd_mf_kernel(FwdMfArgs a) {
   constexpr int F = 32;
   __shared__ __attribute__((aligned(16))) FmLds L;
@@ -102,6 +107,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   // finished; Tc = the value final_T reports; lastc = n_contrib
   float Tin = inside ? 1.0f : 0.0f, Tc = 1.0f;
   uint32_t lastc = 0;
+  float dacc = 0.f;                                      // fp32 depth of this lane's half of every K-step
   // channel column of this lane in the B fragments: block 0 = feature m; block 1 = channel 32 + m, rows >= 40 do not
   // exist (zero): read the zero row 39 instead
   const int brow0 = m * FM_LD, brow1 = min(32 + m, FM_CH - 1) * FM_LD;
@@ -140,8 +146,11 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
         L.k0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         L.k1[lane] = make_float4(0.f, 0.f, -INFINITY, 0.f);
       }
-    } else if ((uint32_t)lane < n) {                     // r g b depth -> tile rows 32..35
-      const float4 cd = a.rgbd[my_id];
+    } else {                                             // r g b depth -> tile rows 32..35; depth also as fp32
+      float4 cd = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((uint32_t)lane < n) cd = a.rgbd[my_id];
+      L.zs[lane] = cd.w;                                 // past the end of the list: 0 (its weight is 0 as well)
+      if ((uint32_t)lane < n) {
       unsigned h01, l01, h23, l23;
       split_pk(cd.x, cd.y, h01, l01);
       split_pk(cd.z, cd.w, h23, l23);
@@ -149,6 +158,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
       unsigned short* tl = reinterpret_cast<unsigned short*>(L.lo) + 32 * FM_LD + lane;
       th[0] = (unsigned short)h01; th[FM_LD] = (unsigned short)(h01 >> 16); th[2 * FM_LD] = (unsigned short)h23; th[3 * FM_LD] = (unsigned short)(h23 >> 16);
       tl[0] = (unsigned short)l01; tl[FM_LD] = (unsigned short)(l01 >> 16); tl[2 * FM_LD] = (unsigned short)l23; tl[3 * FM_LD] = (unsigned short)(l23 >> 16);
+      }
     }
 #pragma unroll
     for (int r = 0; r < FM_G / 16; ++r) {                // transposed: tile[channel 4 (lane & 7) + e][entry 16r + 8wv + (lane >> 3)]
@@ -225,6 +235,9 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
           // finishes reports the whole list (entries behind its last blended one fail the same gates in the backward)
           lastc = (base - range.x) + min(n, (uint32_t)(16 * t + 16));
         }
+        const float4 z0 = *reinterpret_cast<const float4*>(&L.zs[e0]), z1 = *reinterpret_cast<const float4*>(&L.zs[e0 + 4]);
+        dacc = fmaf(w[0], z0.x, dacc); dacc = fmaf(w[1], z0.y, dacc); dacc = fmaf(w[2], z0.z, dacc); dacc = fmaf(w[3], z0.w, dacc);
+        dacc = fmaf(w[4], z1.x, dacc); dacc = fmaf(w[5], z1.y, dacc); dacc = fmaf(w[6], z1.z, dacc); dacc = fmaf(w[7], z1.w, dacc);
         // ---- MFMA: D[nb] += w (32 pixels x 16 entries) * tile (16 entries x 32 channels) ------------------------
         u32x4 ah, al;
 #pragma unroll
@@ -251,11 +264,16 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   // ---- outputs -----------------------------------------------------------------------------------------------
   const size_t hw = (size_t)a.H * a.W;
   const int x0 = tx * SUB, y0 = ty * SUB;
+  {
+    const auto sd = __builtin_amdgcn_permlane32_swap(__float_as_uint(dacc), __float_as_uint(dacc), false, false);
+    dacc = __uint_as_float(sd[0]) + __uint_as_float(sd[1]);
+  }
   if (h == 0) {
     if (inside) {
       const size_t pix = (size_t)(y0 + pi) * a.W + x0 + pj;
       a.final_T[pix] = Tc;
       a.n_contrib[pix] = lastc;
+      a.out_depth[pix] = dacc;
     }
     L.tfin[wv][m] = Tc;                                  // final_T in pixel order: the accumulator layout reads it back
   }
@@ -270,8 +288,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
     const size_t rowo = (size_t)y * a.W + x0 + 4 * h;
     float* pf = a.out_feat + (size_t)m * hw + rowo;
     float* pc = nullptr;                                 // channel block 1: r g b (image planes) and depth
-    if (m < 3) pc = a.out_img + (size_t)m * hw + rowo;
-    else if (m == 3) pc = a.out_depth + rowo;
+    if (m < 3) pc = a.out_img + (size_t)m * hw + rowo;   // (depth: written above from the fp32 accumulation)
     const float4 vf = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
     const float4 tq = *reinterpret_cast<const float4*>(&L.tfin[wv][8 * q + 4 * h]);   // final_T of this register quad's pixels
     const float4 vc = make_float4(fmaf(tq.x, bgc, D[1][4 * q]), fmaf(tq.y, bgc, D[1][4 * q + 1]),

@@ -69,8 +69,12 @@ class SynthCamera:
 
 
 def orbit_camera(width: int, height: int, angle: float = 0.0, radius: float = 4.0,
-                 elevation: float = 0.15, focal_mult: float = 1.2, fid: float = 0.0) -> SynthCamera:
-    """Camera on an orbit looking at the origin; focal = focal_mult * W."""
+                 elevation: float = 0.15, focal_mult: float = 1.2, fid: float = 0.0,
+                 znear: float = 0.01, zfar: float = 100.0) -> SynthCamera:
+    """Camera on an orbit looking at the origin; focal = focal_mult * W.  znear / zfar default to the
+    reference's Camera constants (scene/cameras.py:70-71).  radius < scene extent puts the camera INSIDE the cloud
+    (the reference's GUIs fly through the scene, gui.py:927-1128): Gaussians behind the image plane, at the near cull
+    and with clamped tx/tz then dominate."""
     focal = focal_mult * width
     fovx = 2 * math.atan(width / (2 * focal))
     fovy = 2 * math.atan(height / (2 * focal))
@@ -85,11 +89,11 @@ def orbit_camera(width: int, height: int, angle: float = 0.0, radius: float = 4.
     Rc2w = torch.stack([right, down, fwd], dim=1)          # columns = camera axes in world
     t = -(Rc2w.T @ eye)
     wvt = world2view(Rc2w, t).transpose(0, 1).contiguous()
-    proj = projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).contiguous()
+    proj = projection_matrix(znear, zfar, fovx, fovy).transpose(0, 1).contiguous()
     full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
     center = wvt.inverse()[3, :3].contiguous()
     return SynthCamera(width, height, fovx, fovy, wvt, proj, full, center,
-                       torch.tensor([fid], dtype=torch.float32))
+                       torch.tensor([fid], dtype=torch.float32), znear, zfar)
 
 
 @dataclass
@@ -121,17 +125,40 @@ class SynthScene:
 
 
 def make_scene(n: int, feat_dim: int = 32, seed: int = 0, extent: float = 1.3,
-               scale_mult: float = 0.3, opacity_mode: str = "trained") -> SynthScene:
+               scale_mult: float = 0.3, opacity_mode: str = "trained", layout: str = "cube",
+               world_scale: float = 1.0) -> SynthScene:
     """xyz ~ U(-extent, extent)^3 (scene/dataset_readers.py:409), scales from the mean
     point spacing (stand-in for log(sqrt(distCUDA2)), scene/gaussian_model.py:237-238)
     jittered by +-0.5 in log space, normalised N(0,1) quaternions, opacity logits
     N(0,2) ('trained') or inverse_sigmoid(0.1) ('init'), SH dc = RGB2SH(U(0,1)),
-    rest ~ N(0,0.05), features = RGB2SH(U(0,1)) (scene/gaussian_model.py:232)."""
+    rest ~ N(0,0.05), features = RGB2SH(U(0,1)) (scene/gaussian_model.py:232).
+
+    layout="clusters" (SURVEY 8d names clustered blobs): the same cube draws are pulled towards 2 + seed % 6 blob
+    centres (Gaussian blobs of different widths over a sparse uniform background), so that tile lists range from empty
+    to very deep inside one image.  world_scale multiplies positions AND sizes (the image is unchanged when the camera
+    radius is scaled alike; view depth is not): world_scale 5..20 with a radius-4*world_scale camera gives
+    z in [20, 100], the reference's zfar (scene/cameras.py:70)."""
     g = torch.Generator().manual_seed(seed)
     xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * extent
     spacing = ((2 * extent) ** 3 / max(n, 1)) ** (1.0 / 3.0)
     base = math.log(scale_mult * spacing)
     scaling = base + (torch.rand(n, 3, generator=g) - 0.5)
+    if layout == "clusters":
+        g2 = torch.Generator().manual_seed(seed * 7919 + 13)
+        k = 2 + seed % 6
+        centres = (torch.rand(k, 3, generator=g2) * 2 - 1) * (0.75 * extent)
+        widths = 0.04 + 0.25 * torch.rand(k, generator=g2)
+        which = torch.randint(0, k, (n,), generator=g2)
+        in_blob = torch.rand(n, generator=g2) < 0.85
+        blob = centres[which] + (xyz / extent) * 0.6 * extent * widths[which][:, None] * 3.0
+        xyz = torch.where(in_blob[:, None], blob, xyz)
+        # denser blobs hold smaller splats (what densification produces)
+        scaling = scaling + torch.where(in_blob, torch.log(widths[which] * 3.0).clamp(max=0.0), torch.zeros(n))[:, None]
+    elif layout != "cube":
+        raise ValueError(f"unknown scene layout {layout!r}")
+    if world_scale != 1.0:
+        xyz = xyz * world_scale
+        scaling = scaling + math.log(world_scale)
     rotation = torch.randn(n, 4, generator=g)
     if opacity_mode == "trained":
         opacity = torch.randn(n, 1, generator=g) * 2.0
