@@ -37,6 +37,19 @@ CLOCK_HZ = 2.4e9               # peak engine clock
 C_RGB = 3
 
 
+def source_sha16() -> str:
+    """Hash of the kernel sources the library is built from (stable across rebuilds, unlike the .so): stamps PMC tables
+    so that replayed counters are only reported for the build they were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "trase_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(kernel: str, n: int, r: int, p: int, f: int) -> float:
     """SURVEY.md 8(d) per-kernel algorithmic bytes (general F)."""
     if kernel == "render_bwd":
@@ -301,12 +314,23 @@ def main():
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
         # per-launch PMC figures of the same command (profiles/run_pmc.sh -> profiles/pmc_per_launch.json):
         # HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 note of MI355X_MICROARCH.md; VALU wave-instructions
+        # These are REPLAYED from a tracked table, not counters of this run; `counters_source` says so, and they are only
+        # reported when the table was collected on the kernel sources this library is built from.
         traffic = valu_insts = mfma_insts = None
+        counters_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
         if os.path.exists(tpath) and (N, W, H, F) == (300_000, 1920, 1080, 32) and not args.unfused:   # collected on S4 only
             try:
-                rec = json.load(open(tpath)).get(dom) or {}
-                traffic, valu_insts, mfma_insts = rec.get("hbm_bytes"), rec.get("valu_insts"), rec.get("mfma_insts")
+                table = json.load(open(tpath))
+                rec = table.get(dom) or {}
+                sha_tab, sha_now = table.get("_source_sha16"), source_sha16()
+                if sha_tab == sha_now:
+                    traffic, valu_insts, mfma_insts = rec.get("hbm_bytes"), rec.get("valu_insts"), rec.get("mfma_insts")
+                    counters_source = (f"replayed from profiles/pmc_per_launch.json ({table.get('_from', '?')}; rocprofv3 PMC passes of "
+                                       f"this command on kernel sources {sha_tab}) -- not counters of this run")
+                else:
+                    counters_source = (f"none: profiles/pmc_per_launch.json was collected on kernel sources {sha_tab}, this build is "
+                                       f"{sha_now}; traffic / valu_frac withheld")
             except Exception:
                 pass
         # VALU fraction ("report HBM fraction AND VALU fraction"): a wave64 VALU instruction occupies its SIMD
@@ -333,6 +357,7 @@ def main():
                                         if args.exchange_chunks > 1 else "sink, one all-reduce after the backward")))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "counters_source": counters_source,
                          "valu_frac": None if valu_frac is None else round(valu_frac, 4), "valu_insts": valu_insts,
                          "mfma_insts": mfma_insts,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
@@ -345,7 +370,9 @@ def main():
             # big host the intra-op thread pool costs more than it gives, so the leg is timed twice -- on every core (as
             # BASELINE.md section 4 prescribes) and on min(cores, 32) threads -- and the FASTER one is the baseline
             runs = []
-            for th in sorted({args.cpu_threads or host, min(host, 32)}, reverse=True):
+            # (the all-cores leg is capped at 64 threads: on a 256-core host ONE view of this op chain took 23 s with a
+            # thread per core -- pure pool overhead -- and was then discarded for the 32-thread run)
+            for th in sorted({args.cpu_threads or min(host, 64), min(host, 32)}, reverse=True):
                 print(f"[bench] cpu baseline: reference PyTorch-CPU preprocess on {th} of {host} host cores ...", file=sys.stderr, flush=True)
                 sec_view, reps = cpu_preprocess_baseline(scene_cpu, cams[0], args.cpu_budget_s / 2, th)
                 runs.append({"threads": th, "ms_per_view": round(sec_view * 1e3, 3), "views_timed": reps})

@@ -67,14 +67,23 @@ typedef struct TraseRastSettings {
                             * backward with atomics; 0x40 VALU-only backward for every F; 0x100 dL_ddepth is honoured;
                             * 0x200 point-list gather fused into tile_ranges; 0x400 feature-only backward;
                             * 0x800 round-1 64-entry-chunk MFMA backward; 0x1000 timing instrumentation of the backward;
-                            * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch) */
+                            * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch);
+                            * 0x8000 lane-utilisation counters of the MFMA backward (diagnostic, header words 40..46).
+                            * LINEAGE SWITCHES (the three places the absent fork of the CUDA extension is most
+                            * likely to differ from the public lineage; each flips the HIP kernels AND oracle/raster_oracle.py):
+                            * 0x100 the depth cotangent is honoured; 0x10000 the feature map gets a background term
+                            * feats[c] += T_final * feat_bg; 0x20000 the depth map is normalised, depth = sum(w z) / (1 - T_final) */
   /* Tile-row strip (second multi-GPU axis, SURVEY.md 8e: one view sharded over ranks by rows of 16x16 tiles).  Rows
    * [tile_row_begin, tile_row_end) are binned, composited and differentiated; pixels outside the strip are not written,
    * per-Gaussian gradients are this strip's partial sums (the ranks' strips add up to the full gradient), radii stay
    * whole-image.  begin == end == 0 means the whole image. */
   int32_t tile_row_begin;
   int32_t tile_row_end;
+  float feat_bg;           /* background value of every feature channel; read only when variant & 0x10000 */
+  int32_t reserved0;
 } TraseRastSettings;
+
+enum { TRASE_VARIANT_DEPTH_GRAD = 0x100, TRASE_VARIANT_FEATS_BG = 0x10000, TRASE_VARIANT_DEPTH_NORM = 0x20000 };
 
 /* Inputs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:137-146).
  * Exactly one of shs/colors_precomp and one of (scales,rotations)/cov3D_precomp

@@ -50,8 +50,9 @@ class OracleOptions:
     alpha_max: float = 0.99
     alpha_min: float = 1.0 / 255.0
     t_stop: float = 1e-4
-    feats_bg: bool = False            # features get no background term
-    depth_normalised: bool = False    # depth is NOT divided by accumulated alpha
+    feats_bg: bool = False            # False: features get no background term; True: feats[c] += T_final * feat_bg_value
+    feat_bg_value: float = 0.0
+    depth_normalised: bool = False    # False: blended depth as is; True: depth = sum(w z) / (1 - T_final)
     lineage_grads: bool = True        # straight-through 0.99 clamp; frozen clamped tx/tz
     # fragility margins (relative) used to flag pixels whose discrete decisions
     # may legitimately flip between float32 and float64 arithmetic
@@ -386,6 +387,8 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
     C = 3 + F + 1
     out = torch.zeros(H, W, C, dtype=torch.float64)
     out[..., :3] = out[..., :3] + bg              # pixels of empty tiles show background
+    if opt.feats_bg and F:
+        out[..., 3:3 + F] = opt.feat_bg_value
     final_T = torch.ones(H, W, dtype=torch.float64)
     n_contrib = torch.zeros(H, W, dtype=torch.int64)
     fragile = torch.zeros(H, W, dtype=torch.bool)
@@ -448,7 +451,13 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
             hh, ww = y_hi - y_lo, x_hi - x_lo
             o = o.reshape(hh, ww, C)
             Tf2 = Tf.reshape(hh, ww)
-            o = torch.cat([o[..., :3] + Tf2[..., None] * bg, o[..., 3:]], dim=-1)
+            o_ft, o_dp = o[..., 3:3 + F], o[..., 3 + F:]
+            if opt.feats_bg:                        # lineage switch: features over a background value
+                o_ft = o_ft + Tf2[..., None] * opt.feat_bg_value
+            if opt.depth_normalised:                # lineage switch: depth / accumulated alpha
+                A = (1.0 - Tf2)[..., None]
+                o_dp = torch.where(A > 1e-10, o_dp / A.clamp_min(1e-10), torch.zeros_like(o_dp))
+            o = torch.cat([o[..., :3] + Tf2[..., None] * bg, o_ft, o_dp], dim=-1)
             out[y_lo:y_hi, x_lo:x_hi] = o          # CopySlices: differentiable, O(tile)
             final_T[y_lo:y_hi, x_lo:x_hi] = Tf2.detach()
             n_contrib[y_lo:y_hi, x_lo:x_hi] = nc.reshape(hh, ww)
@@ -470,8 +479,6 @@ def rasterize(settings, means3D, means2D=None, shs=None, sh_objs=None, colors_pr
                 frag_stats["gauss"] += int((~fr).sum())
                 fragile[y_lo:y_hi, x_lo:x_hi] = True
     canvas = out
-    if opt.feats_bg or opt.depth_normalised:
-        raise NotImplementedError("non-default lineage switches are not wired into assembly yet")
     img = canvas[..., :3].permute(2, 0, 1)
     feats = canvas[..., 3:3 + F].permute(2, 0, 1)
     depth = canvas[..., 3 + F:].permute(2, 0, 1)

@@ -5,7 +5,10 @@ kernel name the HBM bytes per launch -- (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH
 wave-instruction counts that bench.py turns into `roofline.traffic` / `roofline.valu_frac`.
 usage: make_pmc_per_launch.py gpurun_out/pmc_<tag>.json [tag]"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NAMES = {"render_bwd": "trase::render_bwd_hw_kernel<false, false>", "render_fwd": "trase::render_fwd_mf_kernel",
          "reduce_rows": "trase::reduce_rows_kernel<44, false>", "preprocess_fwd": "trase::preprocess_fwd_raw_kernel<32>",
@@ -17,6 +20,9 @@ def main():
     tag = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
     out = {"_note": f"per launch, S4 workload, from {tag}: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled per "
                     "the gfx950 correction of MI355X_MICROARCH.md), valu_insts = SQ_INSTS_VALU, mfma_insts = SQ_INSTS_MFMA"}
+    from bench import source_sha16
+    out["_source_sha16"] = source_sha16()     # bench.py replays these figures only for a build of the same kernel sources
+    out["_from"] = tag
     for short, full in NAMES.items():
         c = src.get(full)
         if not c:

@@ -105,3 +105,19 @@ def test_style_transfer_iteration_config5_size():
     assert torch.equal(pc._xyz.detach(), before["_xyz"]) and torch.equal(pc._opacity.detach(), before["_opacity"])
     moved = (pc._features_dc.detach() - before["_features_dc"]).abs().amax(dim=(1, 2)) > 0
     assert not bool(moved[~segmented].any()) and float(moved[segmented].float().mean()) > 0.05
+
+
+def test_style_features_that_require_grad_are_detached_not_refused():
+    """train_style_transfer_nnfm.py:202: ref_vgg_feats comes from a VGG whose weights still require grad."""
+    import warnings
+    from trase_amd.losses import loss_nnfm_style
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.relu(torch.randn(64, 300, generator=g) + 0.3).to(dev).requires_grad_(True)
+    f2 = torch.relu(torch.randn(64, 200, generator=g) + 0.3).to(dev).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = loss_nnfm_style(f1, f2)
+        a.backward()
+    b = loss_nnfm_style(f1.detach().clone().requires_grad_(True), f2.detach())
+    assert torch.equal(a.detach(), b.detach()) and f1.grad is not None and f2.grad is None

@@ -69,7 +69,7 @@ def device_view_of_last_forward(radii):
             "conic_opacity": gv["conic_opacity"].cpu().clone()}
 
 
-def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None, tiles=None):
+def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None, tiles=None, opt=None):
     leaves = {}
     for k in ("means3D", "opacities", "scales", "rotations", "shs", "sh_objs"):
         v = act.get(k)
@@ -86,7 +86,8 @@ def _oracle_call(act, st_cpu, colors=None, cov=None, gpu=None, tiles=None):
                        colors_precomp=leaves.get("colors_precomp"), opacities=leaves["opacities"],
                        scales=leaves.get("scales"), rotations=leaves.get("rotations"),
                        cov3D_precomp=leaves.get("cov3D_precomp"),
-                       device_view=None if gpu is None else _LAST_DEVICE_VIEW, tiles=tiles)
+                       device_view=None if gpu is None else _LAST_DEVICE_VIEW, tiles=tiles,
+                       **({} if opt is None else {"opt": opt}))
     if gpu is not None and _LAST_DEVICE_VIEW is not None:
         _check_device_view(out, _LAST_DEVICE_VIEW)
     return out, leaves

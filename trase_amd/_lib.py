@@ -27,6 +27,7 @@ class RastSettings(C.Structure):
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("device", C.c_int32), ("variant", C.c_int32),
         ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
+        ("feat_bg", C.c_float), ("reserved0", C.c_int32),
     ]
 
 

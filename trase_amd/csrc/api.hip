@@ -339,6 +339,10 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
     g2.dL_dsh_objs = nullptr;
   }
   if (zero_feats) TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
+  if ((s->variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM)) && (s->variant & (1 | 0x800))) {
+    set_error("lineage switches are wired into the default backward kernels only (not variant bits 0x1 / 0x800)");
+    return TRASE_ERR_UNSUPPORTED;
+  }
   if (s->variant & 1) {
     // first-generation "lane = pixel" backward with atomics (kept for A/B ablation)
     TRASE_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * BWD_ACC * (size_t)in->P, stream));
@@ -350,10 +354,10 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
     // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
     if (in2.F == 32 && !(s->variant & 0x40)) {
       rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
-                                : launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+                                : launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity), out->depth);
     } else {
       TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-      rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags);
+      rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags, out->depth);
     }
     if (rc) return rc;
     rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
@@ -461,15 +465,19 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
     in.F = 0;
     d_feats = nullptr;
   }
+  if ((s->variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM)) && (s->variant & 0x800)) {
+    set_error("lineage switches are wired into the default backward kernels only (not variant bit 0x800)");
+    return TRASE_ERR_UNSUPPORTED;
+  }
   if (phase & 1) {
     if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0)
       TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
     if (in.F == 32 && !(s->variant & 0x40)) {
       rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
-                                : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity));
+                                : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity), out->depth);
     } else {
       TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-      rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags);
+      rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags, out->depth);
     }
     if (rc) return rc;
   }

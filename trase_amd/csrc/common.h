@@ -357,7 +357,8 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
 int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                          const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss, uint32_t cap);
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags);
+                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
+                         const float* out_depth = nullptr);
 int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
                          void* chan, size_t flag_bytes);   // clears flag_bytes (a multiple of 16) of row_flags itself
@@ -366,7 +367,7 @@ int launch_split_channels(const LaunchCtx& c, const TraseRastInputs& in, const G
 // half-wave formulation (32-entry chunks, 128 VGPRs): the default for F = 32; variant bit 0x800 selects the 64-entry kernel
 int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan, size_t flag_bytes);
+                         void* chan, size_t flag_bytes, const float* out_depth = nullptr);
 int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                       const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
 

@@ -20,6 +20,8 @@ struct RenderArgs {
   // forward only: when set, the list still holds emit-order slots; the staging step translates them to Gaussian
   // ids (slot -> id is one more dependent load, hidden like the others) and records the ids for the backward
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
+  int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
+  float feat_bg;
 };
 
 // LDS produced and consumed by one wave only: order the accesses without a workgroup barrier
@@ -133,9 +135,12 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
     out_img[pix] = c0 + T * a.bg[0];
     out_img[hw + pix] = c1 + T * a.bg[1];
     out_img[2 * hw + pix] = c2 + T * a.bg[2];
+    if (a.lineage & TRASE_VARIANT_DEPTH_NORM) { const float A = 1.0f - T; cd = A > 1e-10f ? cd / A : 0.0f; }
     out_depth[pix] = cd;
+    const float fb = (a.lineage & TRASE_VARIANT_FEATS_BG) ? a.feat_bg : 0.0f;
 #pragma unroll
-    for (int c = 0; c < F; ++c) out_feat[(size_t)c * hw + pix] = fa2[c >> 1][c & 1];
+    for (int c = 0; c < F; ++c)
+      out_feat[(size_t)c * hw + pix] = (a.lineage & TRASE_VARIANT_FEATS_BG) ? fmaf(T, fb, fa2[c >> 1][c & 1]) : fa2[c >> 1][c & 1];
   }
 }
 
@@ -146,6 +151,7 @@ static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const Tr
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   a.pair_slot = nullptr; a.pair_gauss = nullptr; a.point_list_w = nullptr; a.cap = 0;
+  a.lineage = 0; a.feat_bg = s.feat_bg;
 }
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
@@ -154,6 +160,7 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
     return launch_render_fwd_mf(c, s, in, out, g, b, im, pair_gauss, cap);
   RenderArgs a;
   fill_render_args(a, s, in, g, b);
+  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM);
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip
   const int T = (a.ntiles + WPB - 1) / WPB;

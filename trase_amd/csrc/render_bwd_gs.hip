@@ -33,6 +33,9 @@ struct BwdGsArgs {
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
   int ablate;          // debug/A-B (variant bits 4..7): bit0 skip the row writes, bit1 builtin instead of asm DPP scans
+  int lineage;         // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
+  float feat_bg;
+  const float* out_depth;
 };
 
 __device__ __forceinline__ void wave_lds_sync2() {
@@ -68,6 +71,13 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
       if (a.d_img) { g0 = a.d_img[pix]; g1 = a.d_img[hw + pix]; g2 = a.d_img[2 * hw + pix]; }
       if (a.d_depth) gd = a.d_depth[pix];
     }
+    float bextra = 0.f;                             // lineage switches: see render_bwd_hw.hip
+    if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && a.d_depth && inside) {
+      const float A = 1.0f - Tf;
+      gd = A > 1e-10f ? gd / A : 0.0f;
+      bextra = gd * a.out_depth[pix];
+    }
+    float fsum = 0.f;
     float* row = s_cot[wave][lane];
     *reinterpret_cast<float4*>(row) = make_float4(g0, g1, g2, gd);
     if (F > 0) {
@@ -81,9 +91,11 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
           v.w = a.d_feat[(size_t)(4 * c4 + 3) * hw + pix];
         }
         *reinterpret_cast<float4*>(row + 4 + 4 * c4) = v;
+        fsum += (v.x + v.y) + (v.z + v.w);
       }
     }
-    const float bdot = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2;
+    if (a.lineage & TRASE_VARIANT_FEATS_BG) bextra = fmaf(a.feat_bg, fsum, bextra);
+    const float bdot = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2 + bextra;
     s_pix[wave][lane] = make_float4(Tf, Tf * bdot, __uint_as_float(last), 0.f);
   }
   uint32_t wave_last = last;
@@ -209,8 +221,14 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
 }
 
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags) {
+                         const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
+                         const float* out_depth) {
   BwdGsArgs a;
+  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg; a.out_depth = out_depth;
+  if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && gr.dL_ddepth && !out_depth) {
+    set_error("render_bwd: the normalised-depth switch with a depth cotangent needs the forward's depth map (outputs.depth)");
+    return TRASE_ERR_INVALID;
+  }
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
   a.feats = in.sh_objs; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;

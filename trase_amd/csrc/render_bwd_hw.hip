@@ -51,6 +51,9 @@ struct BwdHwArgs {
   uint32_t* prof;      // 8 counters (TIMING builds) or null
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
+  int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
+  float feat_bg;
+  const float* out_depth;  // the forward's depth map (read only for the normalised-depth switch with a depth cotangent)
 };
 
 // LDS that only ONE wave produces and consumes: the LDS queue of a wave is in order, so a later ds_read sees an earlier
@@ -150,6 +153,21 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       if (a.d_img) { v[F] = a.d_img[pix]; v[F + 1] = a.d_img[hw + pix]; v[F + 2] = a.d_img[2 * hw + pix]; }
       if (a.d_depth) v[F + 3] = a.d_depth[pix];
     }
+    // Lineage switches: an output of the form X + T_final * b contributes b * cotangent to the pixel's "background" sum.
+    float bextra = 0.f;
+    if (a.lineage & TRASE_VARIANT_FEATS_BG) {
+      float sf = 0.f;
+#pragma unroll
+      for (int c = 0; c < F; ++c) sf += v[c];
+      bextra = a.feat_bg * sf;
+    }
+    if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && a.d_depth && inside) {
+      // depth_out = D / A, A = 1 - T_final:  dL/dD = g / A,  d depth_out / d T_final = D / A^2 = depth_out / A
+      const float A = 1.0f - Tf, gd = v[F + 3];
+      const float ga = A > 1e-10f ? gd / A : 0.0f;
+      v[F + 3] = ga;
+      bextra = fmaf(ga, a.out_depth[pix], bextra);
+    }
     __bf16* rh = L.hi + lane * HW_LD;
     __bf16* rl = L.lo + lane * HW_LD;
 #pragma unroll
@@ -160,7 +178,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       *reinterpret_cast<bf16x8*>(rh + 8 * c8) = hi;
       *reinterpret_cast<bf16x8*>(rl + 8 * c8) = lo;
     }
-    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2];
+    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2] + bextra;
     L.pix[lane] = make_float4(Tf, Tf * bdot, __uint_as_float(last), 0.f);
     if (lane == 0) *reinterpret_cast<uint4*>(L.pad) = make_uint4(0u, 0u, 0u, 0u);
   }
@@ -391,8 +409,13 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
 
 int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan, size_t flag_bytes) {
+                         void* chan, size_t flag_bytes, const float* out_depth) {
   BwdHwArgs a;
+  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg; a.out_depth = out_depth;
+  if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && gr.dL_ddepth && !out_depth) {
+    set_error("render_bwd: the normalised-depth switch with a depth cotangent needs the forward's depth map (outputs.depth)");
+    return TRASE_ERR_INVALID;
+  }
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
   a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot;

@@ -62,6 +62,8 @@ struct FwdMfArgs {
   float* out_img; float* out_feat; float* out_depth; float* final_T; uint32_t* n_contrib;
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
+  int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
+  float feat_bg;
 };
 
 // LDS handed between the two waves of the workgroup: LDS-only barrier (no vmcnt drain: stores / loads stay in flight)
@@ -273,6 +275,10 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
       const size_t pix = (size_t)(y0 + pi) * a.W + x0 + pj;
       a.final_T[pix] = Tc;
       a.n_contrib[pix] = lastc;
+      if (a.lineage & TRASE_VARIANT_DEPTH_NORM) {        // lineage switch: depth / accumulated alpha
+        const float A = 1.0f - Tc;
+        dacc = A > 1e-10f ? dacc / A : 0.0f;
+      }
       a.out_depth[pix] = dacc;
     }
     L.tfin[wv][m] = Tc;                                  // final_T in pixel order: the accumulator layout reads it back
@@ -289,8 +295,10 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
     float* pf = a.out_feat + (size_t)m * hw + rowo;
     float* pc = nullptr;                                 // channel block 1: r g b (image planes) and depth
     if (m < 3) pc = a.out_img + (size_t)m * hw + rowo;   // (depth: written above from the fp32 accumulation)
-    const float4 vf = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
+    float4 vf = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
     const float4 tq = *reinterpret_cast<const float4*>(&L.tfin[wv][8 * q + 4 * h]);   // final_T of this register quad's pixels
+    if (a.lineage & TRASE_VARIANT_FEATS_BG)              // lineage switch: features over a background value
+      vf = make_float4(fmaf(tq.x, a.feat_bg, vf.x), fmaf(tq.y, a.feat_bg, vf.y), fmaf(tq.z, a.feat_bg, vf.z), fmaf(tq.w, a.feat_bg, vf.w));
     const float4 vc = make_float4(fmaf(tq.x, bgc, D[1][4 * q]), fmaf(tq.y, bgc, D[1][4 * q + 1]),
                                   fmaf(tq.z, bgc, D[1][4 * q + 2]), fmaf(tq.w, bgc, D[1][4 * q + 3]));
     if (full) {
@@ -318,6 +326,7 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
+  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip

@@ -238,5 +238,17 @@ def loss_nnfm_style(feat1: torch.Tensor, feats2: torch.Tensor) -> torch.Tensor:
     if feat1.dim() != 2 or feats2.dim() != 2 or feat1.shape[0] != feats2.shape[0]:
         raise ValueError(f"expected (C, N1) and (C, N2) feature matrices, got {tuple(feat1.shape)} and {tuple(feats2.shape)}")
     if feats2.requires_grad:
-        raise NotImplementedError("loss_nnfm_style: a gradient w.r.t. the style features is not produced")
+        # At the reference call site (train_style_transfer_nnfm.py:202) the style features come out of a VGG whose weights
+        # were never frozen (style_transfer/fx.py only calls .eval()), so they DO require grad -- but no optimizer holds the
+        # VGG weights: that branch of the graph is dead.  Cut it here instead of refusing the call.
+        global _NNFM_WARNED
+        if not _NNFM_WARNED:
+            import warnings
+            warnings.warn("loss_nnfm_style: the style features require grad; no gradient is produced for them "
+                          "(the reference never consumes it) -- detaching")
+            _NNFM_WARNED = True
+        feats2 = feats2.detach()
     return _NNFM.apply(feat1, feats2)
+
+
+_NNFM_WARNED = False

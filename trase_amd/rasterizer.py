@@ -58,6 +58,7 @@ class _Policy:
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
     max_pending = 8
     tile_rows = (0, 0)          # strip of 16x16-tile rows to render; (0, 0) = the whole image
+    feat_bg = 0.0               # background value of the feature channels (lineage switch, variant bit 0x10000)
 
 
 def set_sync(flag: bool, capacity: int = 0):
@@ -69,6 +70,29 @@ def set_sync(flag: bool, capacity: int = 0):
 
 def set_variant(v: int):
     _Policy.variant = int(v)
+
+
+VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x20000
+
+
+def set_lineage(feats_bg: Optional[float] = None, depth_normalised: bool = False, depth_grad: bool = False):
+    """Lineage switches (the CUDA fork's source is absent, these are the three places it is most
+    likely to differ from the public lineage; oracle/raster_oracle.py ``OracleOptions`` has the same switches):
+
+    feats_bg         None (default, gaussian-grouping: no background term) or a float b: feats[c] += T_final * b
+    depth_normalised False (default, Deformable-3DGS: blended depth as is) or True: depth = sum(w z) / (1 - T_final)
+    depth_grad       False (default, lineage: the depth output carries no gradient) or True: dL/ddepth is honoured
+
+    They flip both directions of the HIP path; forward and backward of one call always use the same setting."""
+    v = _Policy.variant & ~(VARIANT_DEPTH_GRAD | VARIANT_FEATS_BG | VARIANT_DEPTH_NORM)
+    if feats_bg is not None:
+        v |= VARIANT_FEATS_BG
+    if depth_normalised:
+        v |= VARIANT_DEPTH_NORM
+    if depth_grad:
+        v |= VARIANT_DEPTH_GRAD
+    _Policy.variant = v
+    _Policy.feat_bg = 0.0 if feats_bg is None else float(feats_bg)
 
 
 def set_tile_rows(begin: int = 0, end: int = 0):
@@ -223,6 +247,7 @@ def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _li
     s.device = device.index if device.index is not None else torch.cuda.current_device()
     s.variant = _Policy.variant
     s.tile_row_begin, s.tile_row_end = _Policy.tile_rows
+    s.feat_bg = _Policy.feat_bg
     for name in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _prep(getattr(rs, name), name, device)
         if t is None:
@@ -299,26 +324,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         _after_render(geom, capacity)
 
         ctx.raster_settings = raster_settings
-        ctx.variant, ctx.tile_rows = s.variant, (s.tile_row_begin, s.tile_row_end)
+        ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
         ctx.capacity = capacity
         ctx.dims = (P, M, F, H, W)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
+        # the normalised-depth switch with a depth gradient needs the forward's depth map again
+        keep_depth = (s.variant & (VARIANT_DEPTH_NORM | VARIANT_DEPTH_GRAD)) == (VARIANT_DEPTH_NORM | VARIANT_DEPTH_GRAD)
         ctx.save_for_backward(means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
-                              cov3Ds_precomp, radii, geom, binb, img, pre)
+                              cov3Ds_precomp, radii, geom, binb, img, pre, depth if keep_depth else None)
         return image, radii, feats, depth
 
     @staticmethod
     def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
         lib = _lib.load()
         (means3D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-         radii, geom, binb, img, pre) = ctx.saved_tensors
+         radii, geom, binb, img, pre, depth_out) = ctx.saved_tensors
         P, M, F, H, W = ctx.dims
         device = means3D.device
         keep: list = []
         s = _fill_settings(ctx.raster_settings, device, keep)
         s.variant = ctx.variant                # the forward's variant (a global change in between must not split the pair)
         s.tile_row_begin, s.tile_row_end = ctx.tile_rows
+        s.feat_bg = ctx.feat_bg
         inp = _lib.RastInputs()
         inp.P, inp.M, inp.F = P, M, F
         inp.means3D = _lib.ptr(means3D)
@@ -327,6 +355,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         inp.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
         out = _lib.RastOutputs()
         out.radii = _lib.ptr(radii)
+        out.depth = _lib.ptr(depth_out)
 
         sizes = _lib.RastSizes()
         _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")

@@ -147,7 +147,7 @@ class _RenderRaw(torch.autograd.Function):
                    "trase_rast_render_raw")
         _after_render(geom, capacity)
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
-        ctx.variant, ctx.tile_rows = s.variant, (s.tile_row_begin, s.tile_row_end)
+        ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
         ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
         ctx.norm_features = bool(norm_features)
         ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
@@ -157,14 +157,15 @@ class _RenderRaw(torch.autograd.Function):
         ctx.save_for_backward(xyz, d_xyz if d_xyz is not None else z, f_dc, f_rest, opacity, scaling,
                               d_scaling if d_scaling is not None else z, rotation,
                               d_rotation if d_rotation is not None else z, gfeat if gfeat is not None else z,
-                              radii, geom, binb, img, pre, featn)
+                              radii, geom, binb, img, pre, featn,
+                              depth if (s.variant & 0x20100) == 0x20100 else None)   # normalised depth + depth gradient
         return image, radii, feats, depth
 
     @staticmethod
     def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
         lib = _lib.load()
         (xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat,
-         radii, geom, binb, img, pre, featn) = ctx.saved_tensors
+         radii, geom, binb, img, pre, featn, depth_out) = ctx.saved_tensors
         has_dxyz, has_dscale, has_drot, has_feat = ctx.opt
         P, F, H, W = ctx.dims
         device = xyz.device
@@ -172,6 +173,7 @@ class _RenderRaw(torch.autograd.Function):
         s = _fill_settings(ctx.raster_settings, device, keep)
         s.variant = ctx.variant                # the forward's variant and strip, not whatever the globals say now
         s.tile_row_begin, s.tile_row_end = ctx.tile_rows
+        s.feat_bg = ctx.feat_bg
         raw = _lib.RastRawInputs()
         raw.P, raw.F, raw.norm_features = P, F, int(ctx.norm_features)
         raw.xyz, raw.d_xyz = _lib.ptr(xyz), (_lib.ptr(d_xyz) if has_dxyz else None)
@@ -182,6 +184,7 @@ class _RenderRaw(torch.autograd.Function):
         raw.featn = _lib.ptr(featn)
         out = _lib.RastOutputs()
         out.radii = _lib.ptr(radii)
+        out.depth = _lib.ptr(depth_out)
         sizes = _lib.RastSizes()
         _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")
         tmp = _bytes(sizes.bwd_tmp_bytes, device)
