@@ -56,9 +56,10 @@ def test_switch_depth_gradient(feat):
 @pytest.mark.parametrize("feat", [32, 16])
 def test_switch_feature_background(feat):
     g, o = _run(feat, dict(feats_bg=0.35), ro.OracleOptions(feats_bg=True, feat_bg_value=0.35), with_depth_cot=False)
-    # an uncovered corner shows the background value in every feature channel
-    assert abs(float(g[2][:, 0, 0].max()) - float(o.feats[:, 0, 0].max())) < 1e-4
-    assert float(g[2].min()) > -1.0 and float(o.final_T.max()) > 0.5
+    # the switch did something: the feature map differs from the default lineage's by T_final * 0.35
+    base, _ = _run(feat, {}, ro.OracleOptions(), with_depth_cot=False)
+    want = 0.35 * o.final_T.float()
+    assert float(((g[2] - base[2]).cpu() - want[None]).abs().max()) < 1e-5 and float(want.max()) > 1e-3
 
 
 @pytest.mark.parametrize("feat,depth_grad", [(32, True), (32, False), (0, True)])
@@ -67,8 +68,8 @@ def test_switch_normalised_depth(feat, depth_grad):
                 with_depth_cot=depth_grad)
     covered = o.final_T < 0.5
     assert bool(covered.any())
-    # normalised depth of a well-covered pixel lies inside the depth range of the scene
-    assert float(g[3][0][covered.cuda()].min()) > 2.0
+    # normalised depth of a well-covered pixel lies inside the depth range of the scene (camera at radius 4, cube +-1.3)
+    assert float(g[3][0][covered.cuda()].min()) > 1.5
 
 
 def test_all_three_switches_together():

@@ -32,11 +32,12 @@ constexpr int HW_CH = 48;     // channel-table row: [hi 48 | lo 48] bf16 (render
 constexpr int HW_LD = 40;     // LDS row pitch in bf16 (80 B)
 constexpr int HW_G = 32;      // list entries per chunk
 
-struct HwWaveLds {            // contiguous on purpose: the over-read of GEMM 1's last K-step stays inside it
-  __bf16 hi[WAVE * HW_LD];
+struct HwWaveLds {
+  float4 pix[WAVE];           // T_end, U_end, last (bits), -   (first: the carry writes are ds_write2_b64, whose two 8-bit
+                              // offsets only reach 2 KB from the base register)
+  __bf16 hi[WAVE * HW_LD];    // hi | lo | pad contiguous on purpose: the over-read of GEMM 1's last K-step stays inside them
   __bf16 lo[WAVE * HW_LD];
   __bf16 pad[8];              // zeros: what the over-read of the last row of `lo` finds (the low half of a float is not a finite bf16)
-  float4 pix[WAVE];           // T_end, U_end, last (bits), -
 };
 
 struct BwdHwArgs {
@@ -110,6 +111,21 @@ __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ co
 //   44 (pixel, Gaussian) lane slots of executed steps that hold a real list entry
 //   45 ... of those, slots that pass the two exponent gates (power <= 0, alpha >= 1/255)
 //   46 ... of those, slots that are blended (also in front of the pixel's last contributor)
+// The same fragment through the transposing LDS read of gfx950 (ds_read_b64_tr_b16): within a 16-lane group, lane
+// i = 4 jj + cc hands in the address of four consecutive channels (chunk cc) of pixel row jj, and lane c receives element
+// c % 4 of the chunks cc = c / 4 of the rows jj = 0..3 -- i.e. channel c of four pixels: one instruction instead of four
+// 16-bit reads and two packs.  `p` is this lane's chunk address for the K-step's first four pixel rows; the second four
+// are eight rows further on.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 gather_column_tr(const __bf16* __restrict__ p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * HW_LD));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 template <bool FEAT_ONLY, bool TIMING, bool COUNT = false>
 #ifndef HW_OCC
 #define HW_OCC 4
@@ -202,6 +218,11 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   // channel column of this lane for the cot^T gathers: block nb covers channels nb*32 + g; columns >= 40 do not exist
   // (they are zero): read column 39, which is zero, instead
   const int col0 = g, col1 = min(32 + g, HW_LD - 1);
+  // transposing-read addressing of the same fragments: pixel row (lane & 15) >> 2 of the K-step's four, channel chunk
+  // 16 * ((lane >> 4) & 1) + 4 * (lane & 3) of the block; block 1 only has the chunks 32..35 and 36..39 (zeros)
+  const int trrow = ((lane & 15) >> 2) * HW_LD;
+  const int tr0 = trrow + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int tr1 = trrow + min(32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3), HW_LD - 4);
   tick(0);
   // The list entries of a chunk are requested one chunk ahead (two registers): one level less in the dependent chain
   // entry -> geometry / channel rows at a chunk start.
@@ -234,11 +255,13 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;
     const __bf16* const crow = a.chan + (size_t)id * (2 * HW_CH) + 8 * h;   // this lane's B fragments of GEMM 1
     tick(1);
+    // Accumulators are never zero-filled: the first product of each takes a literal zero C operand (an inline constant
+    // of the MFMA encoding), which saves 64 v_mov per chunk.
+    const f32x16 ZERO16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 D[2];                                         // D[channel block]: rows = channels, columns = Gaussians
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) D[nb][r] = 0.f;
+    if constexpr (FEAT_ONLY) D[1] = ZERO16;              // never accumulated there; its four sums are written as zeros
+    // moment sums with the LOCAL column index jl = 0..3 of this lane half (global column j = 4h + jl): the row sums are
+    // then plain constants-weighted sums; the shift to the global index happens once per chunk
     float S0 = 0.f, Sj = 0.f, Si = 0.f, Sjj = 0.f, Sij = 0.f, Sii = 0.f;
     unsigned wh[4], wl[4];                               // 8 weights of the current K-step, packed bf16 pairs
     // ---- GEMM 1: S[mb][p][g] for both 32-pixel halves, the channel fragments loaded once -----------------------
@@ -247,10 +270,6 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     f32x16 Sm[2];
     if constexpr (!FEAT_ONLY) {
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Sm[mb][r] = 0.f;
-#pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(crow + ks * 16);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(crow + ks * 16 + HW_CH);
@@ -258,7 +277,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
         for (int mb = 0; mb < 2; ++mb) {
           const bf16x8 ph = *reinterpret_cast<const bf16x8*>(ahi + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
           const bf16x8 pl = *reinterpret_cast<const bf16x8*>(alo + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
-          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, Sm[mb], 0, 0, 0);
+          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, ks == 0 ? ZERO16 : Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, Sm[mb], 0, 0, 0);
         }
@@ -274,12 +293,12 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
         const float fi = (float)i, fii = (float)(i * i);
         const float base = poly_row_base(k, fi, fii);
         const float slope = poly_row_slope(k, fi);
-        float R0 = 0.f, R1 = 0.f, R2 = 0.f;              // row sums of q, q*j, q*j^2 over this lane's four columns
+        float R0 = 0.f, R1 = 0.f, R2 = 0.f;              // row sums of q, q*jl, q*jl^2 over this lane's four columns (jl = 0..3)
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {                   // two pixels per half and step: their scans are interleaved
           // last-contributor indices of the four pixels of this step (lane = pixel register, wave-uniform reads)
           const int p0 = i * SUB + r;                      // half 0: p0, p0+1; half 1: p0+4, p0+5
-          float wa = 0.f, wb = 0.f;
+          unsigned hb = 0, lb = 0;                         // the step's two weights as packed bf16 pairs: w = hi + lo
           if constexpr (COUNT) { if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) cnt[2] += 1; else cnt[3] += 1; }
           if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) {
             const int pl = p0 + 4 * h;                     // this lane's first pixel of the step
@@ -302,7 +321,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             float Pa = roma, Pb = romb;
             half_scan_mul2(Pa, Pb);
             const float Ta = pa.x * Pa, Tb = pb.x * Pb;   // transmittance in front of this Gaussian
-            wa = ala * Ta; wb = alb * Tb;
+            const float wa = ala * Ta, wb = alb * Tb;
             if constexpr (FEAT_ONLY) {
               if (g == HW_G - 1) { L.pix[pl].x = Ta; L.pix[pl + 1].x = Tb; }
             } else {
@@ -317,20 +336,23 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
                 L.pix[pl + 1].x = Tb; L.pix[pl + 1].y = pb.y + ib;
               }
               const float qa = ra * dLa, qb = rb * dLb;    // == opacity * G * dL/dalpha (straight-through clamp)
-              const float qja = qa * jv[r], qjb = qb * jv[r + 1];
-              R0 += qa + qb;
-              R1 += qja + qjb;
-              R2 = fmaf(qjb, jv[r + 1], fmaf(qja, jv[r], R2));
+              if (r == 0) {                                // local columns jl = 0, 1: weights (1, 0, 0) and (1, 1, 1)
+                R0 = qa + qb; R1 = qb; R2 = qb;
+              } else {                                     // jl = 2, 3: weights (1, 2, 4) and (1, 3, 9)
+                R0 += qa + qb;
+                R2 = fmaf(9.0f, qb, fmaf(4.0f, qa, R2));
+                R1 = fmaf(3.0f, qb, fmaf(2.0f, qa, R1));
+              }
+            }
+            {                                              // split the two weights, packed
+#pragma clang fp contract(off)                             // the residual of the ROUNDED weight in every instantiation (not fma(alpha, T, -hi))
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb) : "v"(wa), "v"(wb));
+              const float ra2 = wa - __uint_as_float(hb << 16), rb2 = wb - __uint_as_float(hb & 0xffff0000u);
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lb) : "v"(ra2), "v"(rb2));
             }
           }
-          {                                                // split the two weights, packed: w = hi + lo
-            unsigned hb, lb;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb) : "v"(wa), "v"(wb));
-            const float ra2 = wa - __uint_as_float(hb << 16), rb2 = wb - __uint_as_float(hb & 0xffff0000u);
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lb) : "v"(ra2), "v"(rb2));
-            wh[2 * (q & 1) + (r >> 1)] = hb;               // K index = 4 * (pixel row parity) + r
-            wl[2 * (q & 1) + (r >> 1)] = lb;
-          }
+          wh[2 * (q & 1) + (r >> 1)] = hb;                 // K index = 4 * (pixel row parity) + r
+          wl[2 * (q & 1) + (r >> 1)] = lb;
         }
         if constexpr (!FEAT_ONLY) {
           S0 += R0; Sj += R1; Sjj += R2;
@@ -345,9 +367,14 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           constexpr int NBLK = FEAT_ONLY ? 1 : 2;          // channel block 1 = r g b depth
 #pragma unroll
           for (int nb = 0; nb < NBLK; ++nb) {
+#ifdef TRASE_BWD_NO_TR
             const int col = nb == 0 ? col0 : col1;
             const bf16x8 Ah = gather_column_hw(ahi + rowoff + col), Al = gather_column_hw(alo + rowoff + col);
-            D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, D[nb], 0, 0, 0);
+#else
+            const int tro = nb == 0 ? tr0 : tr1;
+            const bf16x8 Ah = gather_column_tr(ahi + rowoff + tro), Al = gather_column_tr(alo + rowoff + tro);
+#endif
+            D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, i == 1 ? ZERO16 : D[nb], 0, 0, 0);
             D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, D[nb], 0, 0, 0);
             D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, D[nb], 0, 0, 0);
           }
@@ -369,6 +396,12 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
         *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
     }
     if constexpr (!FEAT_ONLY) {
+      // local -> global column index (j = 4h + jl):  sum q j = Sj + 4h S0,  sum q j^2 = Sjj + 8h Sj + 16 h^2 S0,
+      // sum q i j = Sij + 4h Si   (h = 0: unchanged)
+      const float h4 = (float)(4 * h);
+      Sjj = fmaf(h4, fmaf(h4, S0, 2.0f * Sj), Sjj);
+      Sj = fmaf(h4, S0, Sj);
+      Sij = fmaf(h4, Si, Sij);
       S0 = both(S0); Sj = both(Sj); Si = both(Si); Sjj = both(Sjj); Sij = both(Sij); Sii = both(Sii);
     }
     if (slot != 0xffffffffu && h == 0) {
