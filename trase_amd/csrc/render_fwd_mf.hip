@@ -18,8 +18,11 @@
 //     load chain slot -> id -> geometry / feature rows at every chunk start (PMC: the one-wave version spent 52 % of its
 //     wave cycles parked at s_waitcnt with 2.4 waves per SIMD).  The staging work is shared, not duplicated.
 //   * chan[g][c]: per chunk the 64 feature rows are fetched with wave-wide 16-byte loads (eight lanes per row: 8 cache
-//     lines per instruction instead of one per lane), split to bf16 hi / lo and written TRANSPOSED into a
-//     [channel][entry] tile in LDS, so that a B fragment (eight consecutive entries of one channel) is one ds_read_b128.
+//     lines per instruction instead of one per lane), split to bf16 hi / lo and stored AS ROWS ([entry][channel], one
+//     8-byte store per lane and half); a B fragment (eight consecutive entries of one channel) is gathered by two
+//     transposing LDS reads (ds_read_b64_tr_b16: within a 16-lane group lane 4 jj + cc hands in the address of channel
+//     chunk cc of entry jj and lane c receives channel c of four entries).  Round 2 wrote the tile transposed with 32
+//     two-byte stores per lane and chunk: as many LDS bank-conflict cycles as LDS instruction cycles (PMC).
 //     r, g, b, depth are channels 32..35 of the same tile.
 //   * the DEPTH map is the one output whose magnitude is not O(1) (view depth up to zfar = 100, scene/cameras.py:70): the
 //     bf16-split product carries ~1e-5 RELATIVE, i.e. 5e-4 abs at z = 50.  Depth is therefore accumulated by each lane in
@@ -42,12 +45,12 @@ constexpr int FM_WAVES = 2;       // waves per sub-tile (= workgroup)
 #define FM_G_ 64
 #endif
 constexpr int FM_G = FM_G_;       // list entries per chunk
-constexpr int FM_LD = FM_G + 8;   // tile row pitch in bf16 (entries + 8 pad: conflict-free fragment reads)
-constexpr int FM_CH = 40;         // tile rows: 32 features, r g b depth, 4 zero rows
+constexpr int FM_P = 48;          // tile row pitch in bf16: 32 features, r g b depth, 12 zeros (96 B: the transposing reads
+                                  // of a 16-lane group -- 4 rows x 4 eight-byte chunks -- then fall on 16 different bank pairs)
 
 struct FmLds {
-  __bf16 hi[FM_CH * FM_LD];
-  __bf16 lo[FM_CH * FM_LD];
+  __bf16 hi[FM_G * FM_P];         // [entry][channel]: staged with 8-byte row-contiguous stores, read back TRANSPOSED
+  __bf16 lo[FM_G * FM_P];
   float4 k0[FM_G];                // k0, kj, ki, kjj
   float4 k1[FM_G];                // kii, kij, thr, -
   float zs[FM_G];                 // view depth of the chunk's entries: the depth map is accumulated in fp32 (see below)
@@ -78,6 +81,17 @@ __device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigne
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
 }
 
+// B fragment (eight consecutive entries of this lane's channel) from the [entry][channel] tile: two transposing reads
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* __restrict__ p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * FM_P));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 __global__ __launch_bounds__(FM_WAVES* WAVE) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void render_fwd_mf_kernel(FwdMfArgs a) {
   constexpr int F = 32;
@@ -95,10 +109,10 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   const int pi = 4 * wv + (m >> 3), pj = m & 7;
   const float fj = (float)pj, fi = (float)pi, fii = (float)(pi * pi);
   const bool inside = (tx * SUB + pj) < a.W && (ty * SUB + pi) < a.H;
-  // zero the tile once: rows 36..39 and the pad columns are never written again
+  // zero the tile once: channels 36..47 are never written again
   {
     uint4* z = reinterpret_cast<uint4*>(L.hi);
-    for (int o = threadIdx.x; o < (int)(2 * FM_CH * FM_LD * sizeof(__bf16) / 16); o += FM_WAVES * WAVE) z[o] = make_uint4(0u, 0u, 0u, 0u);
+    for (int o = threadIdx.x; o < (int)(2 * FM_G * FM_P * sizeof(__bf16) / 16); o += FM_WAVES * WAVE) z[o] = make_uint4(0u, 0u, 0u, 0u);
   }
   f32x16 D[2];                                           // D[channel block]: rows = pixels, columns = channels
 #pragma unroll
@@ -110,9 +124,9 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   float Tin = inside ? 1.0f : 0.0f, Tc = 1.0f;
   uint32_t lastc = 0;
   float dacc = 0.f;                                      // fp32 depth of this lane's half of every K-step
-  // channel column of this lane in the B fragments: block 0 = feature m; block 1 = channel 32 + m, rows >= 40 do not
-  // exist (zero): read the zero row 39 instead
-  const int brow0 = m * FM_LD, brow1 = min(32 + m, FM_CH - 1) * FM_LD;
+  // this lane's chunk address in the transposing B-fragment reads: entry (lane & 15) >> 2 of the four, channel chunk
+  // 16 * ((lane >> 4) & 1) + 4 * (lane & 3) of the block (block 1 = channels 32..47: r g b depth and zeros)
+  const int btr = (8 * h + ((lane & 15) >> 2)) * FM_P + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   if (lane == 0) L.live[wv] = 1;
   wg_lds_barrier();
 
@@ -156,22 +170,18 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
       unsigned h01, l01, h23, l23;
       split_pk(cd.x, cd.y, h01, l01);
       split_pk(cd.z, cd.w, h23, l23);
-      unsigned short* th = reinterpret_cast<unsigned short*>(L.hi) + 32 * FM_LD + lane;
-      unsigned short* tl = reinterpret_cast<unsigned short*>(L.lo) + 32 * FM_LD + lane;
-      th[0] = (unsigned short)h01; th[FM_LD] = (unsigned short)(h01 >> 16); th[2 * FM_LD] = (unsigned short)h23; th[3 * FM_LD] = (unsigned short)(h23 >> 16);
-      tl[0] = (unsigned short)l01; tl[FM_LD] = (unsigned short)(l01 >> 16); tl[2 * FM_LD] = (unsigned short)l23; tl[3 * FM_LD] = (unsigned short)(l23 >> 16);
+      *reinterpret_cast<uint2*>(L.hi + lane * FM_P + 32) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(L.lo + lane * FM_P + 32) = make_uint2(l01, l23);
       }
     }
 #pragma unroll
-    for (int r = 0; r < FM_G / 16; ++r) {                // transposed: tile[channel 4 (lane & 7) + e][entry 16r + 8wv + (lane >> 3)]
+    for (int r = 0; r < FM_G / 16; ++r) {                // tile[entry 16r + 8wv + (lane >> 3)][channels 4 (lane & 7) .. + 3]
       unsigned h01, l01, h23, l23;
       split_pk(fr[r].x, fr[r].y, h01, l01);
       split_pk(fr[r].z, fr[r].w, h23, l23);
-      const int o = (4 * (lane & 7)) * FM_LD + 16 * r + 8 * wv + (lane >> 3);
-      unsigned short* th = reinterpret_cast<unsigned short*>(L.hi) + o;
-      unsigned short* tl = reinterpret_cast<unsigned short*>(L.lo) + o;
-      th[0] = (unsigned short)h01; th[FM_LD] = (unsigned short)(h01 >> 16); th[2 * FM_LD] = (unsigned short)h23; th[3 * FM_LD] = (unsigned short)(h23 >> 16);
-      tl[0] = (unsigned short)l01; tl[FM_LD] = (unsigned short)(l01 >> 16); tl[2 * FM_LD] = (unsigned short)l23; tl[3 * FM_LD] = (unsigned short)(l23 >> 16);
+      const int o = (16 * r + 8 * wv + (lane >> 3)) * FM_P + 4 * (lane & 7);
+      *reinterpret_cast<uint2*>(L.hi + o) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(L.lo + o) = make_uint2(l01, l23);
     }
     wg_lds_barrier();
     // ---- K-steps of 16 entries ---------------------------------------------------------------------------------
@@ -247,9 +257,8 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
         const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Al = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-          const int o = (nb == 0 ? brow0 : brow1) + e0;
-          const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(L.hi + o);
-          const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(L.lo + o);
+          const int o = btr + 16 * t * FM_P + 32 * nb;
+          const bf16x8 Bh = frag_tr(L.hi + o), Bl = frag_tr(L.lo + o);
           D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, D[nb], 0, 0, 0);
           D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, D[nb], 0, 0, 0);
           D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, D[nb], 0, 0, 0);
