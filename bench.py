@@ -150,7 +150,17 @@ def main():
     ap.add_argument("--cpu-oracle-budget-s", type=float, default=1.0, help="forward wall-time budget of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core (os.cpu_count())")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
+    ap.add_argument("--shard", choices=["views", "tiles"], default="views",
+                    help="'views' (default, the headline): every rank renders a different view.  'tiles' (BASELINE config 5): ONE "
+                         "view per step for the whole job, every rank renders a load-balanced strip of 16x16-tile rows, the RGB "
+                         "strips are all-gathered (full-frame style loss) and the strips' partial gradients all-reduced; strong "
+                         "scaling; defaults to the S5 size (2.5 M Gaussians, 1280x960) unless sizes are given")
+    ap.add_argument("--strip-table", type=str, default="",
+                    help="ONE GPU: time every rank's strip (fwd+bwd, load-balanced partition) for world = 1, 2, 4, 8 and write the "
+                         "predicted tile-sharding speed-up (communication excluded) to this JSON file; no bench line is printed")
     args = ap.parse_args()
+    if (args.shard == "tiles" or args.strip_table) and "--gaussians" not in " ".join(sys.argv) and "--width" not in " ".join(sys.argv):
+        args.gaussians, args.width, args.height = 2_500_000, 1280, 960          # S5: Google Immersive size
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +222,8 @@ def main():
             set_grad_sink(bucket.sink())
 
     n_views = 16
-    cams = [orbit_camera(W, H, angle=2 * math.pi * (k + rank * 0.37) / n_views, fid=k / n_views) for k in range(n_views)]
+    cams = [orbit_camera(W, H, angle=2 * math.pi * (k + (0 if args.shard == "tiles" else rank * 0.37)) / n_views, fid=k / n_views)
+            for k in range(n_views)]
     settings = [settings_for(c, device) for c in cams]
     cams_dev = [c.to(device) for c in cams]
     bg = torch.zeros(3, device=device)
@@ -220,7 +231,12 @@ def main():
     g_img = torch.randn(3, H, W, generator=g).to(device) / P
     g_feat = torch.randn(F, H, W, generator=g).to(device) / P
 
+    tiles_mode = args.shard == "tiles"
+    strip = {"part": None}          # tile-row partition of the current job (tiles mode)
+
     def step(i):
+        if tiles_mode:
+            return step_tiles(i)
         if bucket is not None and not use_sink:
             bucket.zero()                 # autograd accumulates into the bucket views
         else:
@@ -245,6 +261,26 @@ def main():
             bucket.allreduce()
         return radii
 
+    def step_tiles(i, rows=None):
+        """One rank's share of ONE view: its strip of tile rows (forward), all-gather of the RGB strips (the full frame a
+        style loss needs), backward of the strip, all-reduce of the partial gradients."""
+        from trase_amd import dp
+        for p_ in params:
+            p_.grad = None
+        b, e = rows if rows is not None else strip["part"][rank]
+        with R.tile_rows(b, e) if (b, e) != (0, 0) else _nullctx():
+            out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
+            img, radii, feats = out["render"], out["radii"], out["render_gaussian_features"]
+            if world > 1:
+                img = dp.allgather_strips(img, strip["part"], H)
+            torch.autograd.backward([img, feats], [g_img, g_feat])
+        if bucket is not None:
+            bucket.allreduce()
+        return radii
+
+    import contextlib
+    _nullctx = contextlib.nullcontext
+
     def log(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -252,6 +288,54 @@ def main():
     # ---- sizing pass (synchronising policy): measure the pair count of every view
     log(f"scene ready: N={N} {W}x{H} F={F}")
     R.set_sync(True)
+    if tiles_mode or args.strip_table:
+        from trase_amd import dp
+        tiles_mode = True
+        step_tiles(0, rows=(0, 0))                       # the whole view once: per-tile-row pair loads
+        loads = R.last_tile_row_loads()
+        full_pairs = R.last_status()[2]
+        strip["part"] = dp.tile_row_partition(H, world, loads=loads)
+        log(f"tile rows {len(loads)}, pairs {full_pairs}; load-balanced strips {strip['part']}")
+    if args.strip_table:
+        # ONE GPU: every rank's strip of world = 1, 2, 4, 8 timed in turn (communication excluded)
+        table = {"workload": f"{N} Gaussians, {W}x{H}, F={F}, one view sharded by load-balanced tile-row strips", "steps": args.steps,
+                 "tile_row_loads": [int(x) for x in loads.tolist()], "world": {}}
+        for wsize in (1, 2, 4, 8):
+            part = dp.tile_row_partition(H, wsize, loads=loads)
+            part_eq = dp.tile_row_partition(H, wsize)
+            rec = {"strips": part, "ms": [], "pairs": [], "equal_rows_strips": part_eq, "equal_rows_ms": []}
+            for label, pp, dst in (("balanced", part, rec["ms"]), ("equal", part_eq, rec["equal_rows_ms"])):
+                if label == "equal" and (wsize == 1 or pp == part):
+                    rec["equal_rows_ms"] = list(rec["ms"])
+                    continue
+                for rows in pp:
+                    R.set_sync(True)
+                    caps = []
+                    for i in range(min(4, n_views)):
+                        step_tiles(i, rows=rows)
+                        caps.append(R.last_status()[2])
+                    R.set_sync(False, capacity=int(max(caps) * 1.3) + 1024)
+                    for i in range(2):
+                        step_tiles(i, rows=rows)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        step_tiles(i, rows=rows)
+                    torch.cuda.synchronize()
+                    dst.append(round((time.perf_counter() - t0) / args.steps * 1e3, 4))
+                    if label == "balanced":
+                        rec["pairs"].append(int(sum(caps) / len(caps)))
+            rec["max_ms"], rec["equal_rows_max_ms"] = max(rec["ms"]), max(rec["equal_rows_ms"])
+            table["world"][str(wsize)] = rec
+            log(f"world {wsize}: strip ms {rec['ms']} (equal rows: {rec['equal_rows_ms']})")
+        base = table["world"]["1"]["max_ms"]
+        table["predicted_speedup_excl_comms"] = {k: round(base / v["max_ms"], 3) for k, v in table["world"].items()}
+        table["predicted_speedup_equal_rows"] = {k: round(base / v["equal_rows_max_ms"], 3) for k, v in table["world"].items()}
+        table["note"] = ("single-GPU prediction: step time of a W-rank job = slowest strip; the all-gather of the RGB strips and the "
+                         "all-reduce of the gradient bucket are NOT included (unmeasured on multi-GPU hardware)")
+        json.dump(table, open(args.strip_table, "w"), indent=1)
+        print(json.dumps({"strip_table": args.strip_table, "predicted_speedup_excl_comms": table["predicted_speedup_excl_comms"]}), flush=True)
+        return
     r_list, reff_list = [], []
     for i in range(n_views):
         step(i)
@@ -294,7 +378,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    views_per_s = world * args.steps / elapsed
+    views_per_s = (1 if tiles_mode else world) * args.steps / elapsed     # tiles mode: the whole job renders ONE view per step
     log(f"timed: {ms_per_step:.3f} ms/step, {views_per_s:.1f} views/s")
 
     breakdown = None
@@ -338,13 +422,15 @@ def main():
         valu_frac = None if valu_insts is None else valu_insts * 4.0 / (N_SIMD * dom_ms * 1e-3 * CLOCK_HZ)
         out = {
             # BASELINE.json's metric names the S4 configuration; other sizes (parity-test configurations) say so
-            "metric": "views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
-            else f"views/sec (fwd+bwd), {W}x{H}, {N} Gaussians, {F}-d feat",
+            "metric": ("views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
+                       else f"views/sec (fwd+bwd), {W}x{H}, {N} Gaussians, {F}-d feat") + (", one view tile-row sharded over the ranks" if tiles_mode else ""),
             "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'S4 headline' if (N, W, H, F) == (300_000, 1920, 1080, 32) else 'custom'}: {N} Gaussians, {W}x{H}, F={F}, SH deg 3, one view per step per GPU"
-                                   + (", view-DP + RCCL all-reduce of Gaussian grads" if world > 1 else ""),
+                                   + (", view-DP + RCCL all-reduce of Gaussian grads" if (world > 1 and not tiles_mode) else "")
+                                   + (f", ONE view per step sharded by load-balanced tile-row strips {strip['part']}, RGB strips all-gathered, "
+                                      "partial gradients all-reduced" if tiles_mode else ""),
                        "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
                        "subtile_pairs_mean": round(reff_mean),
                        "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant,
@@ -361,7 +447,7 @@ def main():
                          "valu_frac": None if valu_frac is None else round(valu_frac, 4), "valu_insts": valu_insts,
                          "mfma_insts": mfma_insts,
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
-                         "view_frac": round(view_bytes(N, r_used, P, F) * views_per_s / world / 1e9 / HBM_PEAK_GBS, 5)},
+                         "view_frac": round(view_bytes(N, r_used, P, F) * views_per_s / (1 if tiles_mode else world) / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms_per_view": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -7,20 +7,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _scene(n=6000, w=200, h=150, seed=3):
+def _scene(n=6000, w=200, h=150, seed=3, scale_mult=0.9):
     from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
     dev = torch.device("cuda", 0)
-    scene = make_scene(n, feat_dim=32, seed=seed, scale_mult=0.9).to(dev)
+    scene = make_scene(n, feat_dim=32, seed=seed, scale_mult=scale_mult).to(dev)
     cam = orbit_camera(w, h, angle=0.4).to(dev)
     return scene, cam, dev, SynthGaussianModel, SynthPipe
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_strips_reassemble_the_full_render(world):
+@pytest.mark.parametrize("world,size", [(2, "small"), (3, "small"), (4, "S5")], ids=["2", "3", "S5-4-balanced"])
+def test_strips_reassemble_the_full_render(world, size):
+    """size "S5": BASELINE config 5's shape (2.5 M Gaussians, 1280x960), four LOAD-BALANCED strips (unequal heights)."""
     from gaussian_renderer import render
     from trase_amd import rasterizer as R
     from trase_amd.dp import strip_pixel_rows, tile_row_partition
-    scene, cam, dev, Model, Pipe = _scene()
+    scene, cam, dev, Model, Pipe = _scene() if size == "small" else _scene(n=2_500_000, w=1280, h=960, seed=0, scale_mult=0.27)
     H, W = cam.image_height, cam.image_width
     bg = torch.tensor([0.2, 0.3, 0.1], device=dev)
     g = torch.Generator().manual_seed(0)
@@ -36,6 +37,12 @@ def test_strips_reassemble_the_full_render(world):
 
     full, g_full = run((0, 0))
     part = tile_row_partition(H, world)
+    if size == "S5":
+        loads = R.last_tile_row_loads()
+        assert int(loads.sum()) == R.last_status()[2] and len(loads) == (H + 15) // 16
+        part = tile_row_partition(H, world, loads=loads)
+        strip_loads = [int(loads[b:e].sum()) for b, e in part]
+        assert max(strip_loads) <= 1.25 * (sum(strip_loads) / world), f"unbalanced strips {part}: {strip_loads}"
     acc = [torch.zeros_like(t) for t in g_full]
     for r in range(world):
         o, gs = run(part[r])

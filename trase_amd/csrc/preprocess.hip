@@ -140,10 +140,13 @@ struct PreBwdOut {
 template <bool USE_COV, bool USE_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(PreArgs a, const int32_t* __restrict__ radii,
                                                              const uint32_t* __restrict__ clamped,
+                                                             const uint32_t* __restrict__ tiles,
                                                              const float* __restrict__ acc, PreBwdOut o) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.P) return;
-  const bool vis = radii[i] > 0;
+  // a Gaussian without a (sub-tile, Gaussian) pair -- culled, fainter than 1/255 everywhere, or outside the tile-row strip
+  // being rendered -- received no gradient row: its gradients are exact zeros, nothing is evaluated
+  const bool vis = radii[i] > 0 && tiles[i] > 0;
   SplatGradOut go;
   float dsh[48];
 #pragma unroll
@@ -239,7 +242,7 @@ int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const 
   const bool cov = in.cov3D_precomp != nullptr, sh = in.shs != nullptr;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-#define TRASE_PRE_BWD(C, S) hipLaunchKernelGGL((preprocess_bwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.clamped, acc, o)
+#define TRASE_PRE_BWD(C, S) hipLaunchKernelGGL((preprocess_bwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.clamped, g.tiles, acc, o)
     if (cov) { if (sh) TRASE_PRE_BWD(true, true); else TRASE_PRE_BWD(true, false); }
     else { if (sh) TRASE_PRE_BWD(false, true); else TRASE_PRE_BWD(false, false); }
 #undef TRASE_PRE_BWD

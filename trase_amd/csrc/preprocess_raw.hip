@@ -251,11 +251,13 @@ struct RawBwdOut {
 
 __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
                                                                        const uint32_t* __restrict__ clamped,
+                                                                       const uint32_t* __restrict__ tiles,
                                                                        const float* __restrict__ acc, RawBwdOut o) {
   const int gidx = a.p_begin + blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = gidx < a.p_end;                               // no early return: the wave moves the f_rest rows together
   const int i = active ? gidx : a.P - 1;
-  const bool vis = active && radii[i] > 0;
+  // (no pair -- culled, fainter than 1/255 everywhere, or outside the strip being rendered -- means exact zero gradients)
+  const bool vis = active && radii[i] > 0 && tiles[i] > 0;
   __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
   float* const slab = slabs[threadIdx.x >> 6];
   const int row0 = gidx & ~63;
@@ -348,7 +350,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, acc, o);
+    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, g.tiles, acc, o);
   }
   TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
   return TRASE_OK;

@@ -48,6 +48,7 @@ __device__ __forceinline__ void split2(float x, unsigned& hi, unsigned& lo) {
 
 // ---- per view: channel table [P][hi 48 | lo 48] ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_channels_kernel(const float* __restrict__ feats, const float4* __restrict__ rgbd,
+                                                             const uint32_t* __restrict__ tiles,
                                                              int P, __bf16* __restrict__ out, uint4* __restrict__ flags16,
                                                              size_t nflags16) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (Gaussian, group of 8 channels)
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void split_channels_kernel(const float* __rest
   for (size_t i = (size_t)idx; i < nflags16; i += (size_t)gridDim.x * blockDim.x) flags16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (idx >= P * 6) return;
   const int g = idx / 6, grp = idx % 6;
+  if (tiles[g] == 0) return;                                 // no list holds this Gaussian (culled, or outside the strip being rendered)
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -365,7 +367,7 @@ int launch_split_channels(const LaunchCtx& c, const TraseRastInputs& in, const G
                           size_t flag_bytes) {
   {
     ProfScope ps("split_channels", c.stream);
-    hipLaunchKernelGGL(split_channels_kernel, dim3((in.P * 6 + 255) / 256), dim3(256), 0, c.stream, in.sh_objs, g.rgbd, in.P,
+    hipLaunchKernelGGL(split_channels_kernel, dim3((in.P * 6 + 255) / 256), dim3(256), 0, c.stream, in.sh_objs, g.rgbd, g.tiles, in.P,
                        (__bf16*)chan, reinterpret_cast<uint4*>(row_flags), flag_bytes / 16);
   }
   TRASE_POST_LAUNCH("split_channels", c.stream, c.debug);

@@ -197,17 +197,48 @@ def allreduce_densify_stats(xyz_gradient_accum, denom, max_radii2D):
 TILE = 16
 
 
-def tile_row_partition(image_height: int, world: int):
-    """[(begin, end)] tile-row ranges, one per rank: contiguous, disjoint, covering ceil(H / 16) rows, sizes differing by at
-    most one (ranks beyond the number of tile rows get an empty range)."""
+def tile_row_partition(image_height: int, world: int, loads=None):
+    """[(begin, end)] tile-row ranges, one per rank: contiguous, disjoint, covering ceil(H / 16) rows.
+
+    loads=None: sizes differing by at most one row.  loads = per-tile-row cost (``trase_amd.rasterizer.last_tile_row_loads()``
+    of the previous view: binned pairs per row): the contiguous partition that MINIMISES THE LARGEST strip load -- rows of a
+    scene are far from uniform (sky vs the subject), and the slowest strip sets the step time.  A constant per-row term
+    (``+ mean``) keeps empty rows from piling up in one strip.  Ranks beyond the number of rows get an empty range."""
     rows = (int(image_height) + TILE - 1) // TILE
-    base, extra = divmod(rows, world)
-    out, b = [], 0
-    for r in range(world):
-        e = b + base + (1 if r < extra else 0)
-        out.append((b, e))
-        b = e
-    return out
+    if loads is None:
+        base, extra = divmod(rows, world)
+        out, b = [], 0
+        for r in range(world):
+            e = b + base + (1 if r < extra else 0)
+            out.append((b, e))
+            b = e
+        return out
+    w = [float(x) for x in (loads.tolist() if hasattr(loads, "tolist") else loads)]
+    if len(w) != rows:
+        raise ValueError(f"loads has {len(w)} entries, the image has {rows} tile rows")
+    mean = sum(w) / max(rows, 1)
+    w = [x + 0.05 * mean for x in w]                        # pixels / epilogue: a row is never free
+    pre = [0.0]
+    for x in w:
+        pre.append(pre[-1] + x)
+    k = min(world, rows)
+    # best[j][i] = smallest possible largest-strip load when the first i rows form j strips (rows <= ~70: a tiny table)
+    INF = float("inf")
+    best = [[INF] * (rows + 1) for _ in range(k + 1)]
+    cut = [[0] * (rows + 1) for _ in range(k + 1)]
+    best[0][0] = 0.0
+    for j in range(1, k + 1):
+        for i in range(j, rows + 1):
+            for m in range(j - 1, i):
+                c = max(best[j - 1][m], pre[i] - pre[m])
+                if c < best[j][i]:
+                    best[j][i], cut[j][i] = c, m
+    bounds, i = [], rows
+    for j in range(k, 0, -1):
+        bounds.append((cut[j][i], i))
+        i = cut[j][i]
+    out = bounds[::-1]
+    return out + [(rows, rows)] * (world - k)
 
 
 def strip_pixel_rows(part, rank: int, image_height: int, halo_px: int = 0):
@@ -220,10 +251,21 @@ def strip_pixel_rows(part, rank: int, image_height: int, halo_px: int = 0):
 
 def allgather_strips(local: torch.Tensor, part, image_height: int):
     """Every rank contributes the rows of ITS strip of a (C, H, W) map (what ``render`` under ``tile_rows`` returned: zeros
-    elsewhere); every rank gets the full map.  One all-reduce(SUM) of the zero-padded maps -- the strips are disjoint, so the
-    sum IS the concatenation, and unlike all_gather it needs no equal-sized chunks.  Differentiable: the gradient of a
-    rank's strip is the matching slice of the full map's gradient."""
+    elsewhere); every rank gets the full map.  One ``all_gather_into_tensor`` of the strips padded to the tallest one
+    (a zero-padded all-reduce of the whole map moves twice the bytes).  Differentiable: the gradient of a rank's strip is
+    the matching slice of the full map's gradient."""
     return _AllGatherStrips.apply(local, part, image_height)
+
+
+def allreduce_viewspace_grad(viewspace_points: torch.Tensor):
+    """Tile-row sharding only: every rank's ``viewspace_points.grad`` is its strip's PARTIAL sum.  The reference's
+    ``add_densification_stats`` takes a norm of it (scene/gaussian_model.py:637-639), so the partial sums must be added
+    BEFORE the statistics (sum of norms >= norm of sum) -- call this first and do NOT call ``allreduce_densify_stats``
+    on this axis (every rank then holds the same statistics already)."""
+    import torch.distributed as dist
+    if viewspace_points.grad is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(viewspace_points.grad, op=dist.ReduceOp.SUM)
 
 
 class _AllGatherStrips(torch.autograd.Function):
@@ -231,13 +273,24 @@ class _AllGatherStrips(torch.autograd.Function):
     def forward(ctx, local, part, image_height):
         import torch.distributed as dist
         ctx.rows = None
-        full = local.detach().clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            ctx.rows = strip_pixel_rows(part, dist.get_rank(), image_height)
-            y0, y1 = ctx.rows
-            full[:, :y0] = 0
-            full[:, y1:] = 0                     # only the own strip contributes
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return local.detach().clone()
+        world = dist.get_world_size()
+        spans = [strip_pixel_rows(part, r, image_height) for r in range(world)]
+        ctx.rows = spans[dist.get_rank()]
+        y0, y1 = ctx.rows
+        tall = max(b - a for a, b in spans)
+        C, _, W = local.shape
+        mine = local.new_zeros(C, tall, W)
+        mine[:, :y1 - y0] = local.detach()[:, y0:y1]
+        gathered = local.new_empty(world, C, tall, W)
+        if dist.get_backend() == "gloo":          # the CPU test backend has no all_gather_into_tensor
+            dist.all_gather(list(gathered.unbind(0)), mine)
+        else:
+            dist.all_gather_into_tensor(gathered, mine)
+        full = torch.empty_like(local)
+        for r, (a, b) in enumerate(spans):
+            full[:, a:b] = gathered[r, :, :b - a]
         return full
 
     @staticmethod

@@ -54,6 +54,8 @@ class _Policy:
     capacity = 0
     variant = int(os.environ.get("TRASE_RAST_VARIANT", "0"), 0)
     last_geom: Optional[torch.Tensor] = None
+    last_bin: Optional[torch.Tensor] = None     # bin workspace of the most recent forward (for last_tile_row_loads)
+    last_hw = None
     last_capacity = 0
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
     max_pending = 8
@@ -171,8 +173,9 @@ def _pick_capacity(lib, ws, stream) -> int:
     return max(int(_Policy.capacity), 1)
 
 
-def _after_render(geom: torch.Tensor, capacity: int):
+def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor] = None, hw=None):
     _Policy.last_geom, _Policy.last_capacity = geom, capacity
+    _Policy.last_bin, _Policy.last_hw = binb, hw
     if not _Policy.sync:
         pin = torch.empty(32, dtype=torch.int32).pin_memory()
         pin.copy_(geom[:128].view(torch.int32), non_blocking=True)
@@ -192,6 +195,23 @@ def last_status():
     st = (C.c_int64 * 3)()
     _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), _stream(_Policy.last_geom.device)), "trase_rast_status")
     return int(st[0]), int(st[1]), int(st[2])
+
+
+def last_tile_row_loads() -> torch.Tensor:
+    """Binned (8x8 sub-tile, Gaussian) pairs per ROW of 16x16 tiles of the most recent forward -- what a tile-row strip
+    costs to composite.  ``trase_amd.dp.tile_row_partition(H, world, loads=...)`` turns the previous view's loads into a
+    load-balanced partition (consecutive training views see similar loads).  Synchronises (one small D2H copy)."""
+    if _Policy.last_bin is None or _Policy.last_hw is None:
+        raise RuntimeError("no forward has run yet")
+    H, W = _Policy.last_hw
+    gx8, gy8 = (W + 7) // 8, (H + 7) // 8
+    cap = int(_Policy.last_capacity)
+    off = 2 * ((4 * cap + 255) // 256 * 256)              # BinBuf: point_list | pair_slot | ranges (trase_amd/csrc/api.hip carve_bin)
+    rng = _Policy.last_bin[off:off + 8 * gx8 * gy8].view(torch.int32).reshape(gy8, gx8, 2).to(torch.int64)
+    per_sub_row = (rng[..., 1] - rng[..., 0]).clamp_min(0).sum(dim=1)
+    if gy8 % 2:
+        per_sub_row = torch.cat([per_sub_row, per_sub_row.new_zeros(1)])
+    return per_sub_row.reshape(-1, 2).sum(dim=1).cpu()
 
 
 def geom_view(geom: torch.Tensor, P: int) -> dict:
@@ -321,7 +341,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ws.capacity = capacity
         _lib.check(lib.trase_rast_render(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
                    "trase_rast_render")
-        _after_render(geom, capacity)
+        _after_render(geom, capacity, binb, (H, W))
 
         ctx.raster_settings = raster_settings
         ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg

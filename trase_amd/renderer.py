@@ -145,7 +145,7 @@ class _RenderRaw(torch.autograd.Function):
         ws.capacity = capacity
         _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                    "trase_rast_render_raw")
-        _after_render(geom, capacity)
+        _after_render(geom, capacity, binb, (H, W))
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
         ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
         ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
