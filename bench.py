@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--cpu-oracle-budget-s", type=float, default=1.0, help="forward wall-time budget of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core (os.cpu_count())")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
+    ap.add_argument("--graph", action="store_true",
+                    help="launch-graph replay of the forward / backward launch sequences (trase_amd.rasterizer.set_graph): for the "
+                         "small BASELINE configurations, which are host-bound otherwise")
     ap.add_argument("--shard", choices=["views", "tiles"], default="views",
                     help="'views' (default, the headline): every rank renders a different view.  'tiles' (BASELINE config 5): ONE "
                          "view per step for the whole job, every rank renders a load-balanced strip of 16x16-tile rows, the RGB "
@@ -347,6 +350,10 @@ def main():
     R.set_sync(False, capacity=int(max(reff_list) * 1.25) + 1024)
     log(f"pairs per view: lineage R mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f}); binned sub-tile pairs mean {reff_mean:.0f}")
 
+    if args.graph:
+        R.set_graph(True)
+        for i in range(2 * n_views):      # every view's forward and backward sequence is captured once
+            step(i)
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -434,6 +441,7 @@ def main():
                        "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
                        "subtile_pairs_mean": round(reff_mean),
                        "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant,
+                       "graph_replay": (R.graph_stats() if args.graph else None),
                        "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
                                 else "gaussian_renderer.render() drop-in, A1 prep fused",
                        "exchange": (None if bucket is None else

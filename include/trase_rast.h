@@ -217,6 +217,21 @@ int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* 
                           const TraseRastWorkspace* ws, trase_stream_t stream);
 int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                             const TraseRastWorkspace* ws, const TraseRastRawGrads* g, trase_stream_t stream);
+/* trase_rast_preprocess_raw + trase_rast_render_raw in one call, for callers that know the capacity beforehand (the
+ * sync-free policy): one boundary crossing per direction. */
+int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                           const TraseRastWorkspace* ws, trase_stream_t stream);
+
+/* Launch-graph replay (hipGraph) for small workloads, where the ~45 kernel launches of a direction cost more host time
+ * than the kernels run (BASELINE configs 1 and 2).  With mode != 0, trase_rast_forward / _forward_raw / _backward /
+ * _backward_raw capture their launch sequence once per distinct argument record (every scalar and every pointer of the
+ * settings, inputs, outputs, workspace and gradient structs) on an internal stream and replay the instantiated graph on
+ * the caller's stream when the same record comes back -- which it does in a training loop whose allocator hands out the
+ * same blocks every iteration.  Only the sync-free entry points are graphed (nothing in them reads back to the host).
+ * The cache holds up to 256 graphs and switches itself off when records stop repeating (a miss costs a capture).
+ * trase_rast_graph_stats: {hits, misses, cached, enabled}. */
+int trase_rast_graph_mode(int mode);
+int trase_rast_graph_stats(int64_t stats[4]);
 
 /* The same backward in two phases, for a view-parallel caller that starts exchanging the gradients of the first Gaussians
  * while the last ones are still being reduced (trase_amd/dp.py; the reference is single-process, train.py:303):

@@ -121,6 +121,10 @@ SYMBOLS = [
                                       C.POINTER(RastWorkspace), C.POINTER(RastGrads), C.c_void_p]),
     ("trase_rast_preprocess_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                             C.POINTER(RastWorkspace), C.c_void_p]),
+    ("trase_rast_forward_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                         C.POINTER(RastWorkspace), C.c_void_p]),
+    ("trase_rast_graph_mode", C.c_int, [C.c_int]),
+    ("trase_rast_graph_stats", C.c_int, [C.POINTER(C.c_int64 * 4)]),
     ("trase_rast_render_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                         C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_backward_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -162,6 +163,69 @@ static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
   return TRASE_OK;
 }
 
+// ---- launch-graph replay ----------------------------------------------------------------------------------------
+// key = every byte of the argument records of a call; value = the instantiated graph of its launch sequence
+struct GraphEntry { std::string key; hipGraphExec_t exec; };
+static std::mutex g_graph_mu;
+static int g_graph_mode = 0;
+static std::map<uint64_t, std::vector<GraphEntry>> g_graphs;
+static size_t g_graph_count = 0;
+static int64_t g_graph_hits = 0, g_graph_misses = 0;
+static hipStream_t g_capture_stream = nullptr;
+
+static uint64_t fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+static void graph_clear_locked() {
+  for (auto& kv : g_graphs) for (auto& e : kv.second) hipGraphExecDestroy(e.exec);
+  g_graphs.clear();
+  g_graph_count = 0;
+}
+
+// Runs body(stream) either directly, or -- graph mode, profiler off, no per-kernel debug sync -- as a cached graph.
+template <class Body>
+static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const void*, size_t>> parts, int debug,
+                             hipStream_t stream, Body&& body) {
+  if (!g_graph_mode || debug || prof_on()) return body(stream);
+  std::string key((const char*)&entry_id, sizeof(entry_id));
+  for (auto& p : parts) if (p.first) key.append((const char*)p.first, p.second); else key.append(p.second, '\0');
+  const uint64_t h = fnv1a(key);
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  auto it = g_graphs.find(h);
+  if (it != g_graphs.end()) {
+    for (auto& e : it->second) {
+      if (e.key == key) {
+        ++g_graph_hits;
+        return check_hip(hipGraphLaunch(e.exec, stream), "hipGraphLaunch");
+      }
+    }
+  }
+  ++g_graph_misses;
+  // records that never repeat (an allocator handing out new blocks every iteration): give up, a capture per call is a loss
+  if (g_graph_misses > 512 && g_graph_hits < g_graph_misses) { g_graph_mode = 0; graph_clear_locked(); return body(stream); }
+  if (g_graph_count >= 256) graph_clear_locked();
+  if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) return body(stream);
+  if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return body(stream); }
+  const int rc = body(g_capture_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(g_capture_stream, &graph);
+  if (rc != TRASE_OK || ec != hipSuccess || !graph) {
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return rc != TRASE_OK ? rc : body(stream);
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) { (void)hipGetLastError(); return body(stream); }
+  g_graphs[h].push_back(GraphEntry{key, exec});
+  ++g_graph_count;
+  return check_hip(hipGraphLaunch(exec, stream), "hipGraphLaunch");
+}
+
 enum { WS_GEOM = 1, WS_PRE = 2, WS_BIN = 4, WS_IMG = 8, WS_TMP = 16 };
 static int check_ws(const TraseRastInputs* in, const TraseRastSettings* s, const TraseRastWorkspace* ws, int need) {
   if (!ws) { set_error("null workspace"); return TRASE_ERR_WORKSPACE; }
@@ -302,13 +366,42 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
 
 int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                        const TraseRastWorkspace* ws, trase_stream_t stream) {
-  int rc = trase_rast_preprocess(s, in, out, ws, stream);
-  if (rc) return rc;
-  return trase_rast_render(s, in, out, ws, stream);
+  if (!s || !in || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  return run_maybe_graphed(1, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, (hipStream_t)stream,
+                           [&](hipStream_t st) {
+                             int rc = trase_rast_preprocess(s, in, out, ws, st);
+                             if (rc) return rc;
+                             return trase_rast_render(s, in, out, ws, st);
+                           });
 }
+
+int trase_rast_graph_mode(int mode) {
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  g_graph_mode = mode;
+  g_graph_hits = g_graph_misses = 0;
+  if (!mode) graph_clear_locked();
+  return TRASE_OK;
+}
+
+int trase_rast_graph_stats(int64_t stats[4]) {
+  if (!stats) return TRASE_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  stats[0] = g_graph_hits; stats[1] = g_graph_misses; stats[2] = (int64_t)g_graph_count; stats[3] = g_graph_mode;
+  return TRASE_OK;
+}
+
+static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_);
 
 int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
+  if (!s || !in || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  return run_maybe_graphed(2, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug,
+                           (hipStream_t)stream_, [&](hipStream_t st) { return backward_impl(s, in, out, ws, gr, st); });
+}
+
+static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
+                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
   int rc = validate(s, in);
   if (rc) return rc;
   if (!gr || !out || (in->P > 0 && !out->radii)) { set_error("null grads/outputs"); return TRASE_ERR_INVALID; }
@@ -493,7 +586,20 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
 
 int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                             const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream) {
-  return backward_raw_phases(s, raw, out, ws, gr, stream, 3, -1, -1);
+  if (!s || !raw || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  return run_maybe_graphed(4, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug,
+                           (hipStream_t)stream, [&](hipStream_t st) { return backward_raw_phases(s, raw, out, ws, gr, st, 3, -1, -1); });
+}
+
+int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
+                           const TraseRastWorkspace* ws, trase_stream_t stream) {
+  if (!s || !raw || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  return run_maybe_graphed(3, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, (hipStream_t)stream,
+                           [&](hipStream_t st) {
+                             int rc = trase_rast_preprocess_raw(s, raw, out, ws, st);
+                             if (rc) return rc;
+                             return trase_rast_render_raw(s, raw, out, ws, st);
+                           });
 }
 
 int trase_rast_backward_raw_compose(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,

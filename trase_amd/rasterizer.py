@@ -70,6 +70,22 @@ def set_sync(flag: bool, capacity: int = 0):
     _Policy.pending = []
 
 
+def set_graph(flag: bool = True):
+    """Launch-graph replay (include/trase_rast.h ``trase_rast_graph_mode``): with the sync-free policy, a forward or backward
+    whose argument record (sizes, every pointer) repeats is replayed as ONE hipGraph launch instead of ~45 kernel launches.
+    Pays on small workloads, where the launches cost more host time than the kernels run (BASELINE configs 1 and 2: 1 k and
+    150 k Gaussians); at the 1080p headline the step is GPU-bound either way.  Needs ``set_sync(False)``; records repeat
+    when the allocator hands out the same blocks every iteration (a steady training loop); if they do not, the library
+    switches the mode off by itself."""
+    _lib.check(_lib.load().trase_rast_graph_mode(1 if flag else 0), "trase_rast_graph_mode")
+
+
+def graph_stats() -> dict:
+    st = (C.c_int64 * 4)()
+    _lib.check(_lib.load().trase_rast_graph_stats(C.byref(st)), "trase_rast_graph_stats")
+    return {"hits": int(st[0]), "misses": int(st[1]), "cached": int(st[2]), "enabled": bool(st[3])}
+
+
 def set_variant(v: int):
     _Policy.variant = int(v)
 
@@ -147,6 +163,8 @@ def _poll_pending(block: bool = False):
                 _header_verdict(pin.tolist(), cap, "a previous sync-free forward")
             except RuntimeError as e:      # report the first, still drain the rest
                 err = err or e
+            if len(_PIN_RING) < 16:
+                _PIN_RING.append((pin, ev))
         else:
             keep.append((ev, pin, cap))
     _Policy.pending = keep
@@ -173,13 +191,32 @@ def _pick_capacity(lib, ws, stream) -> int:
     return max(int(_Policy.capacity), 1)
 
 
+_PIN_RING: list = []       # pinned header buffers + their events, recycled once their verdict has been read
+_SIZES: dict = {}          # (P, W, H, F, capacity) -> workspace sizes (a ctypes call per lookup otherwise)
+
+
+def _sizes(lib, P: int, W: int, H: int, F: int, capacity: int):
+    key = (P, W, H, F, capacity)
+    v = _SIZES.get(key)
+    if v is None:
+        sz = _lib.RastSizes()
+        _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sz)), "trase_rast_sizes")
+        v = (sz.geom_bytes, sz.bin_bytes, sz.img_bytes, sz.pre_bytes, sz.tmp_bytes, sz.bwd_tmp_bytes)
+        if len(_SIZES) > 256:
+            _SIZES.clear()
+        _SIZES[key] = v
+    return v
+
+
 def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor] = None, hw=None):
     _Policy.last_geom, _Policy.last_capacity = geom, capacity
     _Policy.last_bin, _Policy.last_hw = binb, hw
     if not _Policy.sync:
-        pin = torch.empty(32, dtype=torch.int32).pin_memory()
+        if _PIN_RING:
+            pin, ev = _PIN_RING.pop()
+        else:
+            pin, ev = torch.empty(32, dtype=torch.int32).pin_memory(), torch.cuda.Event()
         pin.copy_(geom[:128].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(geom.device))
         _Policy.pending.append((ev, pin, capacity))
 
@@ -241,6 +278,8 @@ def _stream(device) -> C.c_void_p:
 def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
     if t is None:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():      # the steady-state case: nothing to do
+        return t
     if t.device != device:
         raise ValueError(f"{name} must live on {device}, got {t.device}")
     if t.dtype != torch.float32:
@@ -255,6 +294,13 @@ def _bytes(n: int, device) -> torch.Tensor:
     if _POISON:
         return torch.full((max(int(n), 1),), 255, dtype=torch.uint8, device=device)
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+
+
+def _output_maps(F: int, H: int, W: int, device, zero: bool):
+    """(image (3,H,W), feats (F,H,W), depth (1,H,W)) as three slices of ONE allocation (one allocator round trip instead
+    of three; a strip render starts from zeros because it leaves the other rows untouched)."""
+    buf = (torch.zeros if zero else torch.empty)(3 + F + 1, H, W, device=device)
+    return buf[:3], buf[3:3 + F], buf[3 + F:]
 
 
 def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _lib.RastSettings:
@@ -310,37 +356,38 @@ class _RasterizeGaussians(torch.autograd.Function):
         inp.opacities, inp.scales, inp.rotations = _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations)
         inp.cov3D_precomp = _lib.ptr(cov3Ds_precomp)
 
-        mk = torch.zeros if (s.tile_row_begin or s.tile_row_end) else torch.empty    # a strip leaves the other rows untouched
-        image = mk(3, H, W, device=device)
-        feats = mk(F, H, W, device=device)
-        depth = mk(1, H, W, device=device)
+        image, feats, depth = _output_maps(F, H, W, device, bool(s.tile_row_begin or s.tile_row_end))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         out = _lib.RastOutputs()
         out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
         out.feats = _lib.ptr(feats) if F > 0 else None
 
-        sizes = _lib.RastSizes()
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, 1, C.byref(sizes)), "trase_rast_sizes")
-        geom = _bytes(sizes.geom_bytes, device)
-        pre = _bytes(sizes.pre_bytes, device)
-        img = _bytes(sizes.img_bytes, device)
+        geom_b, _, img_b, pre_b, _, _ = _sizes(lib, P, W, H, F, 1)
+        geom = _bytes(geom_b, device)
+        pre = _bytes(pre_b, device)
+        img = _bytes(img_b, device)
         ws = _lib.RastWorkspace()
         ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
         ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
         ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
         stream = _stream(device)
 
-        _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
-                   "trase_rast_preprocess")
+        one_call = (not _Policy.sync) and _Policy.capacity > 0      # capacity known beforehand: one boundary crossing
+        if not one_call:
+            _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_preprocess")
         capacity = _pick_capacity(lib, ws, stream)
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
-        binb = _bytes(sizes.bin_bytes, device)
-        tmp = _bytes(sizes.tmp_bytes, device)
+        _, bin_b, _, _, tmp_b, _ = _sizes(lib, P, W, H, F, capacity)
+        binb = _bytes(bin_b, device)
+        tmp = _bytes(tmp_b, device)
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
         ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
         ws.capacity = capacity
-        _lib.check(lib.trase_rast_render(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
-                   "trase_rast_render")
+        if one_call:
+            _lib.check(lib.trase_rast_forward(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream), "trase_rast_forward")
+        else:
+            _lib.check(lib.trase_rast_render(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_render")
         _after_render(geom, capacity, binb, (H, W))
 
         ctx.raster_settings = raster_settings
@@ -377,9 +424,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         out.radii = _lib.ptr(radii)
         out.depth = _lib.ptr(depth_out)
 
-        sizes = _lib.RastSizes()
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")
-        tmp = _bytes(sizes.bwd_tmp_bytes, device)
+        tmp = _bytes(_sizes(lib, P, W, H, F, ctx.capacity)[5], device)
         ws = _lib.RastWorkspace()
         ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()

@@ -18,7 +18,7 @@ from . import _lib
 from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _bytes, _fill_settings,
-                         _pick_capacity, _prep, _stream)
+                         _output_maps, _pick_capacity, _prep, _sizes, _stream)
 
 
 def set_backward_scope(scope: str = "all") -> None:
@@ -119,32 +119,34 @@ class _RenderRaw(torch.autograd.Function):
         raw.gaussian_features = _lib.ptr(gfeat) if F > 0 else None
         raw.featn = _lib.ptr(featn)
 
-        mk = torch.zeros if (s.tile_row_begin or s.tile_row_end) else torch.empty    # a strip leaves the other rows untouched
-        image = mk(3, H, W, device=device)
-        feats = mk(F, H, W, device=device)
-        depth = mk(1, H, W, device=device)
+        image, feats, depth = _output_maps(F, H, W, device, bool(s.tile_row_begin or s.tile_row_end))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         out = _lib.RastOutputs()
         out.image, out.radii, out.depth = _lib.ptr(image), _lib.ptr(radii), _lib.ptr(depth)
         out.feats = _lib.ptr(feats) if F > 0 else None
-        sizes = _lib.RastSizes()
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, 1, C.byref(sizes)), "trase_rast_sizes")
-        geom, pre, img = _bytes(sizes.geom_bytes, device), _bytes(sizes.pre_bytes, device), _bytes(sizes.img_bytes, device)
+        geom_b, _, img_b, pre_b, _, _ = _sizes(lib, P, W, H, F, 1)
+        geom, pre, img = _bytes(geom_b, device), _bytes(pre_b, device), _bytes(img_b, device)
         ws = _lib.RastWorkspace()
         ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
         ws.pre, ws.pre_bytes = _lib.ptr(pre), pre.numel()
         ws.img, ws.img_bytes = _lib.ptr(img), img.numel()
         stream = _stream(device)
-        _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
-                   "trase_rast_preprocess_raw")
+        one_call = (not _Policy.sync) and _Policy.capacity > 0      # capacity known beforehand: one boundary crossing
+        if not one_call:
+            _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_preprocess_raw")
         capacity = _pick_capacity(lib, ws, stream)
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, capacity, C.byref(sizes)), "trase_rast_sizes")
-        binb, tmp = _bytes(sizes.bin_bytes, device), _bytes(sizes.tmp_bytes, device)
+        _, bin_b, _, _, tmp_b, _ = _sizes(lib, P, W, H, F, capacity)
+        binb, tmp = _bytes(bin_b, device), _bytes(tmp_b, device)
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
         ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
         ws.capacity = capacity
-        _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
-                   "trase_rast_render_raw")
+        if one_call:
+            _lib.check(lib.trase_rast_forward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_forward_raw")
+        else:
+            _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_render_raw")
         _after_render(geom, capacity, binb, (H, W))
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
         ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
@@ -185,9 +187,7 @@ class _RenderRaw(torch.autograd.Function):
         out = _lib.RastOutputs()
         out.radii = _lib.ptr(radii)
         out.depth = _lib.ptr(depth_out)
-        sizes = _lib.RastSizes()
-        _lib.check(lib.trase_rast_sizes(P, W, H, F, ctx.capacity, C.byref(sizes)), "trase_rast_sizes")
-        tmp = _bytes(sizes.bwd_tmp_bytes, device)
+        tmp = _bytes(_sizes(lib, P, W, H, F, ctx.capacity)[5], device)
         ws = _lib.RastWorkspace()
         ws.geom, ws.geom_bytes = _lib.ptr(geom), geom.numel()
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
