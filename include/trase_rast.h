@@ -386,6 +386,14 @@ int trase_nnfm_backward(const float* feat1, const float* feats2, int32_t C, int3
 int trase_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
                     double beta2, float eps, int32_t device, trase_stream_t stream);
+/* The same step behind a DEVICE-side guard: `guard` is the geom workspace of the forward whose gradients the step consumes
+ * (its 64-word header holds the overflow flag and the binning guards).  When that forward overflowed its pair buffer the
+ * kernel returns without touching parameters or moments -- the reference skips optimizer.step() on a bad iteration
+ * (train.py:298-301, :378) after a host-side check; the sync-free policy cannot afford that check, so the decision is
+ * taken where the flag lives.  guard == NULL: no guard. */
+int trase_adam_step_guarded(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
+                            double beta2, float eps, const void* guard, int32_t device, trase_stream_t stream);
 
 /* Per-kernel timing with HIP events on the caller's stream (used by bench.py's
  * roofline leg).  enable=1 starts recording, the report call synchronises the
@@ -422,6 +430,9 @@ const char* trase_version(void);
  *   normal_samples on the last call only (after xyz and scaling were gathered); it may be NULL only when M == 0. */
 int trase_densify_stats(const float* viewspace_grad, const int32_t* radii, float* xyz_gradient_accum, float* denom,
                         float* max_radii2D, int32_t P, int32_t device, trase_stream_t stream);
+/* guard: as for trase_adam_step_guarded -- the statistics of an overflowed view are not taken */
+int trase_densify_stats_guarded(const float* viewspace_grad, const int32_t* radii, float* xyz_gradient_accum, float* denom,
+                                float* max_radii2D, int32_t P, const void* guard, int32_t device, trase_stream_t stream);
 int trase_densify_sizes(int32_t P, size_t* ws_bytes);
 int trase_densify_plan(const float* xyz_gradient_accum, const float* denom, const float* scaling, const float* opacity,
                        int32_t P, float grad_threshold, float dense_extent, float min_opacity, int32_t use_screen_size,

@@ -1361,3 +1361,60 @@ def test_feature_only_backward_scope():
         else:
             assert float(b.abs().max()) == 0.0
     assert float(vp_only.abs().max()) == 0.0 and float(vp_full.abs().max()) > 0
+
+
+def test_device_side_guard_skips_the_step_of_an_overflowed_iteration():
+    """under the sync-free policy an overflowing forward is only REPORTED later (the next forward /
+    check_overflow) -- after optimizer.step() has run.  The guarded FusedAdam step and add_densification_stats test the
+    forward's overflow flag on the device: parameters, both Adam moments and the densification statistics stay
+    bit-identical, the step counters are rolled back when the overflow is reported, and the next (fitting) iteration
+    steps normally.  Mirrors the reference's skipped optimizer step on a bad iteration (train.py:298-301, :378)."""
+    from gaussian_renderer import render
+    from trase_amd import rasterizer as R
+    from trase_amd.densify import add_densification_stats
+    from trase_amd.optim import FusedAdam
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, make_scene, orbit_camera
+    dev = _dev()
+    pc = SynthGaussianModel(make_scene(4000, feat_dim=32, seed=9, scale_mult=1.2).to(dev))
+    n = pc._xyz.shape[0]
+    pc.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+    pc.denom = torch.zeros(n, 1, device=dev)
+    pc.max_radii2D = torch.zeros(n, device=dev)
+    cam = orbit_camera(160, 112, angle=0.7).to(dev)
+    bg = torch.zeros(3, device=dev)
+    params = pc.parameters()
+    opt = FusedAdam([{"params": [p], "lr": 1e-3} for p in params], lr=0.0, eps=1e-15)
+    gi, gf = torch.randn(3, 112, 160, device=dev), torch.randn(32, 112, 160, device=dev)
+
+    def iteration():
+        opt.zero_grad(set_to_none=True)
+        out = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0)
+        torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])
+        add_densification_stats(pc, out["viewspace_points"], out["radii"])
+        opt.step()
+
+    try:
+        R.set_sync(True)
+        iteration()                                                    # creates the optimizer state; exact capacity
+        pairs = R.last_status()[2]
+        snap = lambda: [p.detach().clone() for p in params] + [opt.state[p][k].clone() for p in params for k in ("exp_avg", "exp_avg_sq")] + \
+                       [pc.xyz_gradient_accum.clone(), pc.denom.clone(), pc.max_radii2D.clone()]
+        before = snap()
+        steps_before = [float(opt.state[p]["step"]) for p in params]
+        R.set_sync(False, capacity=max(pairs // 3, 1))                 # too small: this iteration overflows on the device
+        iteration()
+        torch.cuda.synchronize()
+        after = snap()
+        for k, (a, b) in enumerate(zip(before, after)):
+            assert torch.equal(a, b), f"tensor {k} changed although its iteration overflowed"
+        with pytest.raises(RuntimeError, match="pair buffer overflowed"):
+            R.check_overflow()
+        assert [float(opt.state[p]["step"]) for p in params] == steps_before, "step counters must be rolled back"
+        assert R._Policy.capacity >= pairs
+        iteration()                                                    # fits now: a normal step
+        R.check_overflow()
+        torch.cuda.synchronize()
+        assert not torch.equal(before[0], params[0].detach())
+        assert [float(opt.state[p]["step"]) for p in params] == [s + 1 for s in steps_before]
+    finally:
+        R.set_sync(True)

@@ -163,6 +163,8 @@ SYMBOLS = [
     ("trase_contrastive_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_densify_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("trase_densify_stats_guarded", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                              C.c_int32, C.c_void_p]),
     ("trase_densify_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     ("trase_densify_plan", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                      C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
@@ -186,6 +188,8 @@ SYMBOLS = [
                                       C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_adam_step", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_int32, C.c_void_p]),
+    ("trase_adam_step_guarded", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_prof_enable", C.c_int, [C.c_int]),
     ("trase_prof_report", C.c_int, [C.c_char_p, C.c_size_t]),
     ("trase_selftest", C.c_int, [C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]),

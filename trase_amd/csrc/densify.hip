@@ -51,7 +51,10 @@ static size_t densify_ws_carve(int P, DensifyWs* w, void* base) {
 
 __global__ __launch_bounds__(256) void densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii,
                                                             float* __restrict__ accum, float* __restrict__ denom,
-                                                            float* __restrict__ max_radii, int P) {
+                                                            float* __restrict__ max_radii, int P,
+                                                            const uint32_t* __restrict__ guard) {
+  // guard = header of the forward's geom workspace: the statistics of an overflowed (incomplete) view are not taken
+  if (guard && (guard[HDR_OVERFLOW] | guard[16] | guard[20])) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const int r = radii[i];
@@ -233,6 +236,11 @@ extern "C" {
 
 int trase_densify_stats(const float* viewspace_grad, const int32_t* radii, float* xyz_gradient_accum, float* denom,
                         float* max_radii2D, int32_t P, int32_t device, trase_stream_t stream_) {
+  return trase_densify_stats_guarded(viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D, P, nullptr, device, stream_);
+}
+
+int trase_densify_stats_guarded(const float* viewspace_grad, const int32_t* radii, float* xyz_gradient_accum, float* denom,
+                                float* max_radii2D, int32_t P, const void* guard, int32_t device, trase_stream_t stream_) {
   if (P < 0 || (P > 0 && (!viewspace_grad || !radii || !xyz_gradient_accum || !denom || !max_radii2D))) {
     set_error("trase_densify_stats: bad arguments"); return TRASE_ERR_INVALID;
   }
@@ -242,7 +250,7 @@ int trase_densify_stats(const float* viewspace_grad, const int32_t* radii, float
   {
     ProfScope ps("densify_stats", stream);
     hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, viewspace_grad, radii,
-                       xyz_gradient_accum, denom, max_radii2D, P);
+                       xyz_gradient_accum, denom, max_radii2D, P, (const uint32_t*)guard);
   }
   TRASE_POST_LAUNCH("densify_stats", stream, 0);
   return TRASE_OK;

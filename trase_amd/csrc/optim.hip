@@ -16,7 +16,13 @@ struct AdamTensors {
 };
 constexpr int AD_PER_BLOCK = 256 * 4;
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float w1, float beta2, float w2, float eps) {
+// guard: the 64-word header of a forward's geom workspace (or null).  A forward whose pair buffer overflowed, or whose
+// binning guards tripped, rendered incomplete images and gradients: the step that would consume them is skipped ON THE
+// DEVICE -- parameters and both moments stay bit-identical -- like the reference skips its optimizer step on a bad
+// iteration (train.py:298-301, :378), without the host ever waiting for the flag.
+__global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float w1, float beta2, float w2, float eps,
+                                                   const uint32_t* __restrict__ guard) {
+  if (guard && (guard[HDR_OVERFLOW] | guard[16] | guard[20])) return;
   int k = 0;
   while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;      // wave-uniform, <= 16 steps
   const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * AD_PER_BLOCK + threadIdx.x * 4;
@@ -54,6 +60,12 @@ extern "C" {
 int trase_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
                     double beta2, float eps, int32_t device, trase_stream_t stream_) {
+  return trase_adam_step_guarded(count, params, grads, exp_avg, exp_avg_sq, numel, lr, step, beta1, beta2, eps, nullptr, device, stream_);
+}
+
+int trase_adam_step_guarded(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const float* lr, const int64_t* step, double beta1,
+                            double beta2, float eps, const void* guard, int32_t device, trase_stream_t stream_) {
   if (count < 0 || count > AD_MAX) { set_error("trase_adam_step: %d tensors (max %d per call)", count, AD_MAX); return TRASE_ERR_INVALID; }
   if (count == 0) return TRASE_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !step) { set_error("trase_adam_step: null table"); return TRASE_ERR_INVALID; }
@@ -79,7 +91,7 @@ int trase_adam_step(int32_t count, float* const* params, const float* const* gra
     ProfScope ps("adam", stream);
     // 1 - beta in double, then rounded (as Python does for torch): 1.0f - 0.999f would lose five digits
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, t, (float)(1.0 - beta1), (float)beta2,
-                       (float)(1.0 - beta2), eps);
+                       (float)(1.0 - beta2), eps, (const uint32_t*)guard);
   }
   TRASE_POST_LAUNCH("adam", stream, 0);
   return TRASE_OK;

@@ -56,8 +56,12 @@ def add_densification_stats(model, viewspace_point_tensor: torch.Tensor, radii: 
         raise ValueError("densification statistics do not match the number of Gaussians")
     lib = _lib.load()
     dev = g.device
-    _lib.check(lib.trase_densify_stats(_lib.ptr(g), _lib.ptr(rad), _lib.ptr(acc), _lib.ptr(den), _lib.ptr(mr), P,
-                                       _dev_index(dev), _stream(dev)), "trase_densify_stats")
+    # under the sync-free policy the statistics of a view whose pair buffer overflowed are not taken (device-side guard)
+    from . import rasterizer as _r
+    gh = _r.current_guard()
+    gp = _lib.ptr(gh[0]) if (gh and gh[0].device == dev) else None
+    _lib.check(lib.trase_densify_stats_guarded(_lib.ptr(g), _lib.ptr(rad), _lib.ptr(acc), _lib.ptr(den), _lib.ptr(mr), P, gp,
+                                               _dev_index(dev), _stream(dev)), "trase_densify_stats_guarded")
 
 
 def _groups(model):

@@ -23,7 +23,14 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, guard="auto"):
+        """guard="auto": under the rasterizer's sync-free policy the step is issued behind a device-side guard on the most
+        recent forward's overflow flag (``trase_amd.rasterizer.current_guard``): if that forward overflowed its pair
+        buffer, parameters and moments stay bit-identical and the step counters are rolled back when the overflow is
+        reported.  guard=None: unconditional."""
+        from . import rasterizer as _r
+        g_handle = _r.current_guard() if guard == "auto" else guard
+        guard_geom, on_overflow = g_handle if g_handle else (None, None)
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -59,6 +66,14 @@ class FusedAdam(torch.optim.Optimizer):
                 N = (C.c_int64 * n)(*[it[0].numel() for it in chunk])
                 LR = (C.c_float * n)(*[float(it[3]) for it in chunk])
                 ST = (C.c_int64 * n)(*[int(it[2]["step"]) for it in chunk])
-                _lib.check(lib.trase_adam_step(n, P, G, M, V, N, LR, ST, C.c_double(betas[0]), C.c_double(betas[1]), float(eps), d,
-                                               _stream(dev)), "trase_adam_step")
+                gp = _lib.ptr(guard_geom) if (guard_geom is not None and guard_geom.device == dev) else None
+                _lib.check(lib.trase_adam_step_guarded(n, P, G, M, V, N, LR, ST, C.c_double(betas[0]), C.c_double(betas[1]),
+                                                       float(eps), gp, d, _stream(dev)), "trase_adam_step_guarded")
+        if on_overflow is not None:
+            states = [it[2] for items in batches.values() for it in items]
+
+            def undo():                  # the device skipped this step: the bias corrections must not count it
+                for st_ in states:
+                    st_["step"] -= 1
+            on_overflow(undo)
         return loss

@@ -58,6 +58,7 @@ class _Policy:
     last_hw = None
     last_capacity = 0
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
+    rollbacks: dict = {}        # id(pinned header) -> callbacks to run if that forward turns out to have overflowed
     max_pending = 8
     tile_rows = (0, 0)          # strip of 16x16-tile rows to render; (0, 0) = the whole image
     feat_bg = 0.0               # background value of the feature channels (lineage switch, variant bit 0x10000)
@@ -68,6 +69,7 @@ def set_sync(flag: bool, capacity: int = 0):
     _Policy.sync = bool(flag)
     _Policy.capacity = int(capacity)
     _Policy.pending = []
+    _Policy.rollbacks = {}
 
 
 def set_graph(flag: bool = True):
@@ -148,7 +150,9 @@ def _header_verdict(h, cap: int, what: str):
     if int(h[1]):
         raise RuntimeError(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
                            f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
-                           f"has been grown to {_Policy.capacity}; re-run the iteration (or use set_sync(True)).")
+                           f"has been grown to {_Policy.capacity}.  Guarded consumers of that iteration (FusedAdam.step, "
+                           f"add_densification_stats) skipped it on the device: parameters and moments are unchanged -- "
+                           f"carry on with the next iteration, or re-run this one (or use set_sync(True)).")
 
 
 def _poll_pending(block: bool = False):
@@ -159,10 +163,13 @@ def _poll_pending(block: bool = False):
         if must:
             ev.synchronize()
         if must or ev.query():
+            undo = _Policy.rollbacks.pop(id(pin), [])
             try:
                 _header_verdict(pin.tolist(), cap, "a previous sync-free forward")
             except RuntimeError as e:      # report the first, still drain the rest
                 err = err or e
+                for fn in undo:            # host-side bookkeeping of steps the device skipped (Adam step counters)
+                    fn()
             if len(_PIN_RING) < 16:
                 _PIN_RING.append((pin, ev))
         else:
@@ -170,6 +177,18 @@ def _poll_pending(block: bool = False):
     _Policy.pending = keep
     if err is not None:
         raise err
+
+
+def current_guard():
+    """(geom workspace, on_overflow) of the most recent forward under the sync-free policy, else None.  The geom header is
+    what the guarded device-side consumers (``FusedAdam.step``, ``add_densification_stats``) test: a forward that
+    overflowed its pair buffer produced incomplete gradients, and the optimizer step that would consume them is skipped ON
+    THE DEVICE (the reference skips ``optimizer.step()`` on a bad iteration, train.py:298-301, :378).  ``on_overflow(fn)``
+    registers host-side bookkeeping to undo once the overflow is reported."""
+    if _Policy.sync or _Policy.last_geom is None or not _Policy.pending:
+        return None
+    pin = _Policy.pending[-1][1]
+    return _Policy.last_geom, _Policy.rollbacks.setdefault(id(pin), []).append
 
 
 def check_overflow():
@@ -219,6 +238,7 @@ def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor
         pin.copy_(geom[:128].view(torch.int32), non_blocking=True)
         ev.record(torch.cuda.current_stream(geom.device))
         _Policy.pending.append((ev, pin, capacity))
+        _Policy.rollbacks[id(pin)] = []
 
 
 def last_status():
