@@ -68,6 +68,7 @@ typedef struct TraseRastSettings {
                             * 0x200 point-list gather fused into tile_ranges; 0x400 feature-only backward;
                             * 0x800 round-1 64-entry-chunk MFMA backward; 0x1000 timing instrumentation of the backward;
                             * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch);
+                            * 0x40000 compositing kernels visit the sub-tiles in image order, 0x80000 in 8x8 blocks (default: 16x16 blocks);
                             * 0x8000 lane-utilisation counters of the MFMA backward (diagnostic, header words 40..46).
                             * LINEAGE SWITCHES (the three places the absent fork of the CUDA extension is most
                             * likely to differ from the public lineage; each flips the HIP kernels AND oracle/raster_oracle.py):

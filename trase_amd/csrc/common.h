@@ -180,6 +180,25 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 #endif
 }
 
+// Sub-tile visited by the i-th unit of the dispatch order.  The compositing kernels are sensitive to which sub-tiles are in
+// flight together: neighbours share most of their Gaussians' geometry and channel rows, and the wave slots of one XCD hold
+// 200-450 sub-tiles at a time.  In image (row-major) order that is one 240-wide row of sub-tiles whose Gaussians (~4 MB of
+// rows) overflow the XCD's L2 and share nothing with the row above; in BxB blocks it is a compact patch whose Gaussians
+// fit.  (Dispatching the longest lists first instead -- to shorten the tail -- made the forward 28 % SLOWER: locality,
+// not the tail, is what the order buys.)  Order: bands of B sub-tile rows; inside a band, blocks of B columns left to
+// right; inside a block, row-major.  Ragged right / bottom blocks are narrower / lower.  Bijective on [0, gx * gy).
+template <int B>
+__device__ __forceinline__ void blocked_tile(int i, int gx, int gy, int& tx, int& ty) {
+  const int band = i / (B * gx), rem = i - band * (B * gx);
+  const int hb = min(B, gy - band * B);                   // rows of this band
+  const int ncol = (gx + B - 1) / B;
+  const int sc = min(rem / (hb * B), ncol - 1);           // block column
+  const int r2 = rem - sc * hb * B;
+  const int wb = min(B, gx - sc * B);                     // columns of this block
+  ty = band * B + r2 / wb;
+  tx = sc * B + r2 - (r2 / wb) * wb;
+}
+
 // value of lane-1 (lane 0 receives `ident`): DPP wave_shr:1
 __device__ __forceinline__ float wave_shr1(float v, float ident) { return dpp_fill<0x138>(v, ident); }
 

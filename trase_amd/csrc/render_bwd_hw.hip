@@ -52,6 +52,7 @@ struct BwdHwArgs {
   uint32_t* prof;      // 8 counters (TIMING builds) or null
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
+  int order_mode;        // 0: image order; 8 / 16: blocks of 8x8 / 16x16 sub-tiles (common.h blocked_tile)
   int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
   float feat_bg;
   const float* out_depth;  // the forward's depth map (read only for the normalised-depth switch with a depth cotangent)
@@ -139,8 +140,13 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   const int g = lane & 31, h = lane >> 5;
   const int local = xcd_block(blockIdx.x, gridDim.x) * HW_WPB + wave;
   if (local >= a.ntiles) return;
-  const int tile = a.tile0 + local;
-  const int tx = tile % a.gx8, ty = tile / a.gx8;
+  int tx, ty;
+  if (a.order_mode == 0) { const int t0 = a.tile0 + local; tx = t0 % a.gx8; ty = t0 / a.gx8; }
+  else {
+    if (a.order_mode == 8) blocked_tile<8>(local, a.gx8, a.ntiles / a.gx8, tx, ty); else blocked_tile<16>(local, a.gx8, a.ntiles / a.gx8, tx, ty);
+    ty += a.tile0 / a.gx8;
+  }
+  const int tile = ty * a.gx8 + tx;
   const uint2 range = a.ranges[tile];
   HwWaveLds& L = s_w[wave];
   uint64_t t_mark = 0, t_acc[5] = {0, 0, 0, 0, 0};
@@ -445,6 +451,7 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
                          void* chan, size_t flag_bytes, const float* out_depth) {
   BwdHwArgs a;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg; a.out_depth = out_depth;
+  a.order_mode = (c.variant & 0x40000) ? 0 : ((c.variant & 0x80000) ? 8 : 16);
   if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && gr.dL_ddepth && !out_depth) {
     set_error("render_bwd: the normalised-depth switch with a depth cotangent needs the forward's depth map (outputs.depth)");
     return TRASE_ERR_INVALID;

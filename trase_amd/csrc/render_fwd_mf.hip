@@ -65,6 +65,7 @@ struct FwdMfArgs {
   float* out_img; float* out_feat; float* out_depth; float* final_T; uint32_t* n_contrib;
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
+  int order_mode;        // 0: image order; 8 / 16: blocks of 8x8 / 16x16 sub-tiles (common.h blocked_tile)
   int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
   float feat_bg;
 };
@@ -101,8 +102,13 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   const int m = lane & 31, h = lane >> 5;
   const int local = xcd_block(blockIdx.x, gridDim.x);
   if (local >= a.ntiles) return;
-  const int tile = a.tile0 + local;
-  const int tx = tile % a.gx8, ty = tile / a.gx8;
+  int tx, ty;
+  if (a.order_mode == 0) { const int t0 = a.tile0 + local; tx = t0 % a.gx8; ty = t0 / a.gx8; }
+  else {
+    if (a.order_mode == 8) blocked_tile<8>(local, a.gx8, a.ntiles / a.gx8, tx, ty); else blocked_tile<16>(local, a.gx8, a.ntiles / a.gx8, tx, ty);
+    ty += a.tile0 / a.gx8;
+  }
+  const int tile = ty * a.gx8 + tx;
   const uint2 range = a.ranges[tile];
   const float bx = (float)(tx * SUB), by = (float)(ty * SUB);
   // this lane's pixel: row 4 wv + (m >> 3), column m & 7
@@ -336,6 +342,7 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
+  a.order_mode = (c.variant & 0x40000) ? 0 : ((c.variant & 0x80000) ? 8 : 16);
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip
