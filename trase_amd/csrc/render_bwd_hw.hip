@@ -33,11 +33,15 @@ constexpr int HW_LD = 40;     // LDS row pitch in bf16 (80 B)
 constexpr int HW_G = 32;      // list entries per chunk
 
 struct HwWaveLds {
-  float4 pix[WAVE];           // T_end, U_end, last (bits), -   (first: the carry writes are ds_write2_b64, whose two 8-bit
-                              // offsets only reach 2 KB from the base register)
-  __bf16 hi[WAVE * HW_LD];    // hi | lo | pad contiguous on purpose: the over-read of GEMM 1's last K-step stays inside them
+  // Pixel-major cotangent image, hi and lo bf16 halves, pitch 40: 36 channels + 4 columns that only pad the row to 16 bytes.
+  // Those padding columns carry the per-pixel scan state, so that a wave's LDS is exactly 10 KB and SIXTEEN waves fit a CU
+  // (a separate 1 KB state array made it 11.25 KB = fourteen; the kernel is bound by latency at that residency):
+  //   hi row p, columns 36..39 (8 bytes): T_end (transmittance behind the entries walked so far), U_end (fp32 bits)
+  //   lo row p, columns 36..37 (4 bytes): n_contrib;  38..39: zero
+  // GEMM 1 would multiply them with the channel table's zeros -- raw fp32 bits are not finite bf16 -- so its last K-step
+  // masks those two dwords of its A fragments; GEMM 2 only produces unused output rows from them.
+  __bf16 hi[WAVE * HW_LD];
   __bf16 lo[WAVE * HW_LD];
-  __bf16 pad[8];              // zeros: what the over-read of the last row of `lo` finds (the low half of a float is not a finite bf16)
 };
 
 struct BwdHwArgs {
@@ -192,17 +196,20 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     }
     __bf16* rh = L.hi + lane * HW_LD;
     __bf16* rl = L.lo + lane * HW_LD;
+    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2] + bextra;
 #pragma unroll
     for (int c8 = 0; c8 < HW_LD / 8; ++c8) {
       bf16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[8 * c8 + e]; lo[e] = (__bf16)(v[8 * c8 + e] - (float)hi[e]); }
-      *reinterpret_cast<bf16x8*>(rh + 8 * c8) = hi;
-      *reinterpret_cast<bf16x8*>(rl + 8 * c8) = lo;
+      u32x4 uh = __builtin_bit_cast(u32x4, hi), ul = __builtin_bit_cast(u32x4, lo);
+      if (c8 == HW_LD / 8 - 1) {                          // columns 36..39: the pixel's scan state instead of zeros
+        uh[2] = __float_as_uint(Tf); uh[3] = __float_as_uint(Tf * bdot);
+        ul[2] = last; ul[3] = 0u;
+      }
+      *reinterpret_cast<u32x4*>(rh + 8 * c8) = uh;
+      *reinterpret_cast<u32x4*>(rl + 8 * c8) = ul;
     }
-    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2] + bextra;
-    L.pix[lane] = make_float4(Tf, Tf * bdot, __uint_as_float(last), 0.f);
-    if (lane == 0) *reinterpret_cast<uint4*>(L.pad) = make_uint4(0u, 0u, 0u, 0u);
   }
   uint32_t wave_last = last;
 #pragma unroll
@@ -224,6 +231,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   // channel column of this lane for the cot^T gathers: block nb covers channels nb*32 + g; columns >= 40 do not exist
   // (they are zero): read column 39, which is zero, instead
   const int col0 = g, col1 = min(32 + g, HW_LD - 1);
+  const unsigned hmask = h ? 0xffffffffu : 0u;           // GEMM 1, last K-step: half 0 holds the state dwords of columns 36..39
   // transposing-read addressing of the same fragments: pixel row (lane & 15) >> 2 of the K-step's four, channel chunk
   // 16 * ((lane >> 4) & 1) + 4 * (lane & 3) of the block; block 1 only has the chunks 32..35 and 36..39 (zeros)
   const int trrow = ((lane & 15) >> 2) * HW_LD;
@@ -281,8 +289,18 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(crow + ks * 16 + HW_CH);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-          const bf16x8 ph = *reinterpret_cast<const bf16x8*>(ahi + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
-          const bf16x8 pl = *reinterpret_cast<const bf16x8*>(alo + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
+          bf16x8 ph, pl;
+          if (ks < 2) {
+            ph = *reinterpret_cast<const bf16x8*>(ahi + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
+            pl = *reinterpret_cast<const bf16x8*>(alo + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
+          } else {
+            // channels 32..39 (h = 0: the state dwords are masked) / 40..47 (h = 1: the next pixel row's first eight columns,
+            // multiplied by the channel table's zeros; the last row of the image reads its own first columns instead)
+            const int off = (mb == 1 && lane == 63) ? 63 * HW_LD : (mb * 32 + g) * HW_LD + 32 + 8 * h;
+            u32x4 rh4 = *reinterpret_cast<const u32x4*>(ahi + off), rl4 = *reinterpret_cast<const u32x4*>(alo + off);
+            rh4[2] &= hmask; rh4[3] &= hmask; rl4[2] &= hmask; rl4[3] &= hmask;
+            ph = __builtin_bit_cast(bf16x8, rh4); pl = __builtin_bit_cast(bf16x8, rl4);
+          }
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, ks == 0 ? ZERO16 : Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, Sm[mb], 0, 0, 0);
@@ -308,8 +326,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           if constexpr (COUNT) { if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) cnt[2] += 1; else cnt[3] += 1; }
           if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) {
             const int pl = p0 + 4 * h;                     // this lane's first pixel of the step
-            const float4 pa = L.pix[pl], pb = L.pix[pl + 1];
-            const uint32_t lasta = __float_as_uint(pa.z), lastb = __float_as_uint(pb.z);
+            const float2 pa = *reinterpret_cast<const float2*>(L.hi + pl * HW_LD + 36);          // T_end, U_end
+            const float2 pb = *reinterpret_cast<const float2*>(L.hi + (pl + 1) * HW_LD + 36);
+            const uint32_t lasta = *reinterpret_cast<const uint32_t*>(L.lo + pl * HW_LD + 36);
+            const uint32_t lastb = *reinterpret_cast<const uint32_t*>(L.lo + (pl + 1) * HW_LD + 36);
             const float ea = poly_eval(k, base, slope, jv[r]);
             const float eb = poly_eval(k, base, slope, jv[r + 1]);
             const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
@@ -329,7 +349,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             const float Ta = pa.x * Pa, Tb = pb.x * Pb;   // transmittance in front of this Gaussian
             const float wa = ala * Ta, wb = alb * Tb;
             if constexpr (FEAT_ONLY) {
-              if (g == HW_G - 1) { L.pix[pl].x = Ta; L.pix[pl + 1].x = Tb; }
+              if (g == HW_G - 1) {
+                *reinterpret_cast<float*>(L.hi + pl * HW_LD + 36) = Ta;
+                *reinterpret_cast<float*>(L.hi + (pl + 1) * HW_LD + 36) = Tb;
+              }
             } else {
               const float sa = S[4 * q + r], sb = S[4 * q + r + 1];
               const float wsa = wa * sa, wsb = wb * sb;
@@ -338,8 +361,8 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
               const float Ua = pa.y + (ia - wsa), Ub = pb.y + (ib - wsb);
               const float dLa = Ta * sa - Ua * roma, dLb = Tb * sb - Ub * romb;
               if (g == HW_G - 1) {                         // carries for the next (nearer) chunk
-                L.pix[pl].x = Ta;     L.pix[pl].y = pa.y + ia;
-                L.pix[pl + 1].x = Tb; L.pix[pl + 1].y = pb.y + ib;
+                *reinterpret_cast<float2*>(L.hi + pl * HW_LD + 36) = make_float2(Ta, pa.y + ia);
+                *reinterpret_cast<float2*>(L.hi + (pl + 1) * HW_LD + 36) = make_float2(Tb, pb.y + ib);
               }
               const float qa = ra * dLa, qb = rb * dLb;    // == opacity * G * dL/dalpha (straight-through clamp)
               if (r == 0) {                                // local columns jl = 0, 1: weights (1, 0, 0) and (1, 1, 1)
