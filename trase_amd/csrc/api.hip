@@ -57,7 +57,10 @@ ProfScope::~ProfScope() {
 }
 
 // ---- workspace layout ---------------------------------------------------------------------------------
-static inline int rs_blocks(size_t n) { return (int)((n + 2047) / 2048); }
+#ifndef TRASE_RS_ITEMS
+#define TRASE_RS_ITEMS 8
+#endif
+static inline int rs_blocks(size_t n) { return (int)((n + 256 * TRASE_RS_ITEMS - 1) / (256 * TRASE_RS_ITEMS)); }   // binning.hip RS_TILE
 
 size_t geom_bytes(int P) {
   const size_t p = (size_t)P;
