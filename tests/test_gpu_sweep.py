@@ -87,7 +87,11 @@ def test_random_parity_sweep():
 #   far       -- the cloud scaled x5..x20, camera moved out alike: z in [14, 106] (the depth map's magnitude)
 #   clusters  -- blobs of different density over a sparse background: empty and very deep tile lists in one image
 #   longfocal -- focal 3-5 W from radius 6-10: large splats, small field of view
-def _family_configs(per_family=12, seed=20260929):
+def _family_configs(per_family=None, seed=None):
+    # TRASE_FAMILY_COUNT / TRASE_FAMILY_SEED widen the sweep without editing the test (round 3: 60 per family with seed 777,
+    # see profiles/r3_parity_extended.txt)
+    per_family = int(os.environ.get("TRASE_FAMILY_COUNT", 12)) if per_family is None else per_family
+    seed = int(os.environ.get("TRASE_FAMILY_SEED", 20260929)) if seed is None else seed
     rnd = random.Random(seed)
     out = []
     for fam in ("inside", "far", "clusters", "longfocal"):

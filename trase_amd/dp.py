@@ -147,6 +147,10 @@ class FlatGradBucket:
                 if p_end == P:
                     self._exchanged.add(id(p))
         self._pending.extend(self._reduce_many(slices))
+        if p_end == P:
+            # a later in-place accumulation into a view (a second backward, a regulariser on the parameter) would race with
+            # the collectives in flight and never be reduced: remember the views' versions as the last range leaves them
+            self._versions = {id(p): v._version for p, v in zip(self.params, self._views) if id(p) in self._exchanged}
 
     def allreduce(self, average: bool = False):
         import torch.distributed as dist
@@ -155,6 +159,14 @@ class FlatGradBucket:
             w.wait()                                         # the current stream waits for the ranges' collectives
         self._pending, self._exchanged = [], set()
         # a range exchange only counts for a parameter whose gradient still IS the bucket view it was written to
+        versions = getattr(self, "_versions", {})
+        self._versions = {}
+        for p, v in zip(self.params, self._views):
+            if id(p) in exchanged and v._version != versions.get(id(p), v._version):
+                raise RuntimeError("FlatGradBucket: a gradient was modified in place after its ranges had been handed to the "
+                                   "overlapped exchange (a second backward or a direct loss term on the parameter?); that "
+                                   "contribution raced with the collective and is not reduced -- use one all-reduce after the "
+                                   "backward (exchange chunks = 1) for such a loop")
         done = {id(p) for p, v in zip(self.params, self._views)
                 if id(p) in exchanged and p.grad is not None and p.grad.data_ptr() == v.data_ptr()}
         self.gather_grads()
