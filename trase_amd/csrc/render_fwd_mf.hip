@@ -226,14 +226,18 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
           // blended.  The products are monotone, so "still live at entry u" is a threshold on Ts * Pu[u].
           uint32_t lastb = 0;                            // 1 + index of this lane's last blended entry
           float cand = INFINITY;                         // transmittance after the last live entry of this lane
+          // (selects, not branches: in a dense scene most pixels finish, each in its own step, so this block runs in a
+          // large share of the K-steps; the per-entry exec-masked regions the compiler made of the nested ifs were ~250
+          // instructions with 96 register-pair moves)
           float prev = 1.0f;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const bool live = Ts * Pu[u] >= T_STOP;
-            if (crossing) {
-              if (!live) w[u] = 0.f;
-              else { cand = Ts * Pu[u]; if (Pu[u] < prev) lastb = (uint32_t)(u + 1); }
-            }
+            const float tu = Ts * Pu[u];
+            const bool live = crossing && tu >= T_STOP;
+            const bool dead = crossing && !(tu >= T_STOP);
+            w[u] = dead ? 0.f : w[u];
+            cand = live ? tu : cand;
+            lastb = (live && Pu[u] < prev) ? (uint32_t)(u + 1) : lastb;
             prev = Pu[u];
           }
           const auto sl = __builtin_amdgcn_permlane32_swap(lastb, lastb, false, false);
