@@ -80,3 +80,43 @@ def test_autograd_matches_finite_differences():
                 continue
             checked += 1
         assert checked >= 8, name
+
+
+def test_lineage_switches_of_the_oracle():
+    """OracleOptions.feats_bg / depth_normalised (SURVEY.md Appendix A switches; the HIP side's variant bits 0x10000 /
+    0x20000 are compared against exactly this in tests/test_gpu_lineage.py): closed-form relations to the default render,
+    and autograd through both (finite differences)."""
+    act, cam = small_case(n=120, w=48, h=32, feat=4, seed=5, scale_mult=1.5)
+    st = settings_for(cam, bg=(0.1, 0.2, 0.3))
+    base = _render(act, st)
+    fb = _render(act, st, opt=ro.OracleOptions(feats_bg=True, feat_bg_value=0.35))
+    dn = _render(act, st, opt=ro.OracleOptions(depth_normalised=True))
+    np.testing.assert_allclose(fb.feats.numpy(), (base.feats + 0.35 * base.final_T[None]).numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fb.image.numpy(), base.image.numpy(), rtol=0, atol=0)
+    A = (1.0 - base.final_T)[None]
+    want = torch.where(A > 1e-10, base.depth / A.clamp_min(1e-10), torch.zeros_like(base.depth))
+    np.testing.assert_allclose(dn.depth.numpy(), want.numpy(), rtol=0, atol=1e-12)
+    covered = base.final_T < 0.5
+    assert bool(covered.any()) and float(dn.depth[0][covered].min()) > 1.5     # a normalised depth is a depth of the scene
+    # gradients: d/d opacity of sum(feats) and sum(depth) through the switches against finite differences
+    op = act["opacities"].double().clone().requires_grad_(True)
+    opt = ro.OracleOptions(feats_bg=True, feat_bg_value=0.35, depth_normalised=True, lineage_grads=False)
+
+    def loss_of(o_):
+        r = ro.rasterize(st, act["means3D"], None, shs=act["shs"], sh_objs=act["sh_objs"], opacities=o_, scales=act["scales"],
+                         rotations=act["rotations"], opt=opt)
+        return r.feats.sum() + r.depth.sum()
+    loss_of(op).backward()
+    rng = np.random.default_rng(1)
+    ok = 0
+    for idx in rng.permutation(op.numel())[:10]:
+        eps = 1e-6
+        v = []
+        for sgn in (+1, -1):
+            o2 = op.detach().clone()
+            o2.reshape(-1)[idx] += sgn * eps
+            v.append(loss_of(o2).item())
+        fd = (v[0] - v[1]) / (2 * eps)
+        if abs(fd - op.grad.reshape(-1)[idx].item()) <= 1e-4 * max(1.0, abs(fd)):
+            ok += 1
+    assert ok >= 7
