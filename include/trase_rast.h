@@ -70,6 +70,8 @@ typedef struct TraseRastSettings {
                             * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch);
                             * 0x40000 compositing kernels visit the sub-tiles in image order, 0x80000 in 8x8 blocks (default: 16x16 blocks);
                             * 0x8000 lane-utilisation counters of the MFMA backward (diagnostic, header words 40..46).
+                            * 0x100000 the sub-tile lists always carry emit-order slots (default: packed (id, pair index) values
+                            * whenever every Gaussian has few enough pairs -- decided on the device, results identical).
                             * LINEAGE SWITCHES (the three places the absent fork of the CUDA extension is most
                             * likely to differ from the public lineage; each flips the HIP kernels AND oracle/raster_oracle.py):
                             * 0x100 the depth cotangent is honoured; 0x10000 the feature map gets a background term

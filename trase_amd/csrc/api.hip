@@ -65,7 +65,7 @@ static inline int rs_blocks(size_t n) { return (int)((n + 256 * TRASE_RS_ITEMS -
 size_t geom_bytes(int P) {
   const size_t p = (size_t)P;
   return align_up(sizeof(uint32_t) * HDR_WORDS) + align_up(sizeof(float2) * p) + align_up(sizeof(float4) * p) * 2 +
-         align_up(sizeof(uint32_t) * p) * 2;
+         align_up(sizeof(uint32_t) * p) * 2 + align_up(sizeof(float4) * 4 * p);
 }
 GeomBuf carve_geom(void* ptr, int P) {
   const size_t p = (size_t)P;
@@ -76,7 +76,8 @@ GeomBuf carve_geom(void* ptr, int P) {
   g.conic_o = (float4*)c; c += align_up(sizeof(float4) * p);
   g.rgbd = (float4*)c; c += align_up(sizeof(float4) * p);
   g.tiles = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
-  g.clamped = (uint32_t*)c;
+  g.clamped = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
+  g.geo = (float4*)c;
   return g;
 }
 // ranges holds T sub-tiles + 1 sentinel ("trash") entry
@@ -101,9 +102,16 @@ ImgBuf carve_img(void* ptr, int W, int H) {
 static size_t sort_bytes_common(size_t n) {   // hist + digit_total
   return align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n)) + align_up(sizeof(uint32_t) * 256 * 8);
 }
+// bits of a packed list value left for the pair index (HDR_PACK); 0 = the variant's kernels need emit-order slots
+static int list_pack_bits(const TraseRastSettings* s, int P) {
+  if (s->variant & (0x1 | 0x200 | 0x100000)) return 0;
+  int lg = 0;
+  while ((1ll << lg) < (long long)P) ++lg;
+  return lg >= 28 ? 0 : 32 - lg;
+}
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 6 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2) + sort_bytes_common(p);
+  return align_up(sizeof(uint32_t) * p) * 6 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -113,7 +121,7 @@ PreBuf carve_pre(void* ptr, int P) {
   for (int i = 0; i < 2; ++i) { t.sort.vals[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   t.offsets = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
-  t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 2);
+  t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3);
   t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(p);
@@ -301,7 +309,7 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   }
   // the pair count is compared against the capacity later (stage 2 knows it); 0xffffffff = no limit yet
   return launch_scan_tiles(c, g, t.sort.vals[0], in->P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
-                           (s->image_height + TILE - 1) / TILE);
+                           (s->image_height + TILE - 1) / TILE, list_pack_bits(s, in->P));
 }
 
 int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream_) {
@@ -334,6 +342,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
   BinBuf b = carve_bin(ws->bin, ws->capacity, T);
   ImgBuf im = carve_img(ws->img, s->image_width, s->image_height);
   PreBuf pre = carve_pre(ws->pre, in->P);
+  b.id_end = pre.id_end;       // the forward turns packed list values into row slots (HDR_PACK)
   PairBuf t = carve_tmp(ws->tmp, ws->capacity);
   const uint32_t cap = (uint32_t)ws->capacity;
   if (in->P > 0) {
@@ -346,10 +355,10 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     t.sort.vals[final_idx] = b.pair_slot;
     t.sort.vals[final_idx ^ 1] = t.spare_vals;
     rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap,
-                           (s->variant & 0x200) ? nullptr : b.ranges);
+                           (s->variant & 0x200) ? nullptr : b.ranges, t.sort.vals[0]);
     if (rc) return rc;
     int idx = 0;
-    rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, true, &idx);
+    rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, false, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
     if (s->variant & 0x200) {       // A/B: dedicated slot -> id gather pass (the render kernel reads ids)
@@ -506,7 +515,7 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   if (rc) return rc;
   if (idx != 0) { set_error("internal: depth sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
   return launch_scan_tiles(c, g, t.sort.vals[0], in.P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
-                           (s->image_height + TILE - 1) / TILE);
+                           (s->image_height + TILE - 1) / TILE, list_pack_bits(s, in.P));
 }
 
 int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,

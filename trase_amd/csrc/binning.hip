@@ -295,7 +295,8 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
                                                                   uint32_t* __restrict__ block_sums,
                                                                   const int32_t* __restrict__ radii,
                                                                   const float2* __restrict__ xy, int gx, int gy,
-                                                                  uint32_t* __restrict__ block_R) {
+                                                                  uint32_t* __restrict__ block_R,
+                                                                  uint32_t* __restrict__ block_max) {
   __shared__ uint32_t sh[SC_THREADS];
   const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
   uint32_t area = 0;
@@ -314,13 +315,26 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
   if (threadIdx.x == SC_THREADS - 1) block_R[blockIdx.x] = area_incl;
   __syncthreads();
   uint32_t v[SC_ITEMS];
-  uint32_t sum = 0;
+  uint32_t sum = 0, mx = 0;
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int r = base + i;
     v[i] = (r < P) ? tiles[ids[r]] : 0u;
+    mx = max(mx, v[i]);
     sum += v[i];
     v[i] = sum;
+  }
+  {   // largest pair count of one Gaussian in this block (decides whether list values can be packed, HDR_PACK)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    __shared__ uint32_t shm[SC_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t m = shm[0];
+      for (int w = 1; w < SC_THREADS / 64; ++w) m = max(m, shm[w]);
+      block_max[blockIdx.x] = m;
+    }
   }
   const uint32_t incl = block_incl_scan(sum, sh);
   const uint32_t excl = incl - sum;
@@ -334,7 +348,8 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
 
 __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks,
                                                                uint32_t* __restrict__ hdr, uint32_t cap,
-                                                               const uint32_t* __restrict__ block_R) {
+                                                               const uint32_t* __restrict__ block_R,
+                                                               const uint32_t* __restrict__ block_max, int pack_bits) {
   __shared__ uint32_t sh[SC_THREADS];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -359,6 +374,16 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
   __syncthreads();
   const uint32_t total = block_incl_scan(part, sh);
   if (threadIdx.x == SC_THREADS - 1) hdr[HDR_R] = total;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (int b = threadIdx.x; b < nblocks; b += SC_THREADS) mx = max(mx, block_max[b]);
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = SC_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hdr[HDR_PACK] = (pack_bits > 0 && sh[0] < (1u << pack_bits)) ? (uint32_t)pack_bits : 0u;
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __restrict__ offsets, int P,
@@ -379,14 +404,16 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __rest
 }
 
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
-                      const int32_t* radii, int gx, int gy) {
+                      const int32_t* radii, int gx, int gy, int pack_bits) {
   const int nblocks = (P + SC_TILE - 1) / SC_TILE;
   uint32_t* const block_R = t.block_sums + ((size_t)P / 1024 + 2);
+  uint32_t* const block_max = t.block_sums + 2 * ((size_t)P / 1024 + 2);
   {
     ProfScope ps("scan_tiles", c.stream);
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, sorted_ids, P,
-                       t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R);
+                       t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R, block_max);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R,
+                       block_max, pack_bits);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums, sorted_ids,
                        t.id_end);
   }
@@ -411,7 +438,11 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ tiles, int W, int H, int gx, int gy,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
                                                          uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key,
-                                                         uint2* __restrict__ ranges, int sy_lo, int sy_hi) {
+                                                         uint2* __restrict__ ranges, int sy_lo, int sy_hi,
+                                                         uint32_t* __restrict__ vals, uint32_t* __restrict__ geo_words) {
+  // list value of a pair (what the sub-tile sort carries): its emit-order slot, or -- HDR_PACK -- (id << jb) | index among
+  // the Gaussian's own pairs, from which the compositing kernels get the id with a shift instead of a load
+  const uint32_t jb = hdr[HDR_PACK];
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = gt >> 2, q = gt & 3;
   // the sub-tile ranges (trash_key + 1 entries incl. the sentinel) are cleared here: tile_ranges runs after the sort
@@ -433,6 +464,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   if (nt) {
     p = xy[id]; co = conic_o[id];
     tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
+    if (q == 0) geo_words[16 * (size_t)id + 2] = off0;        // first row slot, next to the geometry the backward fetches
   }
   const bool big = nt > EMIT_BIG;
   if (nt && !big) {
@@ -452,13 +484,16 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
       const int n3 = __builtin_amdgcn_update_dpp(0, cnt, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
       uint32_t w = pos + (uint32_t)((q > 0 ? n0 : 0) + (q > 1 ? n1 : 0) + (q > 2 ? n2 : 0));
       for (int sx = c0; sx < c1; ++sx, ++w)
-        if (w < end && w < cap) { keys[w] = (uint32_t)(sy * gx8 + sx); pair_gauss[w] = id; }
+        if (w < end && w < cap) {
+          keys[w] = (uint32_t)(sy * gx8 + sx);
+          if (jb) vals[w] = (id << jb) | (w - off0); else { vals[w] = w; pair_gauss[w] = id; }
+        }
       pos += (uint32_t)(n0 + n1 + n2 + n3);
     }
     // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused slots go
     // to the sentinel sub-tile `trash_key` that no kernel renders
     for (pos += q; pos < end; pos += 4)
-      if (pos < cap) { keys[pos] = trash_key; pair_gauss[pos] = id; }
+      if (pos < cap) { keys[pos] = trash_key; pair_gauss[pos] = id; vals[pos] = jb ? (id << jb) : pos; }
   }
   // ---- big splats: the whole wave, one splat after the other -------------------------------------------------------
   unsigned long long todo = __ballot(big && q == 0);
@@ -470,7 +505,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
     const float ba = __shfl(co.x, l), bb = __shfl(co.y, l), bc = __shfl(co.z, l), bo = __shfl(co.w, l);
     const int bx0 = __shfl(x0, l), by0 = __shfl(y0, l), bx1 = __shfl(x1, l), by1 = __shfl(y1, l);
     const uint32_t bid = (uint32_t)__shfl((int)id, l), bend = (uint32_t)__shfl((int)end, l);
-    uint32_t run = (uint32_t)__shfl((int)off0, l);
+    const uint32_t boff0 = (uint32_t)__shfl((int)off0, l);
+    uint32_t run = boff0;
     const SubtileCull cull = subtile_cull_setup(bpx, bpy, ba, bb, bc, bo);
     const int r_lo = max(2 * by0, sy_lo), r_hi = min(2 * by1, sy_hi);
     for (int rb = r_lo; rb < r_hi; rb += WAVE) {
@@ -486,17 +522,20 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
       }
       uint32_t pos = run + incl - cnt;
       for (int sx = c0; sx < c1; ++sx, ++pos)
-        if (pos < bend && pos < cap) { keys[pos] = (uint32_t)(sy * gx8 + sx); pair_gauss[pos] = bid; }
+        if (pos < bend && pos < cap) {
+          keys[pos] = (uint32_t)(sy * gx8 + sx);
+          if (jb) vals[pos] = (bid << jb) | (pos - boff0); else { vals[pos] = pos; pair_gauss[pos] = bid; }
+        }
       run += (uint32_t)__shfl((int)incl, WAVE - 1);
     }
     for (uint32_t o = run + lane; o < bend; o += WAVE)
-      if (o < cap) { keys[o] = trash_key; pair_gauss[o] = bid; }
+      if (o < cap) { keys[o] = trash_key; pair_gauss[o] = bid; vals[o] = jb ? (bid << jb) : o; }
   }
 }
 
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
-                      uint2* ranges_to_clear) {
+                      uint2* ranges_to_clear, uint32_t* vals) {
   const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
   int sy_lo, sy_hi;
   strip_subtile_rows(s, sy_lo, sy_hi);
@@ -505,7 +544,7 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((4 * P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
                        g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
                        (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)), ranges_to_clear,
-                       sy_lo, sy_hi);
+                       sy_lo, sy_hi, vals, (uint32_t*)g.geo);
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
   return TRASE_OK;

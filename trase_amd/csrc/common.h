@@ -267,7 +267,15 @@ static inline void strip_subtile_rows(const TraseRastSettings& s, int& lo, int& 
 // ----------------------------------------------------------------------------------------------
 // workspace carving (must match trase_rast_sizes)
 // ----------------------------------------------------------------------------------------------
-enum { HDR_R = 0, HDR_OVERFLOW = 1, HDR_R_EFF = 2, HDR_WORDS = 64 };
+enum { HDR_R = 0, HDR_OVERFLOW = 1, HDR_R_EFF = 2, HDR_PACK = 3, HDR_WORDS = 64 };
+// HDR_PACK: 0 = list values are emit-order slots (ids through pair_gauss / point_list); jb > 0 = list values are
+// (Gaussian id << jb) | (index of the pair among the Gaussian's own pairs): decided on the device (every Gaussian must have
+// fewer than 2^jb pairs), it saves the compositing kernels the slot -> id load level
+__device__ __forceinline__ uint32_t list_id(uint32_t v, uint32_t jb) { return v >> jb; }
+__device__ __forceinline__ uint32_t list_slot(uint32_t v, uint32_t jb, const uint32_t* id_end, const uint32_t* tiles) {
+  const uint32_t id = v >> jb;
+  return id_end[id] - tiles[id] + (v & ((1u << jb) - 1u));
+}
 
 struct GeomBuf {           // saved between forward and backward
   uint32_t* hdr;           // HDR_WORDS counters
@@ -276,11 +284,13 @@ struct GeomBuf {           // saved between forward and backward
   float4* rgbd;            // (P) colour + view depth
   uint32_t* tiles;         // (P) tiles touched (0 == culled)
   uint32_t* clamped;       // (P) colour clamp bits
+  float4* geo;             // (P, 4) one 64-byte record per Gaussian: {x, y, first row slot, -}, conic_o, rgbd, unused
 };
 struct BinBuf {            // saved between forward and backward
   uint32_t* point_list;    // (capacity) Gaussian ids, sub-tile-major, depth-ordered
   uint32_t* pair_slot;     // (capacity) emit-order slot of every list entry (Gaussian-major numbering)
   uint2* ranges;           // (T) [start,end) per sub-tile
+  const uint32_t* id_end = nullptr;   // PreBuf::id_end (with GeomBuf::tiles: row slot of a packed list value, HDR_PACK); forward only
 };
 struct ImgBuf {            // saved between forward and backward
   float* final_T;          // (H*W)
@@ -353,11 +363,12 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
                      bool vals_are_iota, int* out_idx);
 int radix_passes(int bit_lo, int bit_hi);
 
+// pack_bits: 0 = never pack; jb = pack list values as (id << jb | j) when every Gaussian has fewer than 2^jb pairs
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
-                      const int32_t* radii, int gx, int gy);
+                      const int32_t* radii, int gx, int gy, int pack_bits = 0);
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
-                      uint2* ranges_to_clear = nullptr);
+                      uint2* ranges_to_clear = nullptr, uint32_t* vals = nullptr);
 int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
                       uint32_t cap, uint32_t* point_list);
 // raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)

@@ -33,7 +33,7 @@ __device__ __forceinline__ void fill_view(const PreArgs& a, View& v) {
 template <bool USE_COV, bool USE_SH>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t* __restrict__ radii,
                                                              float2* __restrict__ xy, float4* __restrict__ conic_o,
-                                                             float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
+                                                             float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ tiles,
                                                              uint32_t* __restrict__ clamped,
                                                              uint32_t* __restrict__ depth_keys,
                                                              uint32_t* __restrict__ hdr) {
@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
     xy[i] = make_float2(o.px, o.py);
     conic_o[i] = make_float4(o.ca, o.cb, o.cc, opac);
     rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    // the same 40 bytes as ONE 64-byte record: the compositing kernels fetch a list entry's geometry from one cache line
+    // (word 2 of the record: the Gaussian's first row slot, written by emit_pairs)
+    geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, 0.f);
+    geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, opac);
+    geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }
 }
@@ -122,7 +127,7 @@ int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const 
   const bool cov = in.cov3D_precomp != nullptr, sh = in.shs != nullptr;
   {
     ProfScope ps("preprocess_fwd", c.stream);
-#define TRASE_PRE_FWD(C, S) hipLaunchKernelGGL((preprocess_fwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr)
+#define TRASE_PRE_FWD(C, S) hipLaunchKernelGGL((preprocess_fwd_kernel<C, S>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.tiles, g.clamped, depth_keys, g.hdr)
     if (cov) { if (sh) TRASE_PRE_FWD(true, true); else TRASE_PRE_FWD(true, false); }
     else { if (sh) TRASE_PRE_FWD(false, true); else TRASE_PRE_FWD(false, false); }
 #undef TRASE_PRE_FWD

@@ -139,7 +139,7 @@ constexpr int RAW_BLOCK = 64;                                // one wave per wor
 template <int F>
 __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
                                                                  float2* __restrict__ xy, float4* __restrict__ conic_o,
-                                                                 float4* __restrict__ rgbd, uint32_t* __restrict__ tiles,
+                                                                 float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ tiles,
                                                                  uint32_t* __restrict__ clamped,
                                                                  uint32_t* __restrict__ depth_keys,
                                                                  uint32_t* __restrict__ hdr) {
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
     xy[i] = make_float2(o.px, o.py);
     conic_o[i] = make_float4(o.ca, o.cb, o.cc, act.opac);
     rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    // the same 40 bytes as ONE 64-byte record: the compositing kernels fetch a list entry's geometry from one cache line
+    // (word 2 of the record: the Gaussian's first row slot, written by emit_pairs)
+    geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, 0.f);
+    geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, act.opac);
+    geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }
   // feature rows the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121).  F / 4 lanes per
@@ -230,7 +235,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   const dim3 grid((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), block(RAW_BLOCK);
   {
     ProfScope ps("preprocess_fwd", c.stream);
-#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.tiles, g.clamped, depth_keys, g.hdr)
+#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.tiles, g.clamped, depth_keys, g.hdr)
     switch (raw.F) {
       case 0: TRASE_PRF(0); break;
       case 16: TRASE_PRF(16); break;

@@ -20,6 +20,7 @@ struct RenderArgs {
   // forward only: when set, the list still holds emit-order slots; the staging step translates them to Gaussian
   // ids (slot -> id is one more dependent load, hidden like the others) and records the ids for the backward
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
+  const uint32_t* hdr;
   int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
   float feat_bg;
 };
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
   for (int c = 0; c < F / 2; ++c) fa2[c] = f32x2{0.f, 0.f};
   // a finished pixel (outside the image, or transmittance exhausted) is encoded as live == 0
   float live = inside ? 1.0f : 0.0f;
+  const uint32_t jb = a.point_list_w ? a.hdr[HDR_PACK] : 0u;
   for (uint32_t base = range.x; base < range.y; base += WAVE) {
     if (!__any(live != 0.0f)) break;
     const uint32_t n = min((uint32_t)WAVE, range.y - base);
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(RB) void render_fwd_kernel(RenderArgs a, float* __r
       uint32_t id;
       if (a.point_list_w) {
         const uint32_t slot = a.pair_slot[base + lane];
-        id = a.pair_gauss[slot < a.cap ? slot : 0];
-        a.point_list_w[base + lane] = id;
+        id = jb ? (slot >> jb) : a.pair_gauss[slot < a.cap ? slot : 0];   // HDR_PACK: the id rides in the list value
+        if (!jb) a.point_list_w[base + lane] = id;
       } else {
         id = a.point_list[base + lane];
       }
@@ -162,6 +164,7 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
   fill_render_args(a, s, in, g, b);
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM);
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
+  a.hdr = g.hdr;
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip
   const int T = (a.ntiles + WPB - 1) / WPB;
   {

@@ -27,7 +27,8 @@ struct BwdGsArgs {
   const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
   const float* d_img; const float* d_feat; const float* d_depth;
   const float* final_T; const uint32_t* n_contrib;
-  const uint32_t* pair_slot;   // emit-order slot of every list entry
+  const uint32_t* pair_slot;   // emit-order slot of every list entry (or the packed value, HDR_PACK)
+  const uint32_t* hdr; const float4* geo;
   float* rows;         // (capacity, F+12) one gradient row per pair, indexed by slot
   uint8_t* row_flags;  // (capacity) 1 where a row was written (zeroed by the caller beforehand)
   int W, H, gx8, ntiles;
@@ -107,13 +108,15 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
   // ---- chunks of 64 list entries, back to front ----------------------------------------------------
   // Entries behind the last one any pixel of this sub-tile blended are never touched: they get no
   // row (their flag stays 0).  Chunks are aligned to that last blended entry.
+  const uint32_t jb = a.hdr[HDR_PACK];
   for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > WAVE) ? c1 - WAVE : 0) {
     const uint32_t c0 = (c1 > WAVE) ? c1 - WAVE : 0;
     const uint32_t n = c1 - c0;
     const bool lane_valid = (uint32_t)lane < n;
     const uint32_t pos = lane_valid ? (c1 - 1 - lane) : 0;     // lane 0 = farthest entry of the chunk
-    const uint32_t id = a.point_list[range.x + pos];
-    const uint32_t slot = a.pair_slot[range.x + pos];
+    const uint32_t lv = a.pair_slot[range.x + pos];
+    const uint32_t id = jb ? (lv >> jb) : a.point_list[range.x + pos];   // HDR_PACK: id and pair index in the list value
+    const uint32_t slot = jb ? __float_as_uint(a.geo[4 * (size_t)id].z) + (lv & ((1u << jb) - 1u)) : lv;
     constexpr int ROW = F + 12;
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
@@ -232,7 +235,7 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.rgbd = g.rgbd;
   a.feats = in.sh_objs; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
-  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.rows = rows; a.row_flags = row_flags;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.hdr = g.hdr; a.geo = g.geo; a.rows = rows; a.row_flags = row_flags;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }

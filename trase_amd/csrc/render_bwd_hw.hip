@@ -50,6 +50,8 @@ struct BwdHwArgs {
   const float* d_img; const float* d_feat; const float* d_depth;
   const float* final_T; const uint32_t* n_contrib;
   const uint32_t* pair_slot;
+  const uint32_t* hdr;   // HDR_PACK: pair_slot holds (id << jb) | pair index
+  const float4* geo;     // 64-byte geometry records (GeomBuf::geo): {x, y, first row slot, -}, conic_o, ...
   const __bf16* chan;  // [P][96]
   float* rows;         // (capacity, 44)
   uint8_t* row_flags;
@@ -240,12 +242,15 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   tick(0);
   // The list entries of a chunk are requested one chunk ahead (two registers): one level less in the dependent chain
   // entry -> geometry / channel rows at a chunk start.
+  // HDR_PACK (jb > 0): pair_slot holds (id << jb) | pair index; the row slot = the Gaussian's first slot (a word of
+  // its geometry record, fetched anyway) + that index.  point_list is not read (nor written by the forward) then.
+  const uint32_t jb = a.hdr[HDR_PACK];
   uint32_t id_n = 0, slot_n = 0xffffffffu;
   {
     const uint32_t n0 = min(wave_last, (uint32_t)HW_G);
     const bool v0 = (uint32_t)g < n0;
     const uint32_t p0 = v0 ? (wave_last - 1 - g) : 0;
-    if (wave_last > 0) { id_n = a.point_list[range.x + p0]; slot_n = v0 ? a.pair_slot[range.x + p0] : 0xffffffffu; }
+    if (wave_last > 0) { slot_n = a.pair_slot[range.x + p0]; if (!jb) id_n = a.point_list[range.x + p0]; }
   }
   // ---- chunks of 32 list entries, back to front ----------------------------------------------------
   for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > HW_G) ? c1 - HW_G : 0) {
@@ -254,16 +259,17 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const bool lane_valid = (uint32_t)g < n;
     if constexpr (COUNT) { cnt[0] += n; cnt[1] += 1; }
     const uint32_t pos = lane_valid ? (c1 - 1 - g) : 0;        // g = 0: farthest entry of the chunk
-    const uint32_t id = id_n;
-    const uint32_t slot = slot_n;
-    const float2 gxy = a.xy[id];
-    const float4 co = a.conic_o[id];
+    const uint32_t id = jb ? (slot_n >> jb) : id_n;
+    const float4 gq = a.geo[4 * (size_t)id];
+    const float4 co = a.geo[4 * (size_t)id + 1];
+    const float2 gxy = make_float2(gq.x, gq.y);
+    const uint32_t slot = !lane_valid ? 0xffffffffu : (jb ? __float_as_uint(gq.z) + (slot_n & ((1u << jb) - 1u)) : slot_n);
     if (c0 > 0) {                                              // next (nearer) chunk's entries
       const uint32_t c0n = (c0 > HW_G) ? c0 - HW_G : 0;
       const bool vn = (uint32_t)g < c0 - c0n;
       const uint32_t pn = vn ? (c0 - 1 - g) : 0;
-      id_n = a.point_list[range.x + pn];
-      slot_n = vn ? a.pair_slot[range.x + pn] : 0xffffffffu;
+      slot_n = a.pair_slot[range.x + pn];
+      if (!jb) id_n = a.point_list[range.x + pn];
     }
     const PairPoly k = pair_poly(gxy, co, bx, by);
     const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;
@@ -481,7 +487,7 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   }
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
-  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.hdr = g.hdr; a.geo = g.geo;
   a.chan = (const __bf16*)chan; a.rows = rows; a.row_flags = row_flags;
   a.prof = g.hdr + 32;                                   // header words 32..39: phase cycle counters of the TIMING build
   a.W = s.image_width; a.H = s.image_height;

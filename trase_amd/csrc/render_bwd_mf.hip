@@ -81,6 +81,7 @@ struct BwdMfArgs {
   const float* d_img; const float* d_feat; const float* d_depth;
   const float* final_T; const uint32_t* n_contrib;
   const uint32_t* pair_slot;
+  const uint32_t* hdr; const float4* geo;   // HDR_PACK: pair_slot holds (id << jb) | pair index; first row slot in geo
   const __bf16* chan;  // [P][96]
   float* rows;         // (capacity, 44)
   uint8_t* row_flags;
@@ -165,13 +166,16 @@ void render_bwd_mf_kernel(BwdMfArgs a) {
   // exist -- they are zero, read column 47 instead
   const int col0 = m, col1 = min(32 + m, MF_CH - 1);
   // ---- chunks of 64 list entries, back to front ----------------------------------------------------
+  const uint32_t jb = a.hdr[HDR_PACK];
   for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > WAVE) ? c1 - WAVE : 0) {
     const uint32_t c0 = (c1 > WAVE) ? c1 - WAVE : 0;
     const uint32_t n = c1 - c0;
     const bool lane_valid = (uint32_t)lane < n;
     const uint32_t pos = lane_valid ? (c1 - 1 - lane) : 0;     // lane 0 = farthest entry of the chunk
-    const uint32_t id = a.point_list[range.x + pos];
-    const uint32_t slot = lane_valid ? a.pair_slot[range.x + pos] : 0xffffffffu;
+    const uint32_t lv = a.pair_slot[range.x + pos];
+    const uint32_t id = jb ? (lv >> jb) : a.point_list[range.x + pos];   // HDR_PACK: id and pair index in the list value
+    const uint32_t slot = !lane_valid ? 0xffffffffu
+                                      : (jb ? __float_as_uint(a.geo[4 * (size_t)id].z) + (lv & ((1u << jb) - 1u)) : lv);
     const float2 gxy = a.xy[id];
     const float4 co = a.conic_o[id];
     const PairPoly k = pair_poly(gxy, co, bx, by);
@@ -380,7 +384,7 @@ int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   BwdMfArgs a;
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
-  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot;
+  a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.hdr = g.hdr; a.geo = g.geo;
   a.chan = (const __bf16*)chan; a.rows = rows; a.row_flags = row_flags;
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;

@@ -62,6 +62,8 @@ struct FwdMfArgs {
   const uint2* ranges; const uint32_t* point_list;
   const float2* xy; const float4* conic_o; const float4* rgbd; const float* feats; const float* bg;
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
+  const uint32_t* hdr;                 // HDR_PACK: the list values carry the Gaussian id in their upper bits
+  const float4* geo;                   // 64-byte geometry records (GeomBuf::geo)
   float* out_img; float* out_feat; float* out_depth; float* final_T; uint32_t* n_contrib;
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
@@ -136,6 +138,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   if (lane == 0) L.live[wv] = 1;
   wg_lds_barrier();
 
+  const uint32_t jb = a.point_list_w ? a.hdr[HDR_PACK] : 0u;
   for (uint32_t base = range.x; base < range.y; base += FM_G) {
     if (!(L.live[0] | L.live[1])) break;                 // workgroup-uniform: both waves read the same flags
     const uint32_t n = min((uint32_t)FM_G, range.y - base);
@@ -144,8 +147,12 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
     if ((uint32_t)lane < n) {
       if (a.point_list_w) {                              // the list still holds emit-order slots: translate, record
         const uint32_t slot = a.pair_slot[base + lane];
-        my_id = a.pair_gauss[slot < a.cap ? slot : 0];
-        if (wv == 0) a.point_list_w[base + lane] = my_id;
+        if (jb) {                                        // packed value: the id is a shift away, nothing to record
+          my_id = slot >> jb;
+        } else {
+          my_id = a.pair_gauss[slot < a.cap ? slot : 0];
+          if (wv == 0) a.point_list_w[base + lane] = my_id;
+        }
       } else {
         my_id = a.point_list[base + lane];
       }
@@ -160,7 +167,8 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
     }
     if (wv == 0) {                                       // exponent polynomials
       if ((uint32_t)lane < n) {
-        const PairPoly k = pair_poly(a.xy[my_id], a.conic_o[my_id], bx, by);
+        const float4 gq = a.geo[4 * (size_t)my_id];
+        const PairPoly k = pair_poly(make_float2(gq.x, gq.y), a.geo[4 * (size_t)my_id + 1], bx, by);
         L.k0[lane] = make_float4(k.k0, k.kj, k.ki, k.kjj);
         L.k1[lane] = make_float4(k.kii, k.kij, k.thr, 0.f);
       } else {
@@ -170,7 +178,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
       }
     } else {                                             // r g b depth -> tile rows 32..35; depth also as fp32
       float4 cd = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((uint32_t)lane < n) cd = a.rgbd[my_id];
+      if ((uint32_t)lane < n) cd = a.geo[4 * (size_t)my_id + 2];
       L.zs[lane] = cd.w;                                 // past the end of the list: 0 (its weight is 0 as well)
       if ((uint32_t)lane < n) {
       unsigned h01, l01, h23, l23;
@@ -343,6 +351,7 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.feats = in.sh_objs; a.bg = s.bg;
   a.pair_slot = nullptr; a.pair_gauss = nullptr; a.point_list_w = nullptr; a.cap = 0;
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
+  a.hdr = g.hdr; a.geo = g.geo;
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
