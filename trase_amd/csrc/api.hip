@@ -65,7 +65,7 @@ static inline int rs_blocks(size_t n) { return (int)((n + 256 * TRASE_RS_ITEMS -
 size_t geom_bytes(int P) {
   const size_t p = (size_t)P;
   return align_up(sizeof(uint32_t) * HDR_WORDS) + align_up(sizeof(float2) * p) + align_up(sizeof(float4) * p) * 2 +
-         align_up(sizeof(uint32_t) * p) * 2 + align_up(sizeof(float4) * 4 * p);
+         align_up(sizeof(uint32_t) * p) * 2 + align_up(sizeof(float4) * 4 * p) + align_up(sizeof(uint32_t) * 32 * p);
 }
 GeomBuf carve_geom(void* ptr, int P) {
   const size_t p = (size_t)P;
@@ -77,7 +77,8 @@ GeomBuf carve_geom(void* ptr, int P) {
   g.rgbd = (float4*)c; c += align_up(sizeof(float4) * p);
   g.tiles = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   g.clamped = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
-  g.geo = (float4*)c;
+  g.geo = (float4*)c; c += align_up(sizeof(float4) * 4 * p);
+  g.ftab = (uint32_t*)c;
   return g;
 }
 // ranges holds T sub-tiles + 1 sentinel ("trash") entry

@@ -284,7 +284,10 @@ struct GeomBuf {           // saved between forward and backward
   float4* rgbd;            // (P) colour + view depth
   uint32_t* tiles;         // (P) tiles touched (0 == culled)
   uint32_t* clamped;       // (P) colour clamp bits
-  float4* geo;             // (P, 4) one 64-byte record per Gaussian: {x, y, first row slot, -}, conic_o, rgbd, unused
+  float4* geo;             // (P, 4) one 64-byte record per Gaussian: {x, y, first row slot, -}, conic_o, rgbd,
+                           // rgbd as bf16 pairs {hi(r,g), hi(b,d), lo(r,g), lo(b,d)}
+  uint32_t* ftab;          // (P, 32) F = 32 only: the feature row as bf16 [hi 32 | lo 32] (x = hi + lo to ~2^-17): what the
+                           // MFMA compositing kernels multiply with -- split once per Gaussian, not once per pair
 };
 struct BinBuf {            // saved between forward and backward
   uint32_t* point_list;    // (capacity) Gaussian ids, sub-tile-major, depth-ordered
@@ -344,6 +347,20 @@ PairBuf carve_tmp(void* p, int64_t cap);
 // kernel launchers (one per .hip file)
 // ----------------------------------------------------------------------------------------------
 struct LaunchCtx { hipStream_t stream; int debug; int variant; };
+
+// (a, b) -> packed bf16 high parts and packed bf16 residuals (round to nearest even, twice)
+__device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
+}
+__device__ __forceinline__ float4 split_rgbd(float r, float g, float b, float d) {
+  unsigned h01, l01, h23, l23;
+  split_pk(r, g, h01, l01);
+  split_pk(b, d, h23, l23);
+  return make_float4(__uint_as_float(h01), __uint_as_float(h23), __uint_as_float(l01), __uint_as_float(l23));
+}
+int launch_feature_table(const LaunchCtx& c, const float* feats, const uint32_t* tiles, int P, uint32_t* ftab);
 
 int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
                           const GeomBuf& g, uint32_t* depth_keys);

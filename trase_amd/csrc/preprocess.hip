@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
     geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, 0.f);
     geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, opac);
     geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    geo[4 * (size_t)i + 3] = split_rgbd(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }
 }
@@ -133,6 +134,32 @@ int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const 
 #undef TRASE_PRE_FWD
   }
   TRASE_POST_LAUNCH("preprocess_fwd", c.stream, c.debug);
+  if (in.F == 32) return launch_feature_table(c, in.sh_objs, g.tiles, in.P, g.ftab);
+  return TRASE_OK;
+}
+
+// F = 32: feature rows -> bf16 [hi 32 | lo 32] (GeomBuf::ftab).  One thread per (Gaussian, four channels); the fused
+// (raw) preprocess writes the same table itself.
+__global__ __launch_bounds__(256) void feature_table_kernel(const float* __restrict__ feats, const uint32_t* __restrict__ tiles,
+                                                            int P, uint32_t* __restrict__ ftab) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * 8) return;
+  const int g = idx >> 3, l = idx & 7;
+  if (tiles[g] == 0) return;                                 // in no list: its row is never read
+  const float4 v = reinterpret_cast<const float4*>(feats + (size_t)g * 32)[l];
+  unsigned h01, l01, h23, l23;
+  split_pk(v.x, v.y, h01, l01);
+  split_pk(v.z, v.w, h23, l23);
+  *reinterpret_cast<uint2*>(ftab + (size_t)g * 32 + 2 * l) = make_uint2(h01, h23);
+  *reinterpret_cast<uint2*>(ftab + (size_t)g * 32 + 16 + 2 * l) = make_uint2(l01, l23);
+}
+int launch_feature_table(const LaunchCtx& c, const float* feats, const uint32_t* tiles, int P, uint32_t* ftab) {
+  if (P <= 0) return TRASE_OK;
+  {
+    ProfScope ps("feature_table", c.stream);
+    hipLaunchKernelGGL(feature_table_kernel, dim3((P * 8 + 255) / 256), dim3(256), 0, c.stream, feats, tiles, P, ftab);
+  }
+  TRASE_POST_LAUNCH("feature_table", c.stream, c.debug);
   return TRASE_OK;
 }
 

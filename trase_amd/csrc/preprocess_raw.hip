@@ -139,7 +139,8 @@ constexpr int RAW_BLOCK = 64;                                // one wave per wor
 template <int F>
 __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
                                                                  float2* __restrict__ xy, float4* __restrict__ conic_o,
-                                                                 float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ tiles,
+                                                                 float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ ftab,
+                                                                 uint32_t* __restrict__ tiles,
                                                                  uint32_t* __restrict__ clamped,
                                                                  uint32_t* __restrict__ depth_keys,
                                                                  uint32_t* __restrict__ hdr) {
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
     geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, 0.f);
     geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, act.opac);
     geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    geo[4 * (size_t)i + 3] = split_rgbd(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     clamped[i] = o.clamped;
   }
   // feature rows the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121).  F / 4 lanes per
@@ -214,9 +216,18 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
       if (LPG == 8) n2 += dpp_f<0x141>(n2);                   // row_half_mirror: the other quad of the 8-lane group
       const float sc = a.norm_features ? 1.0f / (sqrtf(n2) + 1e-9f) : 1.0f;
       const int gl = k * GPI + lane / LPG;
-      if (on[k])
-        reinterpret_cast<float4*>(a.featn + (size_t)(row0 + gl) * F)[lane % LPG] =
-            make_float4(r[k].x * sc, r[k].y * sc, r[k].z * sc, r[k].w * sc);
+      if (on[k]) {
+        const float4 v = make_float4(r[k].x * sc, r[k].y * sc, r[k].z * sc, r[k].w * sc);
+        reinterpret_cast<float4*>(a.featn + (size_t)(row0 + gl) * F)[lane % LPG] = v;
+        if constexpr (F == 32) {                              // the same row as bf16 [hi 32 | lo 32] (GeomBuf::ftab)
+          unsigned h01, l01, h23, l23;
+          split_pk(v.x, v.y, h01, l01);
+          split_pk(v.z, v.w, h23, l23);
+          uint32_t* const t = ftab + (size_t)(row0 + gl) * 32 + 2 * (lane % LPG);
+          *reinterpret_cast<uint2*>(t) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(t + 16) = make_uint2(l01, l23);
+        }
+      }
     }
   }
 }
@@ -235,7 +246,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   const dim3 grid((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), block(RAW_BLOCK);
   {
     ProfScope ps("preprocess_fwd", c.stream);
-#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.tiles, g.clamped, depth_keys, g.hdr)
+#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr)
     switch (raw.F) {
       case 0: TRASE_PRF(0); break;
       case 16: TRASE_PRF(16); break;

@@ -15,8 +15,10 @@
 //       - the accumulators of GEMM 2 are 2 x 16 registers instead of 4 x 16, those of GEMM 1 16 instead of 32:
 //         the kernel fits 128 VGPRs (four waves per SIMD instead of three).
 //   * the pixel-major cotangent image in LDS has pitch 40 bf16 (36 channels + 4 zeros): 11.25 KB per wave, two waves
-//     per workgroup -> 14 waves per CU.  K-step 2 of GEMM 1 reads eight columns past the row for h = 1; the channel
-//     table holds zeros there (split_channels_kernel), so the product is zero whatever finite values LDS returns.
+//     per workgroup -> 14 waves per CU.  K-step 2 of GEMM 1 reads eight columns past the row for h = 1; the B
+//     fragment is zero there (channels 40..47 do not exist), so the product is zero whatever finite values LDS returns.
+//   * the B fragments of GEMM 1 come pre-split from GeomBuf::ftab (features, bf16 [hi 32 | lo 32], one cache line) and the
+//     geometry record (colour + depth): two lines per list entry, no per-view channel-table pass.
 //
 // Row format and everything downstream (reduce_rows, preprocess_bwd) are unchanged.
 #include "common.h"
@@ -28,7 +30,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HW_WPB = 2;     // waves (sub-tiles) per workgroup
-constexpr int HW_CH = 48;     // channel-table row: [hi 48 | lo 48] bf16 (render_bwd_mf.hip split_channels_kernel)
 constexpr int HW_LD = 40;     // LDS row pitch in bf16 (80 B)
 constexpr int HW_G = 32;      // list entries per chunk
 
@@ -38,7 +39,7 @@ struct HwWaveLds {
   // (a separate 1 KB state array made it 11.25 KB = fourteen; the kernel is bound by latency at that residency):
   //   hi row p, columns 36..39 (8 bytes): T_end (transmittance behind the entries walked so far), U_end (fp32 bits)
   //   lo row p, columns 36..37 (4 bytes): n_contrib;  38..39: zero
-  // GEMM 1 would multiply them with the channel table's zeros -- raw fp32 bits are not finite bf16 -- so its last K-step
+  // GEMM 1 would multiply them with the B fragment's zeros -- raw fp32 bits are not finite bf16 -- so its last K-step
   // masks those two dwords of its A fragments; GEMM 2 only produces unused output rows from them.
   __bf16 hi[WAVE * HW_LD];
   __bf16 lo[WAVE * HW_LD];
@@ -52,7 +53,7 @@ struct BwdHwArgs {
   const uint32_t* pair_slot;
   const uint32_t* hdr;   // HDR_PACK: pair_slot holds (id << jb) | pair index
   const float4* geo;     // 64-byte geometry records (GeomBuf::geo): {x, y, first row slot, -}, conic_o, ...
-  const __bf16* chan;  // [P][96]
+  const uint32_t* ftab;  // feature rows as bf16 [hi 32 | lo 32] (GeomBuf::ftab)
   float* rows;         // (capacity, 44)
   uint8_t* row_flags;
   uint32_t* prof;      // 8 counters (TIMING builds) or null
@@ -273,7 +274,8 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     }
     const PairPoly k = pair_poly(gxy, co, bx, by);
     const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;
-    const __bf16* const crow = a.chan + (size_t)id * (2 * HW_CH) + 8 * h;   // this lane's B fragments of GEMM 1
+    const uint32_t* const frow = a.ftab + (size_t)id * 32 + 4 * h;   // this lane's B fragments of GEMM 1: bf16 [hi 32 | lo 32]
+    const float4 cs = a.geo[4 * (size_t)id + 3];                     // ... and colour + depth, split the same way
     tick(1);
     // Accumulators are never zero-filled: the first product of each takes a literal zero C operand (an inline constant
     // of the MFMA encoding), which saves 64 v_mov per chunk.
@@ -291,8 +293,15 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     if constexpr (!FEAT_ONLY) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(crow + ks * 16);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(crow + ks * 16 + HW_CH);
+        bf16x8 bh, bl;
+        if (ks < 2) {
+          bh = *reinterpret_cast<const bf16x8*>(frow + ks * 8);
+          bl = *reinterpret_cast<const bf16x8*>(frow + ks * 8 + 16);
+        } else {                                         // channels 32..35 = r g b depth in the h = 0 half, zeros elsewhere
+          const u32x4 ch4 = {h ? 0u : __float_as_uint(cs.x), h ? 0u : __float_as_uint(cs.y), 0u, 0u};
+          const u32x4 cl4 = {h ? 0u : __float_as_uint(cs.z), h ? 0u : __float_as_uint(cs.w), 0u, 0u};
+          bh = __builtin_bit_cast(bf16x8, ch4); bl = __builtin_bit_cast(bf16x8, cl4);
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           bf16x8 ph, pl;
@@ -301,7 +310,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             pl = *reinterpret_cast<const bf16x8*>(alo + (mb * 32 + g) * HW_LD + ks * 16 + 8 * h);
           } else {
             // channels 32..39 (h = 0: the state dwords are masked) / 40..47 (h = 1: the next pixel row's first eight columns,
-            // multiplied by the channel table's zeros; the last row of the image reads its own first columns instead)
+            // multiplied by the B fragment's zeros; the last row of the image reads its own first columns instead)
             const int off = (mb == 1 && lane == 63) ? 63 * HW_LD : (mb * 32 + g) * HW_LD + 32 + 8 * h;
             u32x4 rh4 = *reinterpret_cast<const u32x4*>(ahi + off), rl4 = *reinterpret_cast<const u32x4*>(alo + off);
             rh4[2] &= hmask; rh4[3] &= hmask; rl4[2] &= hmask; rl4[3] &= hmask;
@@ -488,13 +497,13 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.ranges = bb.ranges; a.point_list = bb.point_list; a.xy = g.xy; a.conic_o = g.conic_o; a.bg = s.bg;
   a.d_img = gr.dL_dimage; a.d_feat = gr.dL_dfeats; a.d_depth = gr.dL_ddepth;
   a.final_T = im.final_T; a.n_contrib = im.n_contrib; a.pair_slot = bb.pair_slot; a.hdr = g.hdr; a.geo = g.geo;
-  a.chan = (const __bf16*)chan; a.rows = rows; a.row_flags = row_flags;
+  a.ftab = g.ftab; a.rows = rows; a.row_flags = row_flags;
   a.prof = g.hdr + 32;                                   // header words 32..39: phase cycle counters of the TIMING build
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
-  int rc = launch_split_channels(c, in, g, chan, row_flags, flag_bytes);
-  if (rc) return rc;
+  (void)chan;                                            // (the channel table of the 64-entry-chunk kernel: not used here)
+  TRASE_CHECK(hipMemsetAsync(row_flags, 0, flag_bytes, c.stream));
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the flags are cleared)
   {
     ProfScope ps("render_bwd", c.stream);

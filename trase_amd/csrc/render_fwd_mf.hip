@@ -64,6 +64,7 @@ struct FwdMfArgs {
   const uint32_t* pair_slot; const uint32_t* pair_gauss; uint32_t* point_list_w; uint32_t cap;
   const uint32_t* hdr;                 // HDR_PACK: the list values carry the Gaussian id in their upper bits
   const float4* geo;                   // 64-byte geometry records (GeomBuf::geo)
+  const uint32_t* ftab;                // feature rows as bf16 [hi 32 | lo 32] (GeomBuf::ftab)
   float* out_img; float* out_feat; float* out_depth; float* final_T; uint32_t* n_contrib;
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
@@ -77,12 +78,6 @@ __device__ __forceinline__ void wg_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// (a, b) -> packed bf16 high parts and packed bf16 residuals
-__device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigned& lo) {
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
-}
 
 // B fragment (eight consecutive entries of this lane's channel) from the [entry][channel] tile: two transposing reads
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -159,11 +154,15 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
     }
     // feature rows: 16 rows per instruction and workgroup (eight lanes, 16 bytes each, per row); wave wv takes rows
     // 8wv .. 8wv+7 of each 16
-    float4 fr[FM_G / 16];
+    // (rows of the bf16 table GeomBuf::ftab, [hi 32 | lo 32]: lanes 0..3 of a row fetch the hi parts of channels
+    // 8 (lane & 3) .. + 7, lanes 4..7 the lo parts)
+    uint4 fr[FM_G / 16];
 #pragma unroll
     for (int r = 0; r < FM_G / 16; ++r) {
       const uint32_t rid = (uint32_t)__shfl((int)my_id, 16 * r + 8 * wv + (lane >> 3));
-      fr[r] = *reinterpret_cast<const float4*>(a.feats + (size_t)rid * F + 4 * (lane & 7));
+      // past the end of the list: zeros (weight 0 times a stale or never-written row could be 0 * NaN)
+      fr[r] = make_uint4(0u, 0u, 0u, 0u);
+      if ((uint32_t)(16 * r + 8 * wv + (lane >> 3)) < n) fr[r] = reinterpret_cast<const uint4*>(a.ftab)[(size_t)rid * 8 + (lane & 7)];
     }
     if (wv == 0) {                                       // exponent polynomials
       if ((uint32_t)lane < n) {
@@ -177,25 +176,19 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
         L.k1[lane] = make_float4(0.f, 0.f, -INFINITY, 0.f);
       }
     } else {                                             // r g b depth -> tile rows 32..35; depth also as fp32
-      float4 cd = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((uint32_t)lane < n) cd = a.geo[4 * (size_t)my_id + 2];
-      L.zs[lane] = cd.w;                                 // past the end of the list: 0 (its weight is 0 as well)
+      float z = 0.f;                                     // past the end of the list: 0 (its weight is 0 as well)
       if ((uint32_t)lane < n) {
-      unsigned h01, l01, h23, l23;
-      split_pk(cd.x, cd.y, h01, l01);
-      split_pk(cd.z, cd.w, h23, l23);
-      *reinterpret_cast<uint2*>(L.hi + lane * FM_P + 32) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(L.lo + lane * FM_P + 32) = make_uint2(l01, l23);
+        z = reinterpret_cast<const float*>(a.geo)[16 * (size_t)my_id + 11];
+        const float4 cs = a.geo[4 * (size_t)my_id + 3];  // the colour + depth already split (preprocess)
+        *reinterpret_cast<uint2*>(L.hi + lane * FM_P + 32) = make_uint2(__float_as_uint(cs.x), __float_as_uint(cs.y));
+        *reinterpret_cast<uint2*>(L.lo + lane * FM_P + 32) = make_uint2(__float_as_uint(cs.z), __float_as_uint(cs.w));
       }
+      L.zs[lane] = z;
     }
 #pragma unroll
-    for (int r = 0; r < FM_G / 16; ++r) {                // tile[entry 16r + 8wv + (lane >> 3)][channels 4 (lane & 7) .. + 3]
-      unsigned h01, l01, h23, l23;
-      split_pk(fr[r].x, fr[r].y, h01, l01);
-      split_pk(fr[r].z, fr[r].w, h23, l23);
-      const int o = (16 * r + 8 * wv + (lane >> 3)) * FM_P + 4 * (lane & 7);
-      *reinterpret_cast<uint2*>(L.hi + o) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(L.lo + o) = make_uint2(l01, l23);
+    for (int r = 0; r < FM_G / 16; ++r) {                // tile[entry 16r + 8wv + (lane >> 3)][channels 8 (lane & 3) .. + 7]
+      const int o = (16 * r + 8 * wv + (lane >> 3)) * FM_P + 8 * (lane & 3);
+      *reinterpret_cast<uint4*>(((lane & 4) ? L.lo : L.hi) + o) = fr[r];
     }
     wg_lds_barrier();
     // ---- K-steps of 16 entries ---------------------------------------------------------------------------------
@@ -351,7 +344,7 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.feats = in.sh_objs; a.bg = s.bg;
   a.pair_slot = nullptr; a.pair_gauss = nullptr; a.point_list_w = nullptr; a.cap = 0;
   if (pair_gauss) { a.pair_slot = b.pair_slot; a.pair_gauss = pair_gauss; a.point_list_w = b.point_list; a.cap = cap; }
-  a.hdr = g.hdr; a.geo = g.geo;
+  a.hdr = g.hdr; a.geo = g.geo; a.ftab = g.ftab;
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
