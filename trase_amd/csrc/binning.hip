@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
       float4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        v[u] = (col && b[u] >= 0) ? base[(size_t)b[u] * (bwd_row_stride(F) / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = (col && b[u] >= 0) ? ld_stream(base + (size_t)b[u] * (bwd_row_stride(F) / 4)) : make_float4(0.f, 0.f, 0.f, 0.f);   // read once
 #pragma unroll
       for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
     }
