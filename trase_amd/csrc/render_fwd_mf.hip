@@ -51,8 +51,10 @@ constexpr int FM_P = 48;          // tile row pitch in bf16: 32 features, r g b 
 struct FmLds {
   __bf16 hi[FM_G * FM_P];         // [entry][channel]: staged with 8-byte row-contiguous stores, read back TRANSPOSED
   __bf16 lo[FM_G * FM_P];
-  float4 k0[FM_G];                // k0, kj, ki, kjj
-  float4 k1[FM_G];                // kii, kij, thr, -
+  // exponent polynomials, one 64-byte record per PAIR of entries (a = 2p, b = 2p + 1):
+  //   k0a k0b kja kjb | kia kib kjja kjjb | kiia kiib kija kijb | thra thrb - -
+  // so that a K-step evaluates two entries per v_pk_fma_f32 without any register shuffling
+  float kp[FM_G / 2][16];
   float zs[FM_G];                 // view depth of the chunk's entries: the depth map is accumulated in fp32 (see below)
   float tfin[2][32];              // final_T of the two pixel blocks (epilogue)
   int live[2];                    // "some pixel of wave w is still live"
@@ -72,6 +74,19 @@ struct FwdMfArgs {
   int lineage;           // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
   float feat_bg;
 };
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+// d = a.lo * x + y  /  d = a.hi * x + y  on both halves of (x, y): v_pk_fma_f32 with a broadcast first operand
+__device__ __forceinline__ f2v pk_fma_b0(f2v a, f2v x, f2v y) {
+  f2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(x), "v"(y));
+  return d;
+}
+__device__ __forceinline__ f2v pk_fma_b1(f2v a, f2v x, f2v y) {
+  f2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(x), "v"(y));
+  return d;
+}
 
 // LDS handed between the two waves of the workgroup: LDS-only barrier (no vmcnt drain: stores / loads stay in flight)
 __device__ __forceinline__ void wg_lds_barrier() {
@@ -111,6 +126,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   // this lane's pixel: row 4 wv + (m >> 3), column m & 7
   const int pi = 4 * wv + (m >> 3), pj = m & 7;
   const float fj = (float)pj, fi = (float)pi, fii = (float)(pi * pi);
+  const f2v FI2 = {fi, fii}, FJ2 = {fj, 0.f};            // broadcast operands of the packed polynomial evaluation
   const bool inside = (tx * SUB + pj) < a.W && (ty * SUB + pi) < a.H;
   // zero the tile once: channels 36..47 are never written again
   {
@@ -168,12 +184,12 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
       if ((uint32_t)lane < n) {
         const float4 gq = a.geo[4 * (size_t)my_id];
         const PairPoly k = pair_poly(make_float2(gq.x, gq.y), a.geo[4 * (size_t)my_id + 1], bx, by);
-        L.k0[lane] = make_float4(k.k0, k.kj, k.ki, k.kjj);
-        L.k1[lane] = make_float4(k.kii, k.kij, k.thr, 0.f);
+        float* const rec = &L.kp[lane >> 1][lane & 1];
+        rec[0] = k.k0; rec[2] = k.kj; rec[4] = k.ki; rec[6] = k.kjj; rec[8] = k.kii; rec[10] = k.kij; rec[12] = k.thr;
       } else {
         // past the end of the list: a closed gate (e <= -inf never holds); the tile keeps stale finite values, weight 0
-        L.k0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        L.k1[lane] = make_float4(0.f, 0.f, -INFINITY, 0.f);
+        float* const rec = &L.kp[lane >> 1][lane & 1];
+        rec[0] = 0.f; rec[2] = 0.f; rec[4] = 0.f; rec[6] = 0.f; rec[8] = 0.f; rec[10] = 0.f; rec[12] = -INFINITY;
       }
     } else {                                             // r g b depth -> tile rows 32..35; depth also as fp32
       float z = 0.f;                                     // past the end of the list: 0 (its weight is 0 as well)
@@ -200,16 +216,25 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
         float Pu[8];
         float P = 1.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float4 q0 = L.k0[e0 + u];
-          const float4 q1 = L.k1[e0 + u];
-          PairPoly k;
-          k.k0 = q0.x; k.kj = q0.y; k.ki = q0.z; k.kjj = q0.w; k.kii = q1.x; k.kij = q1.y; k.thr = q1.z;
-          const float ex = poly_eval(k, poly_row_base(k, fi, fii), poly_row_slope(k, fi), fj);
-          const bool gate = (ex <= k.thr) && (ex >= LOG2_ALPHA_MIN);
-          const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(gate ? ex : -INFINITY));   // closed gate: 0
-          P = fmaf(-alpha, P, P);
-          Pu[u] = P;
+        for (int u = 0; u < 8; u += 2) {
+          // two entries per packed FMA; per component the same fmaf tree as poly_row_base / poly_row_slope / poly_eval
+          // (common.h), so the gates agree bit for bit with the backward's
+          const f4v* const rec = reinterpret_cast<const f4v*>(&L.kp[(e0 + u) >> 1][0]);
+          const f4v r0 = rec[0], r1 = rec[1], r2 = rec[2];
+          const f2v thr2 = *reinterpret_cast<const f2v*>(&rec[3]);
+          f2v bs = pk_fma_b0(FI2, __builtin_shufflevector(r1, r1, 0, 1), __builtin_shufflevector(r0, r0, 0, 1));   // i ki + k0
+          bs = pk_fma_b1(FI2, __builtin_shufflevector(r2, r2, 0, 1), bs);                                          // + ii kii
+          const f2v sl = pk_fma_b0(FI2, __builtin_shufflevector(r2, r2, 2, 3), __builtin_shufflevector(r0, r0, 2, 3));   // i kij + kj
+          const f2v in = pk_fma_b0(FJ2, __builtin_shufflevector(r1, r1, 2, 3), sl);                                 // j kjj + slope
+          const f2v ex2 = pk_fma_b0(FJ2, in, bs);                                                                  // j (.) + base
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const float ex = ex2[v];
+            const bool gate = (ex <= thr2[v]) && (ex >= LOG2_ALPHA_MIN);
+            const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(gate ? ex : -INFINITY));   // closed gate: 0
+            P = fmaf(-alpha, P, P);
+            Pu[u + v] = P;
+          }
         }
         // totals of the two halves: Q0 (entries 0..7), Q1 (entries 8..15)
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(P), __float_as_uint(P), false, false);
