@@ -18,6 +18,7 @@ struct RawFwdArgs {
   const float* xyz; const float* d_xyz; const float* f_dc; const float* f_rest; const float* opacity;
   const float* scaling; const float* d_scaling; const float* rotation; const float* d_rotation;
   const float* features; float* featn;
+  int write_featn;        // 0: nobody reads the fp32 rows (F = 32 default kernels read the bf16 table): skip the 128-byte store
   const float* vm; const float* pm; const float* cam;
   int P, F, deg, W, H, norm_features;
   float tanx, tany, mod;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
       const int gl = k * GPI + lane / LPG;
       if (on[k]) {
         const float4 v = make_float4(r[k].x * sc, r[k].y * sc, r[k].z * sc, r[k].w * sc);
-        reinterpret_cast<float4*>(a.featn + (size_t)(row0 + gl) * F)[lane % LPG] = v;
+        if (F != 32 || a.write_featn) reinterpret_cast<float4*>(a.featn + (size_t)(row0 + gl) * F)[lane % LPG] = v;
         if constexpr (F == 32) {                              // the same row as bf16 [hi 32 | lo 32] (GeomBuf::ftab)
           unsigned h01, l01, h23, l23;
           split_pk(v.x, v.y, h01, l01);
@@ -238,6 +239,9 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
   a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
   a.features = raw.gaussian_features; a.featn = raw.featn;
+  // the fp32 normalised rows are read by the VALU forward (0x2000) and by the first-generation / VALU / 64-entry backward
+  // kernels (0x1, 0x40, 0x800) only
+  a.write_featn = (c.variant & (0x1 | 0x40 | 0x800 | 0x2000)) != 0;
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
@@ -352,6 +356,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   if (p_end < 0) p_end = raw.P;
   if (p_end <= p_begin) return TRASE_OK;
   RawFwdArgs a;
+  a.write_featn = 0;
   a.p_begin = p_begin; a.p_end = p_end;
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
   a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
