@@ -33,7 +33,8 @@ g_img = (torch.randn(3, a.height, a.width, generator=g) / P).to(dev)
 g_feat = (torch.randn(32, a.height, a.width, generator=g) / P).to(dev)
 R.set_sync(True)
 R.set_variant(0x8000)
-names = ["entries", "chunks", "steps_run", "steps_skipped", "slots_real", "slots_pass_exponent_gates", "slots_blended"]
+names = ["entries", "chunks", "steps_run", "steps_skipped", "slots_real", "slots_pass_exponent_gates", "slots_blended",
+         "walked_pairs_nobody_blended"]
 tot = dict.fromkeys(names, 0)
 pairs = 0
 for k in range(a.views):
@@ -56,6 +57,7 @@ res["share_blended_of_real"] = res["slots_blended"] / max(res["slots_real"], 1)
 res["lane_utilisation"] = res["slots_blended"] / max(res["slots_evaluated_incl_tail_lanes"], 1)
 res["steps_skipped_share"] = res["steps_skipped"] / max(res["steps_run"] + res["steps_skipped"], 1)
 res["entries_walked_over_pairs"] = res["entries"] / max(res["subtile_pairs"], 1)
+res["rows_not_written_share_of_walked"] = res["walked_pairs_nobody_blended"] / max(res["entries"], 1)
 res["workload"] = f"{a.gaussians} Gaussians {a.width}x{a.height} F=32 scale_mult {a.scale_mult}, {a.views} views"
 js = json.dumps(res, indent=1)
 print(js)

@@ -119,6 +119,7 @@ __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ co
 //   44 (pixel, Gaussian) lane slots of executed steps that hold a real list entry
 //   45 ... of those, slots that pass the two exponent gates (power <= 0, alpha >= 1/255)
 //   46 ... of those, slots that are blended (also in front of the pixel's last contributor)
+//   47 walked (sub-tile, Gaussian) pairs that no pixel blended: their gradient row would be all zeros and is not written
 // The same fragment through the transposing LDS read of gfx950 (ds_read_b64_tr_b16): within a 16-lane group, lane
 // i = 4 jj + cc hands in the address of four consecutive channels (chunk cc) of pixel row jj, and lane c receives element
 // c % 4 of the chunks cc = c / 4 of the rows jj = 0..3 -- i.e. channel c of four pixels: one instruction instead of four
@@ -159,7 +160,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   uint64_t t_mark = 0, t_acc[5] = {0, 0, 0, 0, 0};
   auto tick = [&](int k) { if constexpr (TIMING) { const uint64_t t = __builtin_readcyclecounter(); t_acc[k] += t - t_mark; t_mark = t; } };
   if constexpr (TIMING) t_mark = __builtin_readcyclecounter();
-  uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // ---- stage this sub-tile's per-pixel data (lane = pixel here) ---------------------------------
   uint32_t last;
   {
@@ -280,6 +281,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     // Accumulators are never zero-filled: the first product of each takes a literal zero C operand (an inline constant
     // of the MFMA encoding), which saves 64 v_mov per chunk.
     const f32x16 ZERO16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool blended = false;                                // some pixel of this lane's columns blended this Gaussian
     f32x16 D[2];                                         // D[channel block]: rows = channels, columns = Gaussians
     if constexpr (FEAT_ONLY) D[1] = ZERO16;              // never accumulated there; its four sums are written as zeros
     // moment sums with the LOCAL column index jl = 0..3 of this lane half (global column j = 4h + jl): the row sums are
@@ -349,6 +351,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             const float eb = poly_eval(k, base, slope, jv[r + 1]);
             const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
             const bool okb = (eb <= k.thr) && (eb >= LOG2_ALPHA_MIN) && (pos_cmp < lastb);
+            blended = blended || oka || okb;
             if constexpr (COUNT) {
               cnt[4] += 2 * (uint32_t)__builtin_popcountll(__ballot(lane_valid));
               cnt[5] += (uint32_t)__builtin_popcountll(__ballot(lane_valid && (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN))) +
@@ -432,7 +435,16 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
       return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     };
-    if (slot != 0xffffffffu) {
+    // a pair that no pixel of the sub-tile blended (every gate closed: the 8x8 culling is conservative, and entries can lie
+    // behind all last contributors of their own pixels) has an all-zero row: neither row nor flag is written, reduce_rows
+    // never reads it.  The two lane halves hold the same Gaussians and different pixel columns.
+    bool write_row;
+    {
+      const unsigned long long bm = __ballot(blended);
+      write_row = slot != 0xffffffffu && (((bm | (bm >> 32)) >> g) & 1ull);
+      if constexpr (COUNT) cnt[7] += (uint32_t)__builtin_popcountll(__ballot(slot != 0xffffffffu && h == 0 && !write_row));
+    }
+    if (write_row) {
       float* row = a.rows + (size_t)slot * bwd_row_stride(F);
       // D[0]: lane (g,h), register 4q + r = channel 8q + 4h + r
 #pragma unroll
@@ -448,7 +460,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       Sij = fmaf(h4, Si, Sij);
       S0 = both(S0); Sj = both(Sj); Si = both(Si); Sjj = both(Sjj); Sij = both(Sij); Sii = both(Sii);
     }
-    if (slot != 0xffffffffu && h == 0) {
+    if (write_row && h == 0) {
       float* row = a.rows + (size_t)slot * bwd_row_stride(F) + F;
       // moments about the sub-tile origin -> sums over dx = rx - j, dy = ry - i
       const float rx = gxy.x - bx, ry = gxy.y - by;
@@ -472,7 +484,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   if constexpr (COUNT) {
     if (lane == 0 && a.prof) {
 #pragma unroll
-      for (int k2 = 0; k2 < 7; ++k2) atomicAdd(a.prof + 8 + k2, cnt[k2]);
+      for (int k2 = 0; k2 < 8; ++k2) atomicAdd(a.prof + 8 + k2, cnt[k2]);
     }
   }
   if constexpr (TIMING) {
