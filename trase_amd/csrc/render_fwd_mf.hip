@@ -150,14 +150,20 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   wg_lds_barrier();
 
   const uint32_t jb = a.point_list_w ? a.hdr[HDR_PACK] : 0u;
+  // the list values of a chunk are requested one chunk ahead (one register): the staging step sits on the critical path of
+  // the workgroup -- both waves wait at its barrier -- and this takes one of its two dependent load levels off it
+  const uint32_t* const lv_src = a.point_list_w ? a.pair_slot : a.point_list;
+  uint32_t lv_next = (range.x + (uint32_t)lane < range.y) ? lv_src[range.x + lane] : 0u;
   for (uint32_t base = range.x; base < range.y; base += FM_G) {
     if (!(L.live[0] | L.live[1])) break;                 // workgroup-uniform: both waves read the same flags
     const uint32_t n = min((uint32_t)FM_G, range.y - base);
     // ---- stage the chunk: lane e = list entry (both waves fetch the ids; each does half of the rest) --------------
     uint32_t my_id = 0;
+    const uint32_t lv = lv_next;
+    lv_next = (base + FM_G + (uint32_t)lane < range.y) ? lv_src[base + FM_G + lane] : 0u;
     if ((uint32_t)lane < n) {
       if (a.point_list_w) {                              // the list still holds emit-order slots: translate, record
-        const uint32_t slot = a.pair_slot[base + lane];
+        const uint32_t slot = lv;
         if (jb) {                                        // packed value: the id is a shift away, nothing to record
           my_id = slot >> jb;
         } else {
@@ -165,7 +171,7 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
           if (wv == 0) a.point_list_w[base + lane] = my_id;
         }
       } else {
-        my_id = a.point_list[base + lane];
+        my_id = lv;
       }
     }
     // feature rows: 16 rows per instruction and workgroup (eight lanes, 16 bytes each, per row); wave wv takes rows
