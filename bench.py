@@ -320,12 +320,15 @@ def main():
                     R.set_sync(False, capacity=int(max(caps) * 1.3) + 1024)
                     for i in range(2):
                         step_tiles(i, rows=rows)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for i in range(args.steps):
-                        step_tiles(i, rows=rows)
-                    torch.cuda.synchronize()
-                    dst.append(round((time.perf_counter() - t0) / args.steps * 1e3, 4))
+                    best = float("inf")
+                    for _ in range(3):               # best of three: a transient on the box otherwise decides the max over strips
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for i in range(args.steps):
+                            step_tiles(i, rows=rows)
+                        torch.cuda.synchronize()
+                        best = min(best, (time.perf_counter() - t0) / args.steps * 1e3)
+                    dst.append(round(best, 4))
                     if label == "balanced":
                         rec["pairs"].append(int(sum(caps) / len(caps)))
             rec["max_ms"], rec["equal_rows_max_ms"] = max(rec["ms"]), max(rec["equal_rows_ms"])
