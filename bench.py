@@ -331,6 +331,13 @@ def main():
                     dst.append(round(best, 4))
                     if label == "balanced":
                         rec["pairs"].append(int(sum(caps) / len(caps)))
+                        if rows == pp[0]:            # where a strip's time goes: HIP-event profile of rank 0's strip
+                            R.profile_enable(1)
+                            for i in range(4):
+                                step_tiles(i, rows=rows)
+                            torch.cuda.synchronize()
+                            rec["kernels_ms_rank0"] = {k: round(v["ms"] * v["n"] / 4, 4) for k, v in R.profile_report().items()}
+                            R.profile_enable(0)
             rec["max_ms"], rec["equal_rows_max_ms"] = max(rec["ms"]), max(rec["equal_rows_ms"])
             table["world"][str(wsize)] = rec
             log(f"world {wsize}: strip ms {rec['ms']} (equal rows: {rec['equal_rows_ms']})")
