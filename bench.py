@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--cpu-oracle-budget-s", type=float, default=1.0, help="forward wall-time budget of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core (os.cpu_count())")
     ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
+    ap.add_argument("--policy", choices=["free", "sync"], default="free",
+                    help="capacity policy of the timed steps: free = set_sync(False) with a measured capacity (default, what the "
+                         "metric is quoted on); sync = the drop-in default (pair count read back every forward, exact allocation)")
     ap.add_argument("--graph", action="store_true",
                     help="launch-graph replay of the forward / backward launch sequences (trase_amd.rasterizer.set_graph): for the "
                          "small BASELINE configurations, which are host-bound otherwise")
@@ -357,7 +360,8 @@ def main():
         reff_list.append(st_[2])     # (8x8 sub-tile, Gaussian) pairs actually binned after exact culling
     r_max, r_mean = max(r_list), sum(r_list) / len(r_list)
     reff_mean = sum(reff_list) / len(reff_list)
-    R.set_sync(False, capacity=int(max(reff_list) * 1.25) + 1024)
+    if args.policy == "free":
+        R.set_sync(False, capacity=int(max(reff_list) * 1.25) + 1024)
     log(f"pairs per view: lineage R mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f}); binned sub-tile pairs mean {reff_mean:.0f}")
 
     if args.graph:
@@ -450,7 +454,7 @@ def main():
                                       "partial gradients all-reduced" if tiles_mode else ""),
                        "pairs_R_mean": round(r_mean), "pairs_R_max": r_max, "R_over_N": round(r_mean / N, 2),
                        "subtile_pairs_mean": round(reff_mean),
-                       "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant,
+                       "tiles": ((W + 15) // 16) * ((H + 15) // 16), "variant": R._Policy.variant, "capacity_policy": args.policy,
                        "graph_replay": (R.graph_stats() if args.graph else None),
                        "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
                                 else "gaussian_renderer.render() drop-in, A1 prep fused",
