@@ -386,23 +386,8 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
   if (threadIdx.x == 0) hdr[HDR_PACK] = (pack_bits > 0 && sh[0] < (1u << pack_bits)) ? (uint32_t)pack_bits : 0u;
 }
 
-__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t* __restrict__ offsets, int P,
-                                                                const uint32_t* __restrict__ block_sums,
-                                                                const uint32_t* __restrict__ ids,
-                                                                uint32_t* __restrict__ id_end) {
-  const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-  const uint32_t add = block_sums[blockIdx.x];
-#pragma unroll
-  for (int i = 0; i < SC_ITEMS; ++i) {
-    const int r = base + i;
-    if (r < P) {
-      const uint32_t e = offsets[r] + add;
-      offsets[r] = e;
-      id_end[ids[r]] = e;        // the per-Gaussian tail of the backward walks ids, not depth ranks
-    }
-  }
-}
-
+// (the third step of the scan -- adding a block's exclusive prefix to its offsets and recording every Gaussian's end slot -- is
+// done by emit_pairs, which reads each offset exactly once anyway: one launch less)
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
                       const int32_t* radii, int gx, int gy, int pack_bits) {
   const int nblocks = (P + SC_TILE - 1) / SC_TILE;
@@ -414,8 +399,6 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
                        t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R, block_max);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R,
                        block_max, pack_bits);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, t.offsets, P, t.block_sums, sorted_ids,
-                       t.id_end);
   }
   TRASE_POST_LAUNCH("scan_tiles", c.stream, c.debug);
   return TRASE_OK;
@@ -439,7 +422,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ pair_gauss,
                                                          uint32_t cap, uint32_t* __restrict__ hdr, uint32_t trash_key,
                                                          uint2* __restrict__ ranges, int sy_lo, int sy_hi,
-                                                         uint32_t* __restrict__ vals, uint32_t* __restrict__ geo_words) {
+                                                         uint32_t* __restrict__ vals, uint32_t* __restrict__ geo_words,
+                                                         const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ id_end) {
   // list value of a pair (what the sub-tile sort carries): its emit-order slot, or -- HDR_PACK -- (id << jb) | index among
   // the Gaussian's own pairs, from which the compositing kernels get the id with a shift instead of a load
   const uint32_t jb = hdr[HDR_PACK];
@@ -455,7 +439,10 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   const bool in = r < P;
   const uint32_t id = in ? sorted_ids[r] : 0;
   const uint32_t nt = in ? tiles[id] : 0;
-  const uint32_t end = in ? offsets[r] : 0;           // this Gaussian owns exactly [end - nt, end) -- never more, never less
+  // this Gaussian owns exactly [end - nt, end) -- never more, never less.  offsets[] holds block-local inclusive sums
+  // (scan_partial_kernel); the block's exclusive prefix is added here and in reduce_rows, the per-id end slots are recorded here.
+  const uint32_t end = in ? offsets[r] + block_sums[r / SC_TILE] : 0;
+  if (in && q == 0) id_end[id] = end;   // (offsets[] itself stays as it is: stage 2 may be repeated on one stage 1)
   const uint32_t off0 = end - nt;
   const int gx8 = (W + SUB - 1) / SUB;
   float2 p = make_float2(0.f, 0.f);
@@ -544,7 +531,7 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((4 * P + 255) / 256), dim3(256), 0, c.stream, sorted_ids, P, t.offsets, g.xy,
                        g.conic_o, radii, g.tiles, s.image_width, s.image_height, gx, gy, keys, pair_gauss, cap, g.hdr,
                        (uint32_t)(((s.image_width + SUB - 1) / SUB) * ((s.image_height + SUB - 1) / SUB)), ranges_to_clear,
-                       sy_lo, sy_hi, vals, (uint32_t*)g.geo);
+                       sy_lo, sy_hi, vals, (uint32_t*)g.geo, t.block_sums, t.id_end);
   }
   TRASE_POST_LAUNCH("emit_pairs", c.stream, c.debug);
   return TRASE_OK;
@@ -586,7 +573,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const float* __restrict__ rows,
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
                                                           float* __restrict__ d_feats,
-                                                          const float* __restrict__ raw_feats, int norm_features) {
+                                                          const float* __restrict__ raw_feats, int norm_features,
+                                                          const uint32_t* __restrict__ block_sums) {
   constexpr int F = ROW - 12, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
@@ -598,7 +586,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
   uint32_t k0 = 0, k1 = 0;
   if (live) {
     const uint32_t nt = tiles[id];
-    k1 = offsets[r];
+    k1 = offsets[r] + (BY_ID ? 0u : block_sums[r / SC_TILE]);   // depth-rank offsets are block-local sums (scan_partial_kernel)
     k0 = k1 - nt;
     const uint32_t cap = hdr[HDR_WORDS - 2];        // capacity the lists were built with
     if (k1 > cap) k1 = cap;                         // pairs dropped by an overflow have no row
@@ -677,10 +665,10 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
   do {                                                                                                                        \
     if (by_id)                                                                                                                \
       hipLaunchKernelGGL((reduce_rows_kernel<ROW, true>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
-                         g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features);               \
+                         g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums);   \
     else                                                                                                                      \
       hipLaunchKernelGGL((reduce_rows_kernel<ROW, false>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
-                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features);  \
+                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums);  \
   } while (0)
     switch (F) {
       case 0: TRASE_RR(12); break;
