@@ -310,6 +310,46 @@ __device__ __forceinline__ void store_transposed(__bf16* __restrict__ img_tile, 
   }
 }
 
+// The same image from the LDS activation tile (block kernels): the tile holds [row][column] with 8-byte runs of four columns;
+// gfx950's transposing read (ds_read_b64_tr_b16: inside a 16-lane group lane 4 jj + cc hands in the address of four columns
+// -- chunk cc -- of row jj and lane c receives column c of the four rows) IS the 4 x 4 transpose that the DPP rounds above do
+// with ~14 VALU instructions per piece -- measured: those, not the store traffic, were what kept the training forward at
+// 0.56 ms against 0.33 for inference.  One call moves a 16-row x 16-column patch: lane (grp, i) ends up with column c0 + i of
+// the rows r0 + 4 grp .. + 3, i.e. 8 contiguous image bytes, and the wave's store covers one 512-byte run.
+// rows_valid: rows of the patch that exist (< 16 only in the last tile of the batch: the rest is written as zeros).
+struct PatchLane {        // lane constants of store_patch_transposed (wave block at tile rows lrow0 ..)
+  int lds_elem;           // (lrow0 + 4 grp + jj) * MW + 4 (cc & 1): tile offset without the swizzled chunk term
+  int sw, cch;            // swizzle key of the lane's row, chunk half of the lane's column group
+  int img_elem;           // i * 16 + 4 grp: image offset inside a 16-row x 16-column patch
+  int row4;               // 4 grp
+};
+__device__ __forceinline__ PatchLane patch_lane(int lrow0) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, i = lane & 15, jj = i >> 2, cc = i & 3;
+  PatchLane p;
+  p.lds_elem = (lrow0 + 4 * grp + jj) * MW + 4 * (cc & 1);
+  p.sw = (4 * grp + jj) & 15;                   // lrow0 and r0 are multiples of 16
+  p.cch = cc >> 1;
+  p.img_elem = i * 16 + 4 * grp;
+  p.row4 = 4 * grp;
+  return p;
+}
+// r0, c0: patch origin inside the wave's block (uniform); img_patch: UNIFORM address of the patch's first column in the image
+// (tile base + (row_in_tile >> 4) * MW * 16 + c0 * 16): the store then takes it as a scalar base and the lane offset as is
+__device__ __forceinline__ void store_patch_transposed(const __bf16* __restrict__ act, const PatchLane& pl, int r0, int c0,
+                                                       __bf16* __restrict__ img_patch, int rows_valid) {
+  typedef short s16x4_ __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+  const int chunk = ((c0 >> 3) + pl.cch) ^ pl.sw;
+  s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(act + (pl.lds_elem + r0 * MW + (chunk << 3))));
+  if (rows_valid < 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (pl.row4 + e < rows_valid) ? v[e] : (short)0;
+  }
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v o2 = __builtin_bit_cast(u2v, v);
+  __builtin_nontemporal_store(o2, reinterpret_cast<u2v*>(img_patch + pl.img_elem));
+}
+
 // SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations
 // (input of the next layer's weight-gradient GEMM) and the ReLU gate as one bit per (row, feature)
 template <bool SAVE>
@@ -500,6 +540,21 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
     sb0 = *reinterpret_cast<const uint4*>(src); sb1 = *reinterpret_cast<const uint4*>(src + 8);
     sa0 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16); sa1 = *reinterpret_cast<const uint4*>(src + (size_t)MW * 16 + 8);
   }
+  // SAVE: the transposed image of a layer's activations is NOT stored in that layer's epilogue -- loads and stores share
+  // vmcnt, in order, so the burst of 32 stores per wave stalled the next layer's second weight slab until it had drained
+  // (0.56 ms against 0.33 for inference = exactly the store time).  The tile stays in LDS as the next layer's A operand;
+  // the wave re-reads its own 32 pieces from there, four per K-step pair, while the next layer multiplies.
+  const PatchLane pl = patch_lane(lrow0);
+  const int u_row0 = __builtin_amdgcn_readfirstlane(row0), u_wc = __builtin_amdgcn_readfirstlane(wc);   // wave-uniform: scalar registers
+  auto drain = [&](int l_prev, int piece) {
+    const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;    // 16-row x 16-column patch of this wave's block
+    const int growb = u_row0 + r0;
+    if ((growb & ~31) < N) {                                                  // the 32-row image tile exists
+      __bf16* const patch = actsT + ((size_t)l_prev * ((N + 31) >> 5) + (growb >> 5)) * (MW * 32) +
+                            (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16;
+      store_patch_transposed(act, pl, r0, c0, patch, min(max(N - growb, 0), 16));
+    }
+  };
   for (int l = 0; l < MD; ++l) {
     const bool has_emb = (l == 0 || l == SKIP);
     const int emb_k = has_emb ? EMBP / 16 : 0;
@@ -580,12 +635,16 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
         a1[g] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, (ks + 1 - emb_k) * 16 + 8 * h));
       }
       kpair(ks, a0, a1);
+      if constexpr (SAVE) {                                  // (l >= 1 here: layer 0 has no K-steps of this kind)
+        const int p0 = ((ks - emb_k) >> 1) * (BRG * 16 / (MW / 32));
+#pragma unroll
+        for (int j = 0; j < BRG * 16 / (MW / 32); ++j) drain(l - 1, p0 + j);
+      }
     }
     // epilogue: ReLU, bf16, this wave's 64 x 128 block of the tile (all reads of the old tile are behind the last barrier)
 #pragma unroll
     for (int g = 0; g < BRG; ++g) {
       const int grow = row0 + 32 * g + m;
-      __bf16* const tileT = SAVE ? actsT + ((size_t)l * ((N + 31) >> 5) + ((row0 + 32 * g) >> 5)) * (MW * 32) : nullptr;
       unsigned gate[2] = {0u, 0u};                           // SAVE: this lane's 64 ReLU gates of the layer
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
@@ -599,13 +658,16 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
           if constexpr (SAVE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gate[nb >> 1] |= (pk[e] & 0x7fff) ? 1u << ((nb & 1) * 16 + q * 4 + e) : 0u;
-            if ((row0 + 32 * g) < N) store_transposed(tileT, f0, m, grow < N ? pk : s16x4{0, 0, 0, 0});   // padding rows: zeros
           }
         }
       if constexpr (SAVE)      // the row's 256 gate bits are two uint4 (h = 0 / 1); this wave owns words 2 wc, 2 wc + 1 of each
         if (grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
     }
     lds_barrier();             // the tile is complete; the image stores and the next layer's slab loads stay in flight
+  }
+  if constexpr (SAVE) {
+#pragma unroll 4
+    for (int piece = 0; piece < BRG * 16; ++piece) drain(MD - 1, piece);
   }
   if (wc != 0) return;                                       // heads: one wave per 64 rows
   f32x16 hacc[BRG];
@@ -753,6 +815,8 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
   const int wr = wave & 1, wc = wave >> 1;
   const int lrow0 = wr * (BRG * MROWS);
   const int row0 = blockIdx.x * BROWS + lrow0;
+  const PatchLane pl = patch_lane(lrow0);
+  const int u_row0 = __builtin_amdgcn_readfirstlane(row0), u_wc = __builtin_amdgcn_readfirstlane(wave >> 1);
   const int tiles = (N + 31) >> 5;
   const int sn = threadIdx.x;
   // slabs 0 and 1 of the first hidden stage (l = MD - 1) are requested before the head stage
@@ -853,7 +917,6 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
     for (int gi = 0; gi < BRG; ++gi) {
       const uint2 gv = *reinterpret_cast<const uint2*>(gates + (((size_t)(l - 1) * N + gmr[gi]) * 2 + h) * 4 + wc * 2);
       const unsigned gate[2] = {gv.x, gv.y};
-      __bf16* const tileT = dzT + ((size_t)(l - 1) * tiles + ((row0 + 32 * gi) >> 5)) * (MW * 32);
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -864,8 +927,18 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
 #pragma unroll
           for (int e = 0; e < 4; ++e) pk[e] = (bits >> e & 1u) ? bf16_bits(acc[gi][nb][4 * q + e]) : (short)0;
           *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * gi + m, f0)) = pk;
-          if (row0 + 32 * gi < N) store_transposed(tileT, f0, m, pk);
         }
+    }
+    // the image of this wave's 64 x 128 block, from the tile it has just written (its own region: an LDS wait is enough)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 4
+    for (int piece = 0; piece < 32; ++piece) {
+      const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;
+      const int growb = u_row0 + r0;
+      if ((growb & ~31) < N)
+        store_patch_transposed(act, pl, r0, c0, dzT + ((size_t)(l - 1) * tiles + (growb >> 5)) * (MW * 32) +
+                                                    (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16,
+                               min(max(N - growb, 0), 16));
     }
     lds_barrier();
   }
