@@ -280,6 +280,31 @@ __device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0
 // operands.)  The chain kernels hold lane = row, registers = columns: a 4x4 transpose inside every lane quad (two DPP
 // exchange rounds) turns "4 columns of my row" into "4 rows of my column"; one store instruction of the wave covers
 // 8 columns x 32 rows = two contiguous runs of 256 bytes.
+// ReLU + bf16 of four accumulator values as packed 16-bit work: convert two floats per instruction, then max(x, 0) on the bf16
+// patterns read as signed 16-bit integers (negative floats and -0 are negative integers; positive patterns are unchanged) --
+// the same values as bf16(max(x, 0)), 4 instructions instead of 6, and never a -0
+__device__ __forceinline__ s16x4 relu_bf16x4(float a, float b, float c, float d) {
+  unsigned lo, hi;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(c), "v"(d));
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(lo) : "v"(lo));
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(hi) : "v"(hi));
+  typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+  const u2v_ r = {lo, hi};
+  return __builtin_bit_cast(s16x4, r);
+}
+// the four ReLU gates (value != 0; relu_bf16x4 leaves no -0) of such a group as bits 0..3: a packed unsigned minimum with 1
+// turns each half-word into 0 / 1, two shifts and ors gather the four -- 6 instructions instead of ~16
+__device__ __forceinline__ unsigned gate_bits4(s16x4 pk) {
+  typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+  const u2v_ u = __builtin_bit_cast(u2v_, pk);
+  unsigned lo, hi;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(lo) : "v"(u.x), "s"(0x00010001u));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(hi) : "v"(u.y), "s"(0x00010001u));
+  unsigned x = lo | (hi << 2);                    // bits 0, 16 (e0, e1), 2, 18 (e2, e3)
+  x |= x >> 15;                                   // bit 1 = e1, bit 3 = e3
+  return x & 15u;
+}
 __device__ __forceinline__ size_t timg_off(int M, int col, int row) {
   return (size_t)(row >> 4) * (size_t)(M * 16) + (size_t)col * 16 + (size_t)(row & 15);
 }
@@ -651,14 +676,9 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f0 = wc * 128 + nb * 32 + 8 * q + 4 * h;
-          s16x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = bf16_bits(fmaxf(acc[g][nb][4 * q + e], 0.f));
+          const s16x4 pk = relu_bf16x4(acc[g][nb][4 * q], acc[g][nb][4 * q + 1], acc[g][nb][4 * q + 2], acc[g][nb][4 * q + 3]);
           *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * g + m, f0)) = pk;
-          if constexpr (SAVE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gate[nb >> 1] |= (pk[e] & 0x7fff) ? 1u << ((nb & 1) * 16 + q * 4 + e) : 0u;
-          }
+          if constexpr (SAVE) gate[nb >> 1] |= gate_bits4(pk) << ((nb & 1) * 16 + q * 4);
         }
       if constexpr (SAVE)      // the row's 256 gate bits are two uint4 (h = 0 / 1); this wave owns words 2 wc, 2 wc + 1 of each
         if (grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
