@@ -305,6 +305,20 @@ __device__ __forceinline__ unsigned gate_bits4(s16x4 pk) {
   x |= x >> 15;                                   // bit 1 = e1, bit 3 = e3
   return x & 15u;
 }
+// dZ = dH . gate for four values: two packed conversions, then an AND with half-word masks expanded from the four gate bits
+// (sign-extended one-bit fields) -- the same values as selecting per element
+__device__ __forceinline__ s16x4 gated_bf16x4(float a, float b, float c, float d, unsigned bits) {
+  unsigned lo, hi;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(c), "v"(d));
+  const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+  const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+  lo &= (m0 & 0xffffu) | (m1 & 0xffff0000u);
+  hi &= (m2 & 0xffffu) | (m3 & 0xffff0000u);
+  typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+  const u2v_ r = {lo, hi};
+  return __builtin_bit_cast(s16x4, r);
+}
 __device__ __forceinline__ size_t timg_off(int M, int col, int row) {
   return (size_t)(row >> 4) * (size_t)(M * 16) + (size_t)col * 16 + (size_t)(row & 15);
 }
@@ -943,9 +957,7 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
         for (int q = 0; q < 4; ++q) {
           const int f0 = wc * 128 + nb * 32 + 8 * q + 4 * h;
           const unsigned bits = live[gi] ? gate[nb >> 1] >> ((nb & 1) * 16 + q * 4) : 0u;
-          s16x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = (bits >> e & 1u) ? bf16_bits(acc[gi][nb][4 * q + e]) : (short)0;
+          const s16x4 pk = gated_bf16x4(acc[gi][nb][4 * q], acc[gi][nb][4 * q + 1], acc[gi][nb][4 * q + 2], acc[gi][nb][4 * q + 3], bits);
           *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * gi + m, f0)) = pk;
         }
     }
