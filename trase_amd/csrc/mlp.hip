@@ -374,12 +374,13 @@ __device__ __forceinline__ PatchLane patch_lane(int lrow0) {
 }
 // r0, c0: patch origin inside the wave's block (uniform); img_patch: UNIFORM address of the patch's first column in the image
 // (tile base + (row_in_tile >> 4) * MW * 16 + c0 * 16): the store then takes it as a scalar base and the lane offset as is
-__device__ __forceinline__ void store_patch_transposed(const __bf16* __restrict__ act, const PatchLane& pl, int r0, int c0,
-                                                       __bf16* __restrict__ img_patch, int rows_valid) {
-  typedef short s16x4_ __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+typedef short s16x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4p patch_read(const __bf16* __restrict__ act, const PatchLane& pl, int r0, int c0) {
+  typedef __attribute__((address_space(3))) s16x4p lds_s16x4;
   const int chunk = ((c0 >> 3) + pl.cch) ^ pl.sw;
-  s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(act + (pl.lds_elem + r0 * MW + (chunk << 3))));
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(act + (pl.lds_elem + r0 * MW + (chunk << 3))));
+}
+__device__ __forceinline__ void patch_store(s16x4p v, const PatchLane& pl, __bf16* __restrict__ img_patch, int rows_valid) {
   if (rows_valid < 16) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (pl.row4 + e < rows_valid) ? v[e] : (short)0;
@@ -585,13 +586,18 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
   // the wave re-reads its own 32 pieces from there, four per K-step pair, while the next layer multiplies.
   const PatchLane pl = patch_lane(lrow0);
   const int u_row0 = __builtin_amdgcn_readfirstlane(row0), u_wc = __builtin_amdgcn_readfirstlane(wc);   // wave-uniform: scalar registers
-  auto drain = [&](int l_prev, int piece) {
+  // (reads and stores of a group of pieces are issued apart -- the reads before a K-step pair, the stores after it: a store
+  // right behind its read waits out the LDS latency 32 times per layer)
+  auto drain_read = [&](int piece) {
+    return patch_read(act, pl, (piece >> 3) * 16, u_wc * 128 + (piece & 7) * 16);
+  };
+  auto drain_store = [&](int l_prev, int piece, s16x4p v) {
     const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;    // 16-row x 16-column patch of this wave's block
     const int growb = u_row0 + r0;
     if ((growb & ~31) < N) {                                                  // the 32-row image tile exists
       __bf16* const patch = actsT + ((size_t)l_prev * ((N + 31) >> 5) + (growb >> 5)) * (MW * 32) +
                             (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16;
-      store_patch_transposed(act, pl, r0, c0, patch, min(max(N - growb, 0), 16));
+      patch_store(v, pl, patch, min(max(N - growb, 0), 16));
     }
   };
   for (int l = 0; l < MD; ++l) {
@@ -673,11 +679,17 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
         a0[g] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, (ks - emb_k) * 16 + 8 * h));
         a1[g] = *reinterpret_cast<const bf16x8*>(act + act_off(lrow0 + 32 * g + m, (ks + 1 - emb_k) * 16 + 8 * h));
       }
-      kpair(ks, a0, a1);
+      constexpr int DP = BRG * 16 / (MW / 32);             // image pieces of the previous layer per K-step pair (4)
+      const int p0 = ((ks - emb_k) >> 1) * DP;
+      s16x4p dv[DP];
       if constexpr (SAVE) {                                  // (l >= 1 here: layer 0 has no K-steps of this kind)
-        const int p0 = ((ks - emb_k) >> 1) * (BRG * 16 / (MW / 32));
 #pragma unroll
-        for (int j = 0; j < BRG * 16 / (MW / 32); ++j) drain(l - 1, p0 + j);
+        for (int j = 0; j < DP; ++j) dv[j] = drain_read(p0 + j);
+      }
+      kpair(ks, a0, a1);
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) drain_store(l - 1, p0 + j, dv[j]);
       }
     }
     // epilogue: ReLU, bf16, this wave's 64 x 128 block of the tile (all reads of the old tile are behind the last barrier)
@@ -700,8 +712,13 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
     lds_barrier();             // the tile is complete; the image stores and the next layer's slab loads stay in flight
   }
   if constexpr (SAVE) {
-#pragma unroll 4
-    for (int piece = 0; piece < BRG * 16; ++piece) drain(MD - 1, piece);
+    for (int p0 = 0; p0 < BRG * 16; p0 += 8) {
+      s16x4p dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dv[j] = drain_read(p0 + j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) drain_store(MD - 1, p0 + j, dv[j]);
+    }
   }
   if (wc != 0) return;                                       // heads: one wave per 64 rows
   f32x16 hacc[BRG];
@@ -963,14 +980,18 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
     }
     // the image of this wave's 64 x 128 block, from the tile it has just written (its own region: an LDS wait is enough)
     __builtin_amdgcn_s_waitcnt(0xC07F);
-#pragma unroll 4
-    for (int piece = 0; piece < 32; ++piece) {
-      const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;
-      const int growb = u_row0 + r0;
-      if ((growb & ~31) < N)
-        store_patch_transposed(act, pl, r0, c0, dzT + ((size_t)(l - 1) * tiles + (growb >> 5)) * (MW * 32) +
-                                                    (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16,
-                               min(max(N - growb, 0), 16));
+    for (int p0 = 0; p0 < 32; p0 += 8) {                   // eight reads in flight, then their stores
+      s16x4p dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dv[j] = patch_read(act, pl, ((p0 + j) >> 3) * 16, u_wc * 128 + ((p0 + j) & 7) * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r0 = ((p0 + j) >> 3) * 16, c0 = u_wc * 128 + ((p0 + j) & 7) * 16;
+        const int growb = u_row0 + r0;
+        if ((growb & ~31) < N)
+          patch_store(dv[j], pl, dzT + ((size_t)(l - 1) * tiles + (growb >> 5)) * (MW * 32) +
+                                  (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16, min(max(N - growb, 0), 16));
+      }
     }
     lds_barrier();
   }
