@@ -641,10 +641,11 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
       }
     };
     // a pair of K-steps (ks even): the loop is written two steps at a time so that sa / sb are static registers
-    auto kpair = [&](int ks, const bf16x8 (&a0)[BRG], const bf16x8 (&a1)[BRG]) {
+    auto kpair = [&](int ks, const bf16x8 (&a0)[BRG], const bf16x8 (&a1)[BRG], auto&& between) {
       slab_load(ks + 2, sb0, sb1);
       mma(0, a0);
-      slab_park(1, sa0, sa1);                                // slab ks+1
+      between();                                             // (SAVE: image stores -- early in the pair, so that the slab
+      slab_park(1, sa0, sa1);                                // loads issued after them have ~1.5 pairs to get past them)
       lds_barrier();
       slab_load(ks + 3, sa0, sa1);
       mma(1, a1);
@@ -669,7 +670,7 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
 #pragma unroll
       for (int ks = 0; ks < EMBP / 16; ks += 2) {
         const bf16x8 a0[BRG] = {pe_frag(ks, 0), pe_frag(ks, 1)}, a1[BRG] = {pe_frag(ks + 1, 0), pe_frag(ks + 1, 1)};
-        kpair(ks, a0, a1);
+        kpair(ks, a0, a1, [] {});
       }
     }
     for (int ks = emb_k; ks < steps; ks += 2) {
@@ -686,11 +687,12 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
 #pragma unroll
         for (int j = 0; j < DP; ++j) dv[j] = drain_read(p0 + j);
       }
-      kpair(ks, a0, a1);
-      if constexpr (SAVE) {
+      kpair(ks, a0, a1, [&] {
+        if constexpr (SAVE) {
 #pragma unroll
-        for (int j = 0; j < DP; ++j) drain_store(l - 1, p0 + j, dv[j]);
-      }
+          for (int j = 0; j < DP; ++j) drain_store(l - 1, p0 + j, dv[j]);
+        }
+      });
     }
     // epilogue: ReLU, bf16, this wave's 64 x 128 block of the tile (all reads of the old tile are behind the last barrier)
 #pragma unroll
