@@ -910,7 +910,20 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
       }
     }
   }
+  auto dz_read = [&](int piece) { return patch_read(act, pl, (piece >> 3) * 16, u_wc * 128 + (piece & 7) * 16); };
+  auto dz_store = [&](int img, int piece, s16x4p v) {
+    const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;
+    const int growb = u_row0 + r0;
+    if ((growb & ~31) < N)
+      patch_store(v, pl, dzT + ((size_t)img * tiles + (growb >> 5)) * (MW * 32) + (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16,
+                  min(max(N - growb, 0), 16));
+  };
   for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
+    // this stage's ReLU gates (recorded by the forward) are requested now and used in the epilogue
+    uint2 gv[BRG];
+#pragma unroll
+    for (int gi = 0; gi < BRG; ++gi)
+      gv[gi] = *reinterpret_cast<const uint2*>(gates + (((size_t)(l - 1) * N + gmr[gi]) * 2 + h) * 4 + wc * 2);
     f32x16 acc[BRG][4];
 #pragma unroll
     for (int gi = 0; gi < BRG; ++gi)
@@ -968,8 +981,7 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
     // epilogue: ReLU gate recorded by the forward, bf16, LDS tile for the next stage + transposed image
 #pragma unroll
     for (int gi = 0; gi < BRG; ++gi) {
-      const uint2 gv = *reinterpret_cast<const uint2*>(gates + (((size_t)(l - 1) * N + gmr[gi]) * 2 + h) * 4 + wc * 2);
-      const unsigned gate[2] = {gv.x, gv.y};
+      const unsigned gate[2] = {gv[gi].x, gv[gi].y};
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -980,20 +992,16 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
           *reinterpret_cast<s16x4*>(act + act_off(lrow0 + 32 * gi + m, f0)) = pk;
         }
     }
-    // the image of this wave's 64 x 128 block, from the tile it has just written (its own region: an LDS wait is enough)
+    // the image of this wave's 64 x 128 block, from the tile it has just written (its own region: an LDS wait is enough).
+    // (Spreading these stores over the next stage's K-steps, as the training forward does, needs registers this kernel does not
+    // have: 272 bytes of scratch.)
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    for (int p0 = 0; p0 < 32; p0 += 8) {                   // eight reads in flight, then their stores
+    for (int p0 = 0; p0 < 32; p0 += 8) {                     // eight reads in flight, then their stores
       s16x4p dv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dv[j] = patch_read(act, pl, ((p0 + j) >> 3) * 16, u_wc * 128 + ((p0 + j) & 7) * 16);
+      for (int j = 0; j < 8; ++j) dv[j] = dz_read(p0 + j);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r0 = ((p0 + j) >> 3) * 16, c0 = u_wc * 128 + ((p0 + j) & 7) * 16;
-        const int growb = u_row0 + r0;
-        if ((growb & ~31) < N)
-          patch_store(dv[j], pl, dzT + ((size_t)(l - 1) * tiles + (growb >> 5)) * (MW * 32) +
-                                  (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16, min(max(N - growb, 0), 16));
-      }
+      for (int j = 0; j < 8; ++j) dz_store(l - 1, p0 + j, dv[j]);
     }
     lds_barrier();
   }
