@@ -254,6 +254,25 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const uint32_t p0 = v0 ? (wave_last - 1 - g) : 0;
     if (wave_last > 0) { slot_n = a.pair_slot[range.x + p0]; if (!jb) id_n = a.point_list[range.x + p0]; }
   }
+  // A chunk's gradient rows are stored at the START of the next chunk, right behind that chunk's per-entry loads: loads and
+  // stores retire through one in-order counter, and loads issued behind eight row stores wait for the stores'
+  // acknowledgements before their data counts as arrived.
+  struct PendingRow { uint32_t slot; bool write; float4 d[4]; float4 m[3]; };
+  PendingRow pend;
+  pend.slot = 0xffffffffu; pend.write = false;
+  auto store_pending = [&]() {
+    if (pend.write) {
+      float* row = a.rows + (size_t)pend.slot * bwd_row_stride(F);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = pend.d[q];
+      if (h == 0) {
+        *reinterpret_cast<float4*>(row + F) = pend.m[0];
+        *reinterpret_cast<float4*>(row + F + 4) = pend.m[1];
+        *reinterpret_cast<float4*>(row + F + 8) = pend.m[2];
+        a.row_flags[pend.slot] = 1;
+      }
+    }
+  };
   // ---- chunks of 32 list entries, back to front ----------------------------------------------------
   for (uint32_t c1 = wave_last; c1 > 0; c1 = (c1 > HW_G) ? c1 - HW_G : 0) {
     const uint32_t c0 = (c1 > HW_G) ? c1 - HW_G : 0;
@@ -277,6 +296,15 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const uint32_t pos_cmp = lane_valid ? pos : 0xffffffffu;
     const uint32_t* const frow = a.ftab + (size_t)id * 32 + 4 * h;   // this lane's B fragments of GEMM 1: bf16 [hi 32 | lo 32]
     const float4 cs = a.geo[4 * (size_t)id + 3];                     // ... and colour + depth, split the same way
+    bf16x8 fbh[2], fbl[2];                                           // (requested here, ahead of the pending row stores)
+    if constexpr (!FEAT_ONLY) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        fbh[ks] = *reinterpret_cast<const bf16x8*>(frow + ks * 8);
+        fbl[ks] = *reinterpret_cast<const bf16x8*>(frow + ks * 8 + 16);
+      }
+    }
+    store_pending();                                                 // the previous chunk's rows
     tick(1);
     // Accumulators are never zero-filled: the first product of each takes a literal zero C operand (an inline constant
     // of the MFMA encoding), which saves 64 v_mov per chunk.
@@ -297,8 +325,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       for (int ks = 0; ks < 3; ++ks) {
         bf16x8 bh, bl;
         if (ks < 2) {
-          bh = *reinterpret_cast<const bf16x8*>(frow + ks * 8);
-          bl = *reinterpret_cast<const bf16x8*>(frow + ks * 8 + 16);
+          bh = fbh[ks]; bl = fbl[ks];
         } else {                                         // channels 32..35 = r g b depth in the h = 0 half, zeros elsewhere
           const u32x4 ch4 = {h ? 0u : __float_as_uint(cs.x), h ? 0u : __float_as_uint(cs.y), 0u, 0u};
           const u32x4 cl4 = {h ? 0u : __float_as_uint(cs.z), h ? 0u : __float_as_uint(cs.w), 0u, 0u};
@@ -444,13 +471,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       write_row = slot != 0xffffffffu && (((bm | (bm >> 32)) >> g) & 1ull);
       if constexpr (COUNT) cnt[7] += (uint32_t)__builtin_popcountll(__ballot(slot != 0xffffffffu && h == 0 && !write_row));
     }
-    if (write_row) {
-      float* row = a.rows + (size_t)slot * bwd_row_stride(F);
-      // D[0]: lane (g,h), register 4q + r = channel 8q + 4h + r
+    pend.slot = slot; pend.write = write_row;
+    // D[0]: lane (g,h), register 4q + r = channel 8q + 4h + r
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
-    }
+    for (int q = 0; q < 4; ++q) pend.d[q] = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
     if constexpr (!FEAT_ONLY) {
       // local -> global column index (j = 4h + jl):  sum q j = Sj + 4h S0,  sum q j^2 = Sjj + 8h Sj + 16 h^2 S0,
       // sum q i j = Sij + 4h Si   (h = 0: unchanged)
@@ -460,8 +484,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       Sij = fmaf(h4, Si, Sij);
       S0 = both(S0); Sj = both(Sj); Si = both(Si); Sjj = both(Sjj); Sij = both(Sij); Sii = both(Sii);
     }
-    if (write_row && h == 0) {
-      float* row = a.rows + (size_t)slot * bwd_row_stride(F) + F;
+    {
       // moments about the sub-tile origin -> sums over dx = rx - j, dy = ry - i
       const float rx = gxy.x - bx, ry = gxy.y - by;
       const float Qx = rx * S0 - Sj, Qy = ry * S0 - Si;
@@ -472,15 +495,15 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
       const float a_ny = -(co.z * Qy + co.y * Qx);
       const float a_ca = -0.5f * Qxx, a_cb = -Qxy, a_cc = -0.5f * Qyy;
       const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
-      *reinterpret_cast<float4*>(row) = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
+      pend.m[0] = make_float4(a_nx * ddx, a_ny * ddy, a_ca, a_cb);
       // channels 32..35 (r g b depth sums): registers 0..3 of channel block 1 in the h = 0 half
-      *reinterpret_cast<float4*>(row + 4) = make_float4(a_cc, a_op, D[1][0], D[1][1]);
-      *reinterpret_cast<float4*>(row + 8) = make_float4(D[1][2], D[1][3], 0.f, 0.f);
-      a.row_flags[slot] = 1;
+      pend.m[1] = make_float4(a_cc, a_op, D[1][0], D[1][1]);
+      pend.m[2] = make_float4(D[1][2], D[1][3], 0.f, 0.f);
     }
     wave_lds_sync_hw();                                   // carries written by lanes 31 / 63 are read by the next chunk
     tick(0);
   }
+  store_pending();                                        // the last chunk's rows
   if constexpr (COUNT) {
     if (lane == 0 && a.prof) {
 #pragma unroll
