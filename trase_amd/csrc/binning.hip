@@ -442,7 +442,6 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   // this Gaussian owns exactly [end - nt, end) -- never more, never less.  offsets[] holds block-local inclusive sums
   // (scan_partial_kernel); the block's exclusive prefix is added here and in reduce_rows, the per-id end slots are recorded here.
   const uint32_t end = in ? offsets[r] + block_sums[r / SC_TILE] : 0;
-  if (in && q == 0) id_end[id] = end;   // (offsets[] itself stays as it is: stage 2 may be repeated on one stage 1)
   const uint32_t off0 = end - nt;
   const int gx8 = (W + SUB - 1) / SUB;
   float2 p = make_float2(0.f, 0.f);
@@ -453,6 +452,9 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
     tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
     if (q == 0) geo_words[16 * (size_t)id + 2] = off0;        // first row slot, next to the geometry the backward fetches
   }
+  // (behind the loads above: a store ahead of them would have them wait for its acknowledgement.  offsets[] itself stays as it
+  // is: stage 2 may be repeated on one stage 1)
+  if (in && q == 0) id_end[id] = end;
   const bool big = nt > EMIT_BIG;
   if (nt && !big) {
     const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
