@@ -43,11 +43,19 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
   // Keys arrive in runs (consecutive pairs of one Gaussian share the high bits of the sub-tile id):
   // aggregate runs inside the wave so that a 64-lane run costs one LDS atomic instead of 64 serialized ones.
   const unsigned lane = threadIdx.x & 63;
+  // all keys of the thread are requested before any is used: with the load inside the loop the compiler waits for each one in
+  // turn (the LDS atomics in between pin the order) -- eight dependent round trips per workgroup instead of one
+  uint32_t kk[RS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+    kk[i] = idx < n ? keys[idx] : 0u;
+  }
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
     const bool valid = idx < n;
-    const uint32_t dg = valid ? ((keys[idx] >> shift) & mask) : 0xffffffffu;
+    const uint32_t dg = valid ? ((kk[i] >> shift) & mask) : 0xffffffffu;
     const uint32_t prev = (uint32_t)__shfl_up((int)dg, 1);
     const bool start = valid && (lane == 0 || prev != dg);
     const unsigned long long starts = __ballot(start);
@@ -149,12 +157,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   uint32_t k[RS_ITEMS], v[RS_ITEMS], rk[RS_ITEMS];
   const unsigned long long lt = lanemask_lt();
   volatile uint32_t* cnt = wcount[wave];
+  // (thread d: the global total of digit d and this workgroup's offset inside it -- requested now, used after the ranking)
+  const uint32_t my_digit_total = digit_total[threadIdx.x];
+  const uint32_t my_hist = hist[(size_t)threadIdx.x * nb_max + blockIdx.x];
+  // every key and value of the thread is requested up front: inside the ranking loop (volatile LDS counters, wave barriers)
+  // the compiler waited for each round's pair of loads before ranking it -- eight dependent round trips per workgroup
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
     const bool valid = idx < n;
     k[i] = valid ? keys_in[idx] : 0xffffffffu;
     v[i] = valid ? (IOTA ? idx : vals_in[idx]) : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
+    const bool valid = idx < n;
     const uint32_t dg = (k[i] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
     const uint32_t dg0 = __builtin_amdgcn_readfirstlane(dg);
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       tot += wcount[w][d];
     }
     scan_tmp[d] = tot;
-    scan_dig[d] = digit_total[d];
+    scan_dig[d] = my_digit_total;
   }
   __syncthreads();
   {   // two exclusive scans over the digits: this block's counts -> LDS layout, the global digit totals -> number of
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t ia = block256_incl_scan(mine, part_a);
     const uint32_t ig = block256_incl_scan(mine_g, part_b);
     lstart[d] = ia - mine;
-    gbase[d] = (ig - mine_g) + hist[(size_t)d * nb_max + blockIdx.x];
+    gbase[d] = (ig - mine_g) + my_hist;
   }
   __syncthreads();
 #pragma unroll
