@@ -109,18 +109,18 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
   const int b_lo = threadIdx.x * per, b_hi = min(b_lo + per, nb);
   uint32_t mine = 0, run;
   uint32_t incl;
-  if (per <= 16) {
+  if (per <= 32) {
     // the thread's piece in registers, every load in flight at once (two loops of `per` dependent round trips were most of
     // this kernel's 12 us on the 6 M-pair sort)
-    uint32_t v[16];
+    uint32_t v[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (b_lo + u < b_hi) ? row[b_lo + u] : 0u;
+    for (int u = 0; u < 32; ++u) v[u] = (b_lo + u < b_hi) ? row[b_lo + u] : 0u;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) mine += v[u];
+    for (int u = 0; u < 32; ++u) mine += v[u];
     incl = block256_incl_scan(mine, sh);
     run = incl - mine;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       if (b_lo + u < b_hi) row[b_lo + u] = run;
       run += v[u];
     }
@@ -318,16 +318,23 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
   __shared__ uint32_t sh[SC_THREADS];
   const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
   uint32_t area = 0;
+  // every load of the thread is requested before the first is used (a load inside a branch per item was eight dependent round
+  // trips; the centre of a culled Gaussian is never written -- whatever is read there is discarded by the select)
+  int rad_[SC_ITEMS];
+  float2 c_[SC_ITEMS];
+  uint32_t id_[SC_ITEMS];
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int n = blockIdx.x * SC_TILE + i * SC_THREADS + threadIdx.x;     // natural order, coalesced
-    const int rad = (n < P) ? radii[n] : 0;
-    if (rad > 0) {
-      const float2 c = xy[n];
-      int x0, y0, x1, y1;
-      tile_rect(c.x, c.y, rad, gx, gy, x0, y0, x1, y1);
-      area += (uint32_t)((x1 - x0) * (y1 - y0));
-    }
+    rad_[i] = (n < P) ? radii[n] : 0;
+    c_[i] = (n < P) ? xy[n] : make_float2(0.f, 0.f);
+    id_[i] = (base + i < P) ? ids[base + i] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; ++i) {
+    int x0, y0, x1, y1;
+    tile_rect(c_[i].x, c_[i].y, rad_[i] > 0 ? rad_[i] : 1, gx, gy, x0, y0, x1, y1);
+    area += rad_[i] > 0 ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
   }
   const uint32_t area_incl = block_incl_scan(area, sh);
   if (threadIdx.x == SC_THREADS - 1) block_R[blockIdx.x] = area_incl;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int r = base + i;
-    v[i] = (r < P) ? tiles[ids[r]] : 0u;
+    v[i] = (r < P) ? tiles[id_[i]] : 0u;
     mx = max(mx, v[i]);
     sum += v[i];
     v[i] = sum;
