@@ -473,8 +473,11 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   if (nt) {
-    p = xy[id]; co = conic_o[id];
-    tile_rect(p.x, p.y, radii[id], gx, gy, x0, y0, x1, y1);
+    // centre, radius and conic from the Gaussian's 64-byte record: one cache line instead of three arrays' worth
+    const float4 q0 = reinterpret_cast<const float4*>(geo_words)[4 * (size_t)id];
+    co = reinterpret_cast<const float4*>(geo_words)[4 * (size_t)id + 1];
+    p = make_float2(q0.x, q0.y);
+    tile_rect(p.x, p.y, __float_as_int(q0.w), gx, gy, x0, y0, x1, y1);
     if (q == 0) geo_words[16 * (size_t)id + 2] = off0;        // first row slot, next to the geometry the backward fetches
   }
   // (behind the loads above: a store ahead of them would have them wait for its acknowledgement.  offsets[] itself stays as it

@@ -284,7 +284,7 @@ struct GeomBuf {           // saved between forward and backward
   float4* rgbd;            // (P) colour + view depth
   uint32_t* tiles;         // (P) tiles touched (0 == culled)
   uint32_t* clamped;       // (P) colour clamp bits
-  float4* geo;             // (P, 4) one 64-byte record per Gaussian: {x, y, first row slot, -}, conic_o, rgbd,
+  float4* geo;             // (P, 4) one 64-byte record per Gaussian: {x, y, first row slot, radius}, conic_o, rgbd,
                            // rgbd as bf16 pairs {hi(r,g), hi(b,d), lo(r,g), lo(b,d)}
   uint32_t* ftab;          // (P, 32) F = 32 only: the feature row as bf16 [hi 32 | lo 32] (x = hi + lo to ~2^-17): what the
                            // MFMA compositing kernels multiply with -- split once per Gaussian, not once per pair

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
     rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     // the same 40 bytes as ONE 64-byte record: the compositing kernels fetch a list entry's geometry from one cache line
     // (word 2 of the record: the Gaussian's first row slot, written by emit_pairs)
-    geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, 0.f);
+    geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, __int_as_float(o.radius));   // .w: the radius, for emit_pairs
     geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, opac);
     geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     geo[4 * (size_t)i + 3] = split_rgbd(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
