@@ -549,7 +549,10 @@ __device__ __forceinline__ void lds_barrier() {
 
 // SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations and the
 // ReLU gates (same saved-state layout as the chain kernel, so the backward does not care which forward produced it)
-template <bool SAVE>
+// FULL: every row of the workgroup's 128 exists (all workgroups but the last): the image stores are then unconditional --
+// inside a branch the compiler's wait counts cannot rely on them having been issued, and a wait for an older weight slab then
+// includes them
+template <bool SAVE, bool FULL>
 __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf16 (*s_w)[2][MW * 8], const MlpNet& net,
                                                  const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                                                  float* __restrict__ d_xyz, float* __restrict__ d_rot,
@@ -594,11 +597,10 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
   auto drain_store = [&](int l_prev, int piece, s16x4p v) {
     const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;    // 16-row x 16-column patch of this wave's block
     const int growb = u_row0 + r0;
-    if ((growb & ~31) < N) {                                                  // the 32-row image tile exists
-      __bf16* const patch = actsT + ((size_t)l_prev * ((N + 31) >> 5) + (growb >> 5)) * (MW * 32) +
-                            (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16;
-      patch_store(v, pl, patch, min(max(N - growb, 0), 16));
-    }
+    __bf16* const patch = actsT + ((size_t)l_prev * ((N + 31) >> 5) + (growb >> 5)) * (MW * 32) +
+                          (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16;
+    if constexpr (FULL) patch_store(v, pl, patch, 16);
+    else if ((growb & ~31) < N) patch_store(v, pl, patch, min(max(N - growb, 0), 16));   // the 32-row image tile exists
   };
   for (int l = 0; l < MD; ++l) {
     const bool has_emb = (l == 0 || l == SKIP);
@@ -709,7 +711,7 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
           if constexpr (SAVE) gate[nb >> 1] |= gate_bits4(pk) << ((nb & 1) * 16 + q * 4);
         }
       if constexpr (SAVE)      // the row's 256 gate bits are two uint4 (h = 0 / 1); this wave owns words 2 wc, 2 wc + 1 of each
-        if (grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
+        if (FULL || grow < N) *reinterpret_cast<uint2*>(gates + (((size_t)l * N + grow) * 2 + h) * 4 + wc * 2) = uint2{gate[0], gate[1]};
     }
     lds_barrier();             // the tile is complete; the image stores and the next layer's slab loads stay in flight
   }
@@ -759,7 +761,7 @@ void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __
                         float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
   __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
   __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // [buffer][k half][n][8]: 16 KiB
-  mlp_fwd_blk_body<false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
+  mlp_fwd_blk_body<false, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -768,7 +770,10 @@ void mlp_fwd_train_kernel_blk(MlpNet net, const float* __restrict__ x, const flo
                               __bf16* __restrict__ actsT, uint4* __restrict__ gates) {
   __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];
-  mlp_fwd_blk_body<true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
+  if ((int)(blockIdx.x + 1) * BROWS <= N)
+    mlp_fwd_blk_body<true, true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
+  else
+    mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
 }
 
 // the training forward spends a third of its time draining the saved-state stores (vmcnt is shared by loads and
