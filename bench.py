@@ -46,7 +46,7 @@ def source_sha16() -> str:
     # the sources of the path this bench times (the other kernels of the library -- MLP, losses, KNN, optimizer ... -- do not
     # change what the replayed counters describe)
     path_files = ("api.hip", "binning.hip", "common.h", "gs_math.h", "preprocess.hip", "preprocess_raw.hip", "render.hip",
-                  "render_bwd_gs.hip", "render_bwd_hw.hip", "render_bwd_mf.hip", "render_fwd_mf.hip")
+                  "render_bwd_gs.hip", "render_bwd_hw.hip", "render_fwd_mf.hip")
     for name in sorted(os.listdir(d)):
         if name in path_files:
             h.update(name.encode())

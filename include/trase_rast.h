@@ -63,30 +63,40 @@ typedef struct TraseRastSettings {
   int32_t prefiltered;
   int32_t debug;           /* !=0: synchronise + check after every kernel */
   int32_t device;          /* HIP device ordinal of all pointers and of `stream` */
-  int32_t variant;         /* kernel variant selector for A/B ablation; 0 = default.  Bits: 0x1 first-generation lane = pixel
-                            * backward with atomics; 0x40 VALU-only backward for every F; 0x100 dL_ddepth is honoured;
-                            * 0x200 point-list gather fused into tile_ranges; 0x400 feature-only backward;
-                            * 0x800 round-1 64-entry-chunk MFMA backward; 0x1000 timing instrumentation of the backward;
-                            * 0x2000 round-1 VALU forward; 0x4000 row reduction in Gaussian-id order (one launch);
-                            * 0x40000 compositing kernels visit the sub-tiles in image order, 0x80000 in 8x8 blocks (default: 16x16 blocks);
-                            * 0x8000 lane-utilisation counters of the MFMA backward (diagnostic, header words 40..46).
-                            * 0x100000 the sub-tile lists always carry emit-order slots (default: packed (id, pair index) values
-                            * whenever every Gaussian has few enough pairs -- decided on the device, results identical).
-                            * LINEAGE SWITCHES (the three places the absent fork of the CUDA extension is most
-                            * likely to differ from the public lineage; each flips the HIP kernels AND oracle/raster_oracle.py):
-                            * 0x100 the depth cotangent is honoured; 0x10000 the feature map gets a background term
-                            * feats[c] += T_final * feat_bg; 0x20000 the depth map is normalised, depth = sum(w z) / (1 - T_final) */
+  int32_t variant;         /* 0 = default; a bit set of TraseVariant (below): lineage switches, backward scope, the
+                            * VALU cross-check kernels, the list-value form */
   /* Tile-row strip (second multi-GPU axis, SURVEY.md 8e: one view sharded over ranks by rows of 16x16 tiles).  Rows
    * [tile_row_begin, tile_row_end) are binned, composited and differentiated; pixels outside the strip are not written,
    * per-Gaussian gradients are this strip's partial sums (the ranks' strips add up to the full gradient), radii stay
    * whole-image.  begin == end == 0 means the whole image. */
   int32_t tile_row_begin;
   int32_t tile_row_end;
-  float feat_bg;           /* background value of every feature channel; read only when variant & 0x10000 */
+  float feat_bg;           /* background value of every feature channel; read only when variant & TRASE_VARIANT_FEATS_BG */
   int32_t reserved0;
 } TraseRastSettings;
 
-enum { TRASE_VARIANT_DEPTH_GRAD = 0x100, TRASE_VARIANT_FEATS_BG = 0x10000, TRASE_VARIANT_DEPTH_NORM = 0x20000 };
+/* Bits of TraseRastSettings.variant.  Every other bit is ignored. */
+typedef enum TraseVariant {
+  /* -- lineage switches (the three places the absent fork of the CUDA extension is most likely to
+   *    differ from the public lineage; each flips the HIP kernels AND oracle/raster_oracle.py's OracleOptions) -- */
+  TRASE_VARIANT_DEPTH_GRAD = 0x100,          /* dL_ddepth is honoured (lineage: the depth output carries no gradient) */
+  TRASE_VARIANT_FEATS_BG = 0x10000,          /* feats[c] += T_final * feat_bg */
+  TRASE_VARIANT_DEPTH_NORM = 0x20000,        /* depth = sum(w z) / (1 - T_final) */
+  /* -- backward scope -- */
+  TRASE_VARIANT_FEATURES_ONLY_BWD = 0x400,   /* F = 32: only dL/dsh_objs is produced (FEATURE state once densification has
+                                              * ended); every other gradient is written as zeros */
+  /* -- cross-check formulations (same results to fp32 rounding; the tests compare the MFMA kernels against them) -- */
+  TRASE_VARIANT_VALU_BACKWARD = 0x40,        /* packed-FP32 compositing backward (render_bwd_gs.hip) also for F = 32 */
+  TRASE_VARIANT_VALU_FORWARD = 0x2000,       /* packed-FP32 compositing forward (render.hip) also for F = 32 */
+  TRASE_VARIANT_SLOT_LISTS = 0x100000,       /* sub-tile lists always carry emit-order slots (default: packed (id, pair index)
+                                              * values whenever every Gaussian has few enough pairs -- decided on the device,
+                                              * results identical) */
+  /* -- diagnostics: compiled only into `make AB=1` builds of the library (-DTRASE_AB), ignored otherwise -- */
+  TRASE_VARIANT_AB_TIMING = 0x1000,          /* phase cycle counters of the MFMA backward (geom header words 32..39) */
+  TRASE_VARIANT_AB_COUNT = 0x8000,           /* lane-utilisation counters of the MFMA backward (header words 40..47) */
+  TRASE_VARIANT_AB_ORDER_IMAGE = 0x40000,    /* compositing kernels visit the sub-tiles in image order ... */
+  TRASE_VARIANT_AB_ORDER_8 = 0x80000         /* ... in 8x8 blocks (default: 16x16 blocks) */
+} TraseVariant;
 
 /* Inputs of GaussianRasterizer.forward (gaussian_renderer/__init__.py:137-146).
  * Exactly one of shs/colors_precomp and one of (scales,rotations)/cov3D_precomp
@@ -277,8 +287,7 @@ typedef struct TraseMlpWeights {
                           * timenet(PE(t))), 93 inputs -- the caller evaluates the tiny timenet and passes its 30 outputs
                           * as `t` with t_stride 0 (train.py:190-202 feeds the same time to every row when is_blender) */
   int32_t is_6dof;       /* 1: the 3-vector head is a screw-axis branch (branch_w / branch_v); trase_amd/deform.py runs the network twice */
-  int32_t variant;       /* 0 = default (block-GEMM inference kernel); bit 0 = first-generation kernel, bit 1 = per-wave
-                          * weight streaming (both kept for A/B) */
+  int32_t variant;       /* reserved, must be 0 (the superseded kernel organisations it used to select are gone) */
   int32_t reserved;
   const float* weight[8];/* linear.{i}.weight: (256, 84|93) / (256, 256) / (256, 340|349) for the skip layer i = 5 */
   const float* bias[8];  /* linear.{i}.bias  : (256,) */

@@ -32,7 +32,7 @@ P = a.width * a.height
 g_img = (torch.randn(3, a.height, a.width, generator=g) / P).to(dev)
 g_feat = (torch.randn(32, a.height, a.width, generator=g) / P).to(dev)
 R.set_sync(True)
-R.set_variant(0x8000)
+R.set_variant(0x8000)     # TRASE_VARIANT_AB_COUNT: needs a `make -C trase_amd/csrc AB=1` build of the library
 names = ["entries", "chunks", "steps_run", "steps_skipped", "slots_real", "slots_pass_exponent_gates", "slots_blended",
          "walked_pairs_nobody_blended"]
 tot = dict.fromkeys(names, 0)

@@ -105,10 +105,11 @@ static size_t sort_bytes_common(size_t n) {   // hist + digit_total
 }
 // bits of a packed list value left for the pair index (HDR_PACK); 0 = the variant's kernels need emit-order slots
 static int list_pack_bits(const TraseRastSettings* s, int P) {
-  if (s->variant & (0x1 | 0x200 | 0x100000)) return 0;
+  if (s->variant & TRASE_VARIANT_SLOT_LISTS) return 0;
   int lg = 0;
   while ((1ll << lg) < (long long)P) ++lg;
-  return lg >= 28 ? 0 : 32 - lg;
+  if (lg >= 28) return 0;
+  return lg < 1 ? 31 : 32 - lg;       // never 32: the kernels evaluate (1u << jb) and v >> jb
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -146,8 +147,7 @@ PairBuf carve_tmp(void* ptr, int64_t cap) {
   return t;
 }
 size_t bwd_tmp_bytes(int P, int F, int64_t cap) {
-  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up((size_t)cap) + align_up(sizeof(float) * bwd_row_stride(F) * (size_t)cap) +
-         align_up(bwd_chan_bytes(P));
+  return align_up(sizeof(float) * BWD_ACC * (size_t)P) + align_up((size_t)cap) + align_up(sizeof(float) * bwd_row_stride(F) * (size_t)cap);
 }
 
 static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
@@ -355,22 +355,17 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     const int final_idx = passes & 1;
     t.sort.vals[final_idx] = b.pair_slot;
     t.sort.vals[final_idx ^ 1] = t.spare_vals;
-    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap,
-                           (s->variant & 0x200) ? nullptr : b.ranges, t.sort.vals[0]);
+    rc = launch_emit_pairs(c, *s, g, out->radii, pre.sort.vals[0], in->P, pre, t.sort.keys[0], t.pair_gauss, cap, b.ranges,
+                           t.sort.vals[0]);
     if (rc) return rc;
     int idx = 0;
     rc = radix_sort_pairs(c, t.sort, g.hdr + HDR_R_EFF, cap, 0, bits, false, &idx);
     if (rc) return rc;
     if (idx != final_idx) { set_error("internal: tile sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-    if (s->variant & 0x200) {       // A/B: dedicated slot -> id gather pass (the render kernel reads ids)
-      rc = launch_tile_ranges_gather(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, b.pair_slot, t.pair_gauss,
-                                     b.point_list, g.hdr + 16);
-      if (rc) return rc;
-    } else {                        // default: ranges only; the forward's staging step does the gather
-      rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, g.hdr + 16, false);
-      if (rc) return rc;
-      return launch_render_fwd(c, *s, *in, *out, g, b, im, t.pair_gauss, (uint32_t)cap);
-    }
+    // ranges only; with emit-order slots as list values the forward's staging step translates slot -> id
+    rc = launch_tile_ranges(c, t.sort.keys[idx], g.hdr + HDR_R_EFF, cap, b.ranges, T + 1, g.hdr + 16, false);
+    if (rc) return rc;
+    return launch_render_fwd(c, *s, *in, *out, g, b, im, t.pair_gauss, (uint32_t)cap);
   } else {
     TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * ((size_t)T + 1), stream));
   }
@@ -432,10 +427,9 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
   float* acc = (float*)ws->tmp;
   uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in->P);
   float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
-  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_stride(in->F) * (size_t)ws->capacity);
   if (in->P == 0) return TRASE_OK;
   TraseRastGrads g2 = *gr;
-  if (!(s->variant & 0x100)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
+  if (!(s->variant & TRASE_VARIANT_DEPTH_GRAD)) g2.dL_ddepth = nullptr;   // lineage: depth carries no gradient
   TraseRastInputs in2 = *in;
   bool zero_feats = false;
   if (!g2.dL_dfeats) {
@@ -445,30 +439,17 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
     g2.dL_dsh_objs = nullptr;
   }
   if (zero_feats) TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
-  if ((s->variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM)) && (s->variant & (1 | 0x800))) {
-    set_error("lineage switches are wired into the default backward kernels only (not variant bits 0x1 / 0x800)");
-    return TRASE_ERR_UNSUPPORTED;
-  }
-  if (s->variant & 1) {
-    // first-generation "lane = pixel" backward with atomics (kept for A/B ablation)
-    TRASE_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * BWD_ACC * (size_t)in->P, stream));
-    if (g2.dL_dsh_objs) TRASE_CHECK(hipMemsetAsync(g2.dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
-    rc = launch_render_bwd(c, *s, in2, g, b, im, g2, acc);
-    if (rc) return rc;
+  // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
+  // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
+  if (in2.F == 32 && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+    rc = launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
   } else {
-    // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
-    // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
-    if (in2.F == 32 && !(s->variant & 0x40)) {
-      rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
-                                : launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity), out->depth);
-    } else {
-      TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
-      rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags, out->depth);
-    }
-    if (rc) return rc;
-    rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
-    if (rc) return rc;
+    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+    rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags, out->depth);
   }
+  if (rc) return rc;
+  rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
+  if (rc) return rc;
   return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);
 }
 
@@ -559,28 +540,22 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
   float* acc = (float*)ws->tmp;
   uint8_t* row_flags = (uint8_t*)ws->tmp + align_up(sizeof(float) * BWD_ACC * (size_t)in.P);
   float* rows = (float*)(row_flags + align_up((size_t)ws->capacity));
-  void* chan = (char*)rows + align_up(sizeof(float) * bwd_row_stride(in.F) * (size_t)ws->capacity);
   if (in.P == 0) return TRASE_OK;
   TraseRastGrads g2;
   memset(&g2, 0, sizeof(g2));
   g2.dL_dimage = gr->dL_dimage; g2.dL_dfeats = gr->dL_dfeats;
-  g2.dL_ddepth = (s->variant & 0x100) ? gr->dL_ddepth : nullptr;
+  g2.dL_ddepth = (s->variant & TRASE_VARIANT_DEPTH_GRAD) ? gr->dL_ddepth : nullptr;
   float* d_feats = gr->dL_dgaussian_features;
   const bool no_feat_cotangent = !g2.dL_dfeats;
   if (no_feat_cotangent) {
     in.F = 0;
     d_feats = nullptr;
   }
-  if ((s->variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM)) && (s->variant & 0x800)) {
-    set_error("lineage switches are wired into the default backward kernels only (not variant bit 0x800)");
-    return TRASE_ERR_UNSUPPORTED;
-  }
   if (phase & 1) {
     if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0)
       TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
-    if (in.F == 32 && !(s->variant & 0x40)) {
-      rc = (s->variant & 0x800) ? launch_render_bwd_mf(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity))
-                                : launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, chan, align_up((size_t)ws->capacity), out->depth);
+    if (in.F == 32 && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+      rc = launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
     } else {
       TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
       rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags, out->depth);
@@ -588,9 +563,8 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
     if (rc) return rc;
   }
   if (phase & 2) {
-    const bool by_id_all = !ranged && (s->variant & 0x4000);       // experiment: id order in one launch
     rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features,
-                            ranged ? p_begin : (by_id_all ? 0 : -1), ranged ? p_end : (by_id_all ? raw->P : -1));
+                            ranged ? p_begin : -1, ranged ? p_end : -1);
     if (rc) return rc;
     rc = launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr, ranged ? p_begin : 0, ranged ? p_end : raw->P);
   }

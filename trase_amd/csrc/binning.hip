@@ -567,29 +567,6 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
   return TRASE_OK;
 }
 
-// ---- list entry -> Gaussian id (the sort carried the emit-order slot) ---------------------------
-__global__ __launch_bounds__(256) void gather_ids_kernel(const uint32_t* __restrict__ pair_slot,
-                                                         const uint32_t* __restrict__ pair_gauss,
-                                                         const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                         uint32_t* __restrict__ point_list) {
-  const uint32_t n = dev_n(n_ptr, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    point_list[i] = pair_gauss[pair_slot[i]];
-}
-
-int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
-                      uint32_t cap, uint32_t* point_list) {
-  int blocks = (int)((cap + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
-  {
-    ProfScope ps("gather_ids", c.stream);
-    hipLaunchKernelGGL(gather_ids_kernel, dim3(blocks), dim3(256), 0, c.stream, pair_slot, pair_gauss, n_ptr, cap, point_list);
-  }
-  TRASE_POST_LAUNCH("gather_ids", c.stream, c.debug);
-  return TRASE_OK;
-}
-
 // ---- backward phase 2: per-Gaussian sum of its (contiguous) per-pair gradient rows ----------------
 // Four depth ranks per wave: a 16-lane group owns one Gaussian and lane t of the group owns columns 4t..4t+3 of
 // its rows (ROW/4 <= 11 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
@@ -713,14 +690,10 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
 }
 
 // ---- tile ranges ---------------------------------------------------------------------------------
-// GATHER: also translate every list entry's emit-order slot into its Gaussian id (one pass over the list)
-template <bool GATHER>
+// (grid-stride form: only for key buffers that are not 16-byte aligned)
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                          uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ pair_slot,
-                                                          const uint32_t* __restrict__ pair_gauss,
-                                                          uint32_t* __restrict__ point_list, uint32_t T,
+                                                          uint2* __restrict__ ranges, uint32_t T,
                                                           uint32_t* __restrict__ dbg) {
   const uint32_t n = dev_n(n_ptr, cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -729,17 +702,12 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
       if (dbg) { dbg[0] = 1; dbg[1] = i; dbg[2] = t; }
       t = T - 1;
     }
-    if (GATHER) {
-      uint32_t slot = pair_slot[i];
-      if (slot >= n) { if (dbg) { dbg[4] = 1; dbg[5] = i; dbg[6] = slot; } slot = 0; }
-      point_list[i] = pair_gauss[slot];
-    }
     if (i == 0 || keys[i - 1] != t) ranges[t].x = i;
     if (i == n - 1 || keys[i + 1] != t) ranges[t].y = i + 1;
   }
 }
 
-// The default path (ids are gathered by the forward kernel): four consecutive list entries per thread, one 16-byte load
+// The default path: four consecutive list entries per thread, one 16-byte load
 // plus the two neighbours -- a single pass with every load in flight at once (the grid-stride form above took six
 // dependent trips per thread for 6 M entries).
 __global__ __launch_bounds__(256) void tile_ranges4_kernel(const uint32_t* __restrict__ keys,
@@ -769,22 +737,6 @@ __global__ __launch_bounds__(256) void tile_ranges4_kernel(const uint32_t* __res
   }
 }
 
-int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
-                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
-                              uint32_t* dbg) {
-  TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
-  int blocks = (int)((cap + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
-  {
-    ProfScope ps("tile_ranges", c.stream);
-    hipLaunchKernelGGL(tile_ranges_kernel<true>, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, pair_slot,
-                       pair_gauss, point_list, (uint32_t)T, dbg);
-  }
-  TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
-  return TRASE_OK;
-}
-
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg, bool clear) {
   if (clear) TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
@@ -795,8 +747,8 @@ int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t*
     if ((reinterpret_cast<uintptr_t>(keys) & 15) == 0)
       hipLaunchKernelGGL(tile_ranges4_kernel, dim3(blocks), dim3(256), 0, c.stream, keys, n_ptr, cap, ranges, (uint32_t)T, dbg);
     else
-      hipLaunchKernelGGL(tile_ranges_kernel<false>, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, c.stream, keys, n_ptr, cap,
-                         ranges, nullptr, nullptr, nullptr, (uint32_t)T, dbg);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, c.stream, keys, n_ptr, cap,
+                         ranges, (uint32_t)T, dbg);
   }
   TRASE_POST_LAUNCH("tile_ranges", c.stream, c.debug);
   return TRASE_OK;

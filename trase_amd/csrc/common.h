@@ -317,9 +317,7 @@ struct PairBuf {           // stage-2 scratch (capacity-sized)
   uint32_t* spare_vals;
   uint32_t* pair_gauss;    // (capacity) Gaussian id of every pair in emit order
 };
-struct BwdTmp {            // backward scratch: per-Gaussian accumulators filled by atomics
-  float* acc;              // (P, BWD_ACC) : d_ndc(2) d_conic(3) d_opacity(1) d_rgb(3) d_depth(1) pad
-};
+// backward scratch acc: (P, BWD_ACC) = d_ndc(2) d_conic(3) d_opacity(1) d_rgb(3) d_depth(1) pad(2), written by reduce_rows
 constexpr int BWD_ACC = 12;
 enum { ACC_NDCX = 0, ACC_NDCY = 1, ACC_CA = 2, ACC_CB = 3, ACC_CC = 4, ACC_OP = 5, ACC_R = 6, ACC_G = 7, ACC_B = 8, ACC_D = 9 };
 
@@ -336,7 +334,6 @@ static inline int bwd_row_floats(int F) { return F + 12; }
 #define TRASE_ROW_STRIDE32 44
 #endif
 constexpr int bwd_row_stride(int F) { return F == 32 ? TRASE_ROW_STRIDE32 : F + 12; }
-static inline size_t bwd_chan_bytes(int P) { return (size_t)P * 96 * 2; }   // render_bwd_mf.hip: [P][hi 48 | lo 48] bf16   // per-pair gradient row: F features + 10 scalars + 2 zeros (a multiple of 16 B)
 GeomBuf carve_geom(void* p, int P);
 BinBuf carve_bin(void* p, int64_t cap, int T);
 ImgBuf carve_img(void* p, int W, int H);
@@ -399,17 +396,12 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
                       const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t* keys, uint32_t* pair_gauss, uint32_t cap,
                       uint2* ranges_to_clear = nullptr, uint32_t* vals = nullptr);
-int launch_gather_ids(const LaunchCtx& c, const uint32_t* pair_slot, const uint32_t* pair_gauss, const uint32_t* n_ptr,
-                      uint32_t cap, uint32_t* point_list);
 // raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
                        int norm_features = 0, int id_begin = -1, int id_end = -1);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg = nullptr, bool clear = true);
-int launch_tile_ranges_gather(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges,
-                              int T, const uint32_t* pair_slot, const uint32_t* pair_gauss, uint32_t* point_list,
-                              uint32_t* dbg);
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss = nullptr,
@@ -419,16 +411,9 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
 int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
                          const float* out_depth = nullptr);
-int launch_render_bwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                         const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan, size_t flag_bytes);   // clears flag_bytes (a multiple of 16) of row_flags itself
-int launch_split_channels(const LaunchCtx& c, const TraseRastInputs& in, const GeomBuf& g, void* chan, uint8_t* row_flags,
-                          size_t flag_bytes);
-// half-wave formulation (32-entry chunks, 128 VGPRs): the default for F = 32; variant bit 0x800 selects the 64-entry kernel
+// half-wave MFMA formulation (32-entry chunks, 128 VGPRs): the default for F = 32
 int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan, size_t flag_bytes, const float* out_depth = nullptr);
-int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                      const BinBuf& b, const ImgBuf& im, const TraseRastGrads& gr, float* acc);
+                         size_t flag_bytes, const float* out_depth = nullptr);
 
 }  // namespace trase

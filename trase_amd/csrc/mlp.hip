@@ -37,8 +37,6 @@ struct MlpNet {
   const float* temb;     // is_blender: the 30 timenet outputs shared by all rows (columns 63..92); else nullptr
 };
 
-__device__ __forceinline__ int mlp_kp(int l) { return l == 0 ? EMBP : (l == SKIP ? EMBP + MW : MW); }
-
 // ---- weight packing: fp32 nn.Linear parameters -> bf16, padded / re-ordered -----------------------
 struct MlpPackArgs {
   const float* w[MD]; const float* b[MD];
@@ -102,106 +100,13 @@ __device__ __forceinline__ float pe_value(int c, float x0, float x1, float x2, f
   return 0.f;
 }
 
-__device__ __forceinline__ bf16x8 pe_fragment(int c0, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
-  bf16x8 a;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = (__bf16)pe_value(c0 + j, x0, x1, x2, t, temb);
-  return a;
-}
-
 // LDS activation tile of one wave: 32 rows x 256 bf16, 16-byte chunks XOR-swizzled by the row
 __device__ __forceinline__ int act_off(int m, int k) {   // element offset of (row m, column k)
   const int chunk = (k >> 3) ^ (m & 15);
   return m * MW + (chunk << 3) + (k & 7);
 }
 
-__global__ __launch_bounds__(MWAVES* WAVE) void mlp_fwd_kernel(MlpNet net, const float* __restrict__ x,
-                                                              const float* __restrict__ t, int t_stride, int N,
-                                                              float* __restrict__ d_xyz, float* __restrict__ d_rot,
-                                                              float* __restrict__ d_scale) {
-  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int row0 = (blockIdx.x * MWAVES + wave) * MROWS;
-  if (row0 >= N) return;
-  const int gm = min(row0 + m, N - 1);
-  const float x0 = x[3 * gm], x1 = x[3 * gm + 1], x2 = x[3 * gm + 2];
-  const float tt = t[(size_t)gm * t_stride];
-  __bf16* act = s_act[wave];
-  for (int l = 0; l < MD; ++l) {
-    const int kp = mlp_kp(l);
-    const int emb_steps = (l == 0 || l == SKIP) ? EMBP / 16 : 0;
-    const int steps = kp / 16;
-    const __bf16* __restrict__ W = net.w[l];
-    f32x16 acc[8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    for (int ks = 0; ks < steps; ++ks) {
-      bf16x8 a;
-      if (ks < emb_steps) a = pe_fragment(ks * 16 + 8 * h, x0, x1, x2, tt, net.temb);
-      else a = *reinterpret_cast<const bf16x8*>(act + act_off(m, (ks - emb_steps) * 16 + 8 * h));
-      const __bf16* wk = W + ((size_t)ks * MW + m) * 16 + 8 * h;    // column n = nb*32 + m of this N block
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wk + (size_t)nb * 32 * 16);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
-      }
-    }
-    // every row of this wave has been fully consumed: overwrite the tile with relu(acc + bias) as bf16
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const float* __restrict__ B = net.b[l];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int col = nb * 32 + m;
-      const float bias = B[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        act[act_off(row, col)] = (__bf16)fmaxf(acc[nb][r] + bias, 0.f);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  // heads: one 32-wide block, fp32 out
-  f32x16 hacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-  for (int ks = 0; ks < MW / 16; ++ks) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(act + act_off(m, ks * 16 + 8 * h));
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(net.w_head + ((size_t)ks * HEADP + m) * 16 + 8 * h);
-    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, hacc, 0, 0, 0);
-  }
-  const int col = m;
-  if (col < 10) {
-    const float bias = net.b_head[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < N) {
-        const float v = hacc[r] + bias;
-        if (col < 3) d_xyz[(size_t)row * 3 + col] = v;
-        else if (col < 7) d_rot[(size_t)row * 4 + (col - 3)] = v;
-        else d_scale[(size_t)row * 3 + (col - 7)] = v;
-      }
-    }
-  }
-}
-
-// ---- v3 (default) --------------------------------------------------------------------------------------
-// What limited v1 (ISA + counters): 405 registers => one wave per SIMD with un-prefetched weight loads, and an
-// epilogue of 128 two-byte LDS writes per layer.  v3:
-//  * operand roles swapped: D^T = W_frag * act_frag^T, so a lane owns ONE batch row and its 16 results per block
-//    are 4 runs of 4 consecutive features -> bias+ReLU+bf16 pack -> one 8-byte LDS write per run (32 per layer);
-//  * the 256 outputs are produced in two halves of 128 (64 accumulator registers instead of 128; the first
-//    half waits in 32 packed registers until the second has consumed the inputs) => 2 waves per SIMD;
-//  * weight fragments are double-buffered in registers: the loads of K-step ks+1 are in flight during the
-//    MFMAs of K-step ks;
-//  * the positional encoding is generated branch-free (both lane halves' columns are compile-time constants).
+// ---- helpers shared by the block-GEMM kernels ------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float pe_const(int c, float x0, float x1, float x2, float t, const float* __restrict__ temb) {   // c is a compile-time constant
@@ -219,55 +124,6 @@ __device__ __forceinline__ float pe_const(int c, float x0, float x1, float x2, f
     return (q & 1) ? __cosf(v) : __sinf(v);
   }
   return 0.f;
-}
-
-template <int KS>
-__device__ __forceinline__ bf16x8 pe_fragment_ct(int h, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
-  bf16x8 a;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float lo = pe_const(KS * 16 + j, x0, x1, x2, t, temb);
-    const float hi = pe_const(KS * 16 + 8 + j, x0, x1, x2, t, temb);
-    a[j] = (__bf16)(h ? hi : lo);
-  }
-  return a;
-}
-
-__device__ __forceinline__ short bf16_bits(float v) { return __builtin_bit_cast(short, (__bf16)v); }
-
-// one K-step of a 128-wide output half: 4 MFMAs, lane = batch row
-__device__ __forceinline__ void mma4(f32x16 (&acc)[4], const bf16x8 (&w)[4], const bf16x8& a) {
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nb], a, acc[nb], 0, 0, 0);
-}
-// fragment of K-step `kstep` (K-slice-major weights): rows row_base + nb*32 + m, columns 8h..8h+7 of the slice
-__device__ __forceinline__ void load_w4(bf16x8 (&w)[4], const __bf16* __restrict__ W, int row_base, int m, int h, int kstep) {
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-    w[nb] = *reinterpret_cast<const bf16x8*>(W + ((size_t)kstep * MW + row_base + nb * 32 + m) * 16 + 8 * h);
-}
-
-// positional-encoding K-steps of layers 0 and 5: the six fragments are computed once per wave and stay in registers
-__device__ __forceinline__ void emb_steps(f32x16 (&acc)[4], const __bf16* __restrict__ W, int row_base, int m, int h,
-                                          const bf16x8 (&pe)[EMBP / 16]) {
-  bf16x8 w0[4], w1[4];
-  load_w4(w0, W, row_base, m, h, 0);
-#pragma unroll
-  for (int ks = 0; ks < EMBP / 16; ks += 2) {
-    load_w4(w1, W, row_base, m, h, ks + 1);
-    mma4(acc, w0, pe[ks]);
-    if (ks + 2 < EMBP / 16) load_w4(w0, W, row_base, m, h, ks + 2);
-    mma4(acc, w1, pe[ks + 1]);
-  }
-}
-
-template <int KS>
-__device__ __forceinline__ void pe_fill(bf16x8 (&pe)[EMBP / 16], int h, float x0, float x1, float x2, float tt,
-                                        const float* __restrict__ temb) {
-  if constexpr (KS < EMBP / 16) {
-    pe[KS] = pe_fragment_ct<KS>(h, x0, x1, x2, tt, temb);
-    pe_fill<KS + 1>(pe, h, x0, x1, x2, tt, temb);
-  }
 }
 
 // ---- saved state of the training forward ---------------------------------------------------------------
@@ -322,33 +178,6 @@ __device__ __forceinline__ s16x4 gated_bf16x4(float a, float b, float c, float d
 __device__ __forceinline__ size_t timg_off(int M, int col, int row) {
   return (size_t)(row >> 4) * (size_t)(M * 16) + (size_t)col * 16 + (size_t)(row & 15);
 }
-__device__ __forceinline__ void store_transposed(__bf16* __restrict__ img_tile, int f0, int m, s16x4 pk) {
-  const bool odd = m & 1, hi = m & 2;
-  unsigned d[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {        // round 1: lanes m^1 swap -> d[p] = column f0 + 2p + odd, rows (m&~1, m|1)
-    const unsigned a = (unsigned short)pk[2 * p], b = (unsigned short)pk[2 * p + 1];
-    const unsigned send = odd ? a : b;
-    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
-    d[p] = odd ? (recv | (b << 16)) : (a | (recv << 16));
-  }
-  // round 2: lanes m^2 swap -> column f0 + (m&3), rows (m&~3) .. +3
-  const unsigned send2 = hi ? d[0] : d[1];
-  const unsigned recv2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send2, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
-  uint2 out;
-  out.x = hi ? recv2 : d[0];
-  out.y = hi ? d[1] : recv2;
-  // quad position q = m&3 owns column f0 + (q&1) + 2*(q>>1)... round 1 gave odd lanes the odd columns, round 2 the
-  // upper lane pair the columns +2: column = f0 + (m&1) + (m&2)
-  {   // written once, read much later by the weight-gradient GEMMs: a non-temporal store (full 256-byte runs, unlike the
-      // rasterizer's partial-line maps) keeps the 1.2 GB image from evicting what the chain kernels re-read -- training step
-      // 1.94 -> 1.81 ms (data chain 0.63 -> 0.515)
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    const u2v o2 = {out.x, out.y};
-    __builtin_nontemporal_store(o2, reinterpret_cast<u2v*>(img_tile + timg_off(MW, f0 + (m & 3), m & ~3)));
-  }
-}
-
 // The same image from the LDS activation tile (block kernels): the tile holds [row][column] with 8-byte runs of four columns;
 // gfx950's transposing read (ds_read_b64_tr_b16: inside a 16-lane group lane 4 jj + cc hands in the address of four columns
 // -- chunk cc -- of row jj and lane c receives column c of the four rows) IS the 4 x 4 transpose that the DPP rounds above do
@@ -388,121 +217,6 @@ __device__ __forceinline__ void patch_store(s16x4p v, const PatchLane& pl, __bf1
   typedef unsigned u2v __attribute__((ext_vector_type(2)));
   const u2v o2 = __builtin_bit_cast(u2v, v);
   __builtin_nontemporal_store(o2, reinterpret_cast<u2v*>(img_patch + pl.img_elem));
-}
-
-// SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations
-// (input of the next layer's weight-gradient GEMM) and the ReLU gate as one bit per (row, feature)
-template <bool SAVE>
-__device__ __forceinline__ void mlp_fwd_body(__bf16 (*s_act)[MROWS * MW], const MlpNet& net, const float* __restrict__ x,
-                                             const float* __restrict__ t, int t_stride, int N,
-                                             float* __restrict__ d_xyz, float* __restrict__ d_rot,
-                                             float* __restrict__ d_scale, __bf16* __restrict__ actsT,
-                                             uint4* __restrict__ gates) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int row0 = (blockIdx.x * MWAVES + wave) * MROWS;
-  if (row0 >= N) return;
-  const int grow = row0 + m;
-  const int gm = min(grow, N - 1);
-  const float x0 = x[3 * gm], x1 = x[3 * gm + 1], x2 = x[3 * gm + 2];
-  const float tt = t[(size_t)gm * t_stride];
-  __bf16* act = s_act[wave];
-  bf16x8 pe[EMBP / 16];
-  pe_fill<0>(pe, h, x0, x1, x2, tt, net.temb);
-  for (int l = 0; l < MD; ++l) {
-    const bool has_emb = (l == 0 || l == SKIP);
-    const int hid_steps = (l == 0) ? 0 : MW / 16;
-    const int kst0 = has_emb ? EMBP / 16 : 0;             // first K-step of the hidden columns
-    const __bf16* __restrict__ W = net.w[l];
-    const float* __restrict__ B = net.b[l];
-    s16x4 held[4][4];                                      // first half, packed bf16: [block][run of 4 features]
-    unsigned gate[4] = {0u, 0u, 0u, 0u};                   // SAVE: this lane's 128 ReLU gates of the layer
-    __bf16* const tileT = SAVE ? actsT + ((size_t)l * ((N + 31) >> 5) + (row0 >> 5)) * (MW * 32) : nullptr;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row_base = half * 128;
-      __builtin_amdgcn_sched_barrier(0);                  // the two halves must not be interleaved (register budget)
-      f32x16 acc[4];                                       // accumulators start at the bias
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 bias = *reinterpret_cast<const float4*>(B + row_base + nb * 32 + 8 * q + 4 * h);
-          acc[nb][4 * q + 0] = bias.x; acc[nb][4 * q + 1] = bias.y; acc[nb][4 * q + 2] = bias.z; acc[nb][4 * q + 3] = bias.w;
-        }
-      if (has_emb) emb_steps(acc, W, row_base, m, h, pe);
-      if (hid_steps) {
-        bf16x8 w0[4], w1[4];
-        load_w4(w0, W, row_base, m, h, kst0);
-        for (int ks = 0; ks < hid_steps; ks += 2) {       // unrolled by two: static register double buffer
-          load_w4(w1, W, row_base, m, h, kst0 + ks + 1);
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(act + act_off(m, ks * 16 + 8 * h));
-          mma4(acc, w0, a0);
-          if (ks + 2 < hid_steps) load_w4(w0, W, row_base, m, h, kst0 + ks + 2);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(act + act_off(m, (ks + 1) * 16 + 8 * h));
-          mma4(acc, w1, a1);
-        }
-      }
-      // epilogue of this half: lane = batch row m; register r of block nb is feature row_base + nb*32 + 8(r/4) + 4h + r%4
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int f0 = row_base + nb * 32 + 8 * q + 4 * h;
-          s16x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = bf16_bits(fmaxf(acc[nb][4 * q + e], 0.f));
-          if (half == 0) held[nb][q] = pk;                 // inputs are still needed by the second half
-          else *reinterpret_cast<s16x4*>(act + act_off(m, f0)) = pk;
-          if constexpr (SAVE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gate[half * 2 + (nb >> 1)] |= (pk[e] & 0x7fff) ? 1u << ((nb & 1) * 16 + q * 4 + e) : 0u;
-            store_transposed(tileT, f0, m, grow < N ? pk : s16x4{0, 0, 0, 0});   // padding rows contribute nothing
-          }
-        }
-      }
-    }
-    if constexpr (SAVE)
-      if (grow < N) gates[((size_t)l * N + grow) * 2 + h] = uint4{gate[0], gate[1], gate[2], gate[3]};
-    // both halves have consumed the old tile: now the first half may land
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<s16x4*>(act + act_off(m, nb * 32 + 8 * q + 4 * h)) = held[nb][q];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  // heads: D^T[o][row], one block; lane = batch row, register r is output 8(r/4) + 4h + r%4
-  f32x16 hacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-  for (int ks = 0; ks < MW / 16; ++ks) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(act + act_off(m, ks * 16 + 8 * h));
-    const bf16x8 w = *reinterpret_cast<const bf16x8*>(net.w_head + ((size_t)ks * HEADP + m) * 16 + 8 * h);
-    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, hacc, 0, 0, 0);
-  }
-  if (grow < N) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {                           // outputs 0..15 live in registers 0..7 (q = 0,1)
-      const int o = 8 * (r >> 2) + 4 * h + (r & 3);
-      if (o < 10) {
-        const float v = hacc[r] + net.b_head[o];
-        if (o < 3) d_xyz[(size_t)grow * 3 + o] = v;
-        else if (o < 7) d_rot[(size_t)grow * 4 + (o - 3)] = v;
-        else d_scale[(size_t)grow * 3 + (o - 7)] = v;
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mlp_fwd_kernel_v3(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
-                       float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
-  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
-  mlp_fwd_body<false>(s_act, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, nullptr);
 }
 
 // ---- inference forward, block-GEMM organisation ---------------------------------------------------------------------
@@ -776,17 +490,6 @@ void mlp_fwd_train_kernel_blk(MlpNet net, const float* __restrict__ x, const flo
     mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
 }
 
-// the training forward spends a third of its time draining the saved-state stores (vmcnt is shared by loads and
-// stores, so a wave waiting for its next weight fragment also waits for its stores): two waves per SIMD let one
-// wave compute while the other drains
-__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mlp_fwd_train_kernel(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
-                          float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
-                          __bf16* __restrict__ actsT, uint4* __restrict__ gates) {
-  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
-  mlp_fwd_body<true>(s_act, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, gates);
-}
-
 // ---- training backward ------------------------------------------------------------------------------------
 // (1) data chain:  dZ_l = dH_l * [h_l > 0];  dH_{l-1} = dZ_l . W_l[:, hidden columns]  (x and t are detached at the
 //     call site, train.py:196-204 `deform.step(gaussians.get_xyz.detach(), time_input)`: nothing flows into the PE).
@@ -1009,103 +712,6 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
       for (int j = 0; j < 8; ++j) dz_store(l - 1, p0 + j, dv[j]);
     }
     lds_barrier();
-  }
-}
-
-__global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_bwd_data_kernel(MlpNetT net, const float* __restrict__ g_xyz,
-                                                                      const float* __restrict__ g_rot,
-                                                                      const float* __restrict__ g_scale, int N,
-                                                                      const uint4* __restrict__ gates,
-                                                                      __bf16* __restrict__ dzT, __bf16* __restrict__ gT) {
-  __shared__ __attribute__((aligned(16))) __bf16 s_act[MWAVES][MROWS * MW];   // 64 KiB
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int row0 = (blockIdx.x * MWAVES + wave) * MROWS;
-  if (row0 >= N) return;
-  const int grow = row0 + m;
-  const int gm = min(grow, N - 1);
-  const bool live = grow < N;
-  const int tiles = (N + 31) >> 5, tile = row0 >> 5;
-  __bf16* act = s_act[wave];
-  // cotangent of the ten head outputs as one 16-wide K-step: columns 0-2 d_xyz, 3-6 rotation, 7-9 scaling
-  bf16x8 g8;
-  {
-    float g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
-    if (live) {
-      if (h == 0) {
-        if (g_xyz) { g[0] = g_xyz[3 * (size_t)gm]; g[1] = g_xyz[3 * (size_t)gm + 1]; g[2] = g_xyz[3 * (size_t)gm + 2]; }
-        if (g_rot) { g[3] = g_rot[4 * (size_t)gm]; g[4] = g_rot[4 * (size_t)gm + 1]; g[5] = g_rot[4 * (size_t)gm + 2]; g[6] = g_rot[4 * (size_t)gm + 3]; }
-        if (g_scale) g[7] = g_scale[3 * (size_t)gm];
-      } else if (g_scale) { g[0] = g_scale[3 * (size_t)gm + 1]; g[1] = g_scale[3 * (size_t)gm + 2]; }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g8[j] = (__bf16)g[j];
-    // transposed image of the cotangent, [tile][2][32 columns][16 rows] (columns 10..31 zero): operand of the head GEMM
-    __bf16* gt = gT + (size_t)tile * (HEADP * 32);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gt[timg_off(HEADP, 8 * h + j, m)] = g8[j];
-      gt[timg_off(HEADP, 16 + 8 * h + j, m)] = (__bf16)0.f;
-    }
-  }
-  for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
-    const __bf16* __restrict__ W = (l == MD) ? net.wt_head : net.wt[l];
-    const uint4 gv = gates[((size_t)(l - 1) * N + gm) * 2 + h];
-    const unsigned gate[4] = {gv.x, gv.y, gv.z, gv.w};
-    __bf16* const tileT = dzT + ((size_t)(l - 1) * tiles + tile) * (MW * 32);
-    s16x4 held[4][4];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row_base = half * 128;
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 acc[4];
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-      if (l == MD) {
-        bf16x8 w0[4];
-        load_w4(w0, W, row_base, m, h, 0);
-        mma4(acc, w0, g8);
-      } else {
-        bf16x8 w0[4], w1[4];
-        load_w4(w0, W, row_base, m, h, 0);
-        for (int ks = 0; ks < MW / 16; ks += 2) {
-          load_w4(w1, W, row_base, m, h, ks + 1);
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(act + act_off(m, ks * 16 + 8 * h));
-          mma4(acc, w0, a0);
-          if (ks + 2 < MW / 16) load_w4(w0, W, row_base, m, h, ks + 2);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(act + act_off(m, (ks + 1) * 16 + 8 * h));
-          mma4(acc, w1, a1);
-        }
-      }
-      // epilogue: ReLU gate recorded by the forward, bf16, LDS tile for the next stage + transposed image
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int f0 = row_base + nb * 32 + 8 * q + 4 * h;
-          const unsigned bits = live ? gate[half * 2 + (nb >> 1)] >> ((nb & 1) * 16 + q * 4) : 0u;
-          s16x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = (bits >> e & 1u) ? bf16_bits(acc[nb][4 * q + e]) : (short)0;
-          if (half == 0) held[nb][q] = pk;
-          else *reinterpret_cast<s16x4*>(act + act_off(m, f0)) = pk;
-          store_transposed(tileT, f0, m, pk);
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<s16x4*>(act + act_off(m, nb * 32 + 8 * q + 4 * h)) = held[nb][q];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 }
 
@@ -1440,17 +1046,12 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
     if (t_stride != 0) { set_error("trase_mlp_forward: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
     net.temb = t;
   }
-  const int rows_per_block = MWAVES * MROWS;
   {
     ProfScope ps("mlp_fwd", stream);
-    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
-    if (w->variant & 1)       // v1: first-generation kernel (kept for A/B)
-      hipLaunchKernelGGL(mlp_fwd_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
-    else if (w->variant & 2)  // v3: every wave streams the weights for its own 32 rows (kept for A/B)
-      hipLaunchKernelGGL(mlp_fwd_kernel_v3, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
-    else                      // block-GEMM organisation: weight slabs staged in LDS once per 128-row workgroup
-      hipLaunchKernelGGL(mlp_fwd_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N, d_xyz,
-                         d_rotation, d_scaling);
+    const dim3 block(MWAVES * WAVE);
+    // block-GEMM organisation: weight slabs staged in LDS once per 128-row workgroup
+    hipLaunchKernelGGL(mlp_fwd_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N, d_xyz,
+                       d_rotation, d_scaling);
   }
   TRASE_POST_LAUNCH("mlp_fwd", stream, 0);
   return TRASE_OK;
@@ -1480,16 +1081,11 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
     hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT);
   }
   TRASE_POST_LAUNCH("mlp_pe", stream, 0);
-  const int rows_per_block = MWAVES * MROWS;
   {
     ProfScope ps("mlp_fwd_train", stream);
-    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
-    if (w->variant & 2)       // per-wave weight streaming (kept for A/B)
-      hipLaunchKernelGGL(mlp_fwd_train_kernel, grid, block, 0, stream, net, x, t, t_stride, N, d_xyz, d_rotation,
-                         d_scaling, sv.actsT, sv.gates);
-    else
-      hipLaunchKernelGGL(mlp_fwd_train_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N,
-                         d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates);
+    const dim3 block(MWAVES * WAVE);
+    hipLaunchKernelGGL(mlp_fwd_train_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N,
+                       d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates);
   }
   TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
   return TRASE_OK;
@@ -1523,14 +1119,9 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
   TRASE_POST_LAUNCH("mlp_pack_t", stream, 0);
   {
     ProfScope ps("mlp_bwd_data", stream);
-    const int rows_per_block = MWAVES * MROWS;
-    const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(MWAVES * WAVE);
-    if (w->variant & 2)       // per-wave weight streaming (kept for A/B)
-      hipLaunchKernelGGL(mlp_bwd_data_kernel, grid, block, 0, stream, net, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling, N,
-                         (const uint4*)sv.gates, bp.dzT, bp.gT);
-    else
-      hipLaunchKernelGGL(mlp_bwd_data_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, dL_dd_xyz, dL_dd_rotation,
-                         dL_dd_scaling, N, (const uint32_t*)sv.gates, bp.dzT, bp.gT);
+      const dim3 block(MWAVES * WAVE);
+    hipLaunchKernelGGL(mlp_bwd_data_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, dL_dd_xyz, dL_dd_rotation,
+                       dL_dd_scaling, N, (const uint32_t*)sv.gates, bp.dzT, bp.gT);
   }
   TRASE_POST_LAUNCH("mlp_bwd_data", stream, 0);
   const size_t img = (size_t)tiles * MW * 32;              // one layer's transposed image, elements

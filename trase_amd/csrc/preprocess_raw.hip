@@ -239,9 +239,8 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
   a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
   a.features = raw.gaussian_features; a.featn = raw.featn;
-  // the fp32 normalised rows are read by the VALU forward (0x2000) and by the first-generation / VALU / 64-entry backward
-  // kernels (0x1, 0x40, 0x800) only
-  a.write_featn = (c.variant & (0x1 | 0x40 | 0x800 | 0x2000)) != 0;
+  // the fp32 normalised rows are read by the VALU forward and the VALU backward only
+  a.write_featn = (c.variant & (TRASE_VARIANT_VALU_BACKWARD | TRASE_VARIANT_VALU_FORWARD)) != 0;
   a.vm = s.viewmatrix; a.pm = s.projmatrix; a.cam = s.campos;
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;

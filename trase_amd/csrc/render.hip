@@ -1,4 +1,5 @@
-// render.hip -- alpha compositing of the per-tile depth-ordered lists (forward) and its backward.
+// render.hip -- alpha compositing of the per-tile depth-ordered lists, packed-FP32 forward (F = 0 / 16; F = 32 as the
+// cross-check of the MFMA forward, TRASE_VARIANT_VALU_FORWARD).
 // Variant 0 ("valu"): one wave per 8x8 sub-tile (4 independent waves per workgroup, no workgroup
 // barriers); batches of 64 list entries are staged through wave-private LDS; the per-Gaussian
 // feature row is fetched with a wave-uniform address and only when some lane of the wave
@@ -158,7 +159,7 @@ static void fill_render_args(RenderArgs& a, const TraseRastSettings& s, const Tr
 
 int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const TraseRastOutputs& out,
                       const GeomBuf& g, const BinBuf& b, const ImgBuf& im, const uint32_t* pair_gauss, uint32_t cap) {
-  if (in.F == 32 && !(c.variant & 0x2000))               // default: channel accumulation on the matrix cores
+  if (in.F == 32 && !(c.variant & TRASE_VARIANT_VALU_FORWARD))               // default: channel accumulation on the matrix cores
     return launch_render_fwd_mf(c, s, in, out, g, b, im, pair_gauss, cap);
   RenderArgs a;
   fill_render_args(a, s, in, g, b);
@@ -177,154 +178,6 @@ int launch_render_fwd(const LaunchCtx& c, const TraseRastSettings& s, const Tras
     }
   }
   TRASE_POST_LAUNCH("render_fwd", c.stream, c.debug);
-  return TRASE_OK;
-}
-
-// ---- backward -----------------------------------------------------------------------------------
-// Back-to-front over the same lists.  With s_g = <channels of Gaussian g, pixel cotangent> the
-// whole multi-channel recurrence collapses to scalars:
-//   dL/dalpha_g = T_g * (s_g - A_g),   A_g = alpha_{g+1} s_{g+1} + (1 - alpha_{g+1}) A_{g+1},  A_last = <bg, d_rgb>
-// Per-Gaussian sums over the wave's 64 pixels are reduced with DPP before one atomic per value.
-struct RenderBwdArgs {
-  RenderArgs r;
-  const float* d_img; const float* d_feat; const float* d_depth;
-  const float* final_T; const uint32_t* n_contrib;
-  float* acc;        // (P, BWD_ACC)
-  float* d_feats_out;  // (P, F) or null
-};
-
-template <int F>
-__global__ __launch_bounds__(RB) void render_bwd_kernel(RenderBwdArgs b) {
-  const RenderArgs& a = b.r;
-  __shared__ float2 s_xy[WPB][WAVE];
-  __shared__ float4 s_co[WPB][WAVE];
-  __shared__ float4 s_cd[WPB][WAVE];
-  __shared__ uint32_t s_id[WPB][WAVE];
-  int px, py, wave, lane;
-  const int tile = subtile_of_wave(a, px, py, wave, lane);
-  if (tile < 0) return;
-  const bool inside = px < a.W && py < a.H;
-  const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = a.ranges[tile];
-  const size_t hw = (size_t)a.H * a.W;
-  const size_t pix = (size_t)py * a.W + px;
-  // pixel cotangents
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f;
-  float gf[F > 0 ? F : 1];
-#pragma unroll
-  for (int c = 0; c < F; ++c) gf[c] = 0.f;
-  float T_final = 0.f;
-  uint32_t last = 0;
-  if (inside) {
-    T_final = b.final_T[pix];
-    last = b.n_contrib[pix];
-    if (b.d_img) { g0 = b.d_img[pix]; g1 = b.d_img[hw + pix]; g2 = b.d_img[2 * hw + pix]; }
-    if (b.d_depth) gd = b.d_depth[pix];
-    if (F > 0 && b.d_feat) {
-#pragma unroll
-      for (int c = 0; c < F; ++c) gf[c] = b.d_feat[(size_t)c * hw + pix];
-    }
-  }
-  float T = T_final;
-  float A = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2;   // "colour behind", projected on the cotangent
-  const float ddx = 0.5f * (float)a.W, ddy = 0.5f * (float)a.H;
-  // entries behind the last one any pixel of this sub-tile blended are never touched
-  uint32_t wave_last = last;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o));
-  uint32_t contributor = wave_last;
-  for (uint32_t prog = 0; prog < wave_last; prog += WAVE) {
-    const uint32_t n = min((uint32_t)WAVE, wave_last - prog);
-    wave_lds_sync();
-    if ((uint32_t)lane < n) {
-      const uint32_t id = a.point_list[range.x + wave_last - 1 - prog - lane];
-      s_id[wave][lane] = id;
-      s_xy[wave][lane] = a.xy[id];
-      s_co[wave][lane] = a.conic_o[id];
-      s_cd[wave][lane] = a.rgbd[id];
-    }
-    wave_lds_sync();
-    for (uint32_t j = 0; j < n; ++j) {
-      --contributor;   // 0-based list position of this entry
-      const bool live = contributor < last;
-      if (!__any(live)) continue;
-      const float2 g = s_xy[wave][j];
-      const float4 co = s_co[wave][j];
-      const float dx = g.x - pxf, dy = g.y - pyf;
-      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(ALPHA_MAX, co.w * G);
-      const bool ok = live && power <= 0.0f && alpha >= ALPHA_MIN;
-      if (!__any(ok)) continue;
-      const uint32_t id = __builtin_amdgcn_readfirstlane(s_id[wave][j]);
-      const float4 col = s_cd[wave][j];
-      float s = col.x * g0 + col.y * g1 + col.z * g2 + col.w * gd;
-      const float* __restrict__ f = a.feats + (size_t)id * F;
-      float fr[F > 0 ? F : 1];
-      if (F > 0) {
-#pragma unroll
-        for (int c = 0; c < F; ++c) { fr[c] = f[c]; s += fr[c] * gf[c]; }
-      }
-      float wgt = 0.f, dL_dalpha = 0.f;
-      if (ok) {
-        T = T / (1.0f - alpha);
-        wgt = alpha * T;
-        dL_dalpha = T * (s - A);
-        A = alpha * s + (1.0f - alpha) * A;
-      }
-      const float dL_dG = co.w * dL_dalpha;
-      const float gdx = G * dx, gdy = G * dy;
-      const float dG_ddelx = -gdx * co.x - gdy * co.y;
-      const float dG_ddely = -gdy * co.z - gdx * co.y;
-      // 10 geometry/colour sums + F feature sums, reduced over the wave then one atomic each
-      float mine = 0.f;
-      float r;
-#define TRASE_RED(slot, expr)                                   \
-  r = readlane_f(wave_sum_lane63(expr), 63);                    \
-  if (lane == (slot)) mine = r;
-      TRASE_RED(F + ACC_NDCX, dL_dG * dG_ddelx * ddx)
-      TRASE_RED(F + ACC_NDCY, dL_dG * dG_ddely * ddy)
-      TRASE_RED(F + ACC_CA, -0.5f * gdx * dx * dL_dG)
-      TRASE_RED(F + ACC_CB, -gdx * dy * dL_dG)
-      TRASE_RED(F + ACC_CC, -0.5f * gdy * dy * dL_dG)
-      TRASE_RED(F + ACC_OP, G * dL_dalpha)
-      TRASE_RED(F + ACC_R, wgt * g0)
-      TRASE_RED(F + ACC_G, wgt * g1)
-      TRASE_RED(F + ACC_B, wgt * g2)
-      TRASE_RED(F + ACC_D, wgt * gd)
-      if (F > 0) {
-#pragma unroll
-        for (int c = 0; c < F; ++c) { TRASE_RED(c, wgt * gf[c]) }
-      }
-#undef TRASE_RED
-      if (lane < F) {
-        if (b.d_feats_out) atomic_add_f32(b.d_feats_out + (size_t)id * F + lane, mine);
-      } else if (lane < F + 10) {
-        atomic_add_f32(b.acc + (size_t)id * BWD_ACC + (lane - F), mine);
-      }
-    }
-  }
-}
-
-int launch_render_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
-                      const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* acc) {
-  RenderBwdArgs b;
-  RenderArgs& a = b.r;
-  fill_render_args(a, s, in, g, bb);
-  b.d_img = gr.dL_dimage; b.d_feat = gr.dL_dfeats; b.d_depth = gr.dL_ddepth;
-  b.final_T = im.final_T; b.n_contrib = im.n_contrib; b.acc = acc; b.d_feats_out = gr.dL_dsh_objs;
-  if (a.ntiles <= 0) return TRASE_OK;
-  const int T = (a.ntiles + WPB - 1) / WPB;
-  {
-    ProfScope ps("render_bwd", c.stream);
-    switch (in.F) {
-      case 0: hipLaunchKernelGGL(render_bwd_kernel<0>, dim3(T), dim3(RB), 0, c.stream, b); break;
-      case 16: hipLaunchKernelGGL(render_bwd_kernel<16>, dim3(T), dim3(RB), 0, c.stream, b); break;
-      case 32: hipLaunchKernelGGL(render_bwd_kernel<32>, dim3(T), dim3(RB), 0, c.stream, b); break;
-      default: set_error("render_bwd: feature width %d not compiled in (0,16,32)", in.F); return TRASE_ERR_UNSUPPORTED;
-    }
-  }
-  TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);
   return TRASE_OK;
 }
 

@@ -33,7 +33,6 @@ struct BwdGsArgs {
   uint8_t* row_flags;  // (capacity) 1 where a row was written (zeroed by the caller beforehand)
   int W, H, gx8, ntiles;
   int tile0;             // first sub-tile of the strip being rendered (ntiles counts the strip's sub-tiles)
-  int ablate;          // debug/A-B (variant bits 4..7): bit0 skip the row writes, bit1 builtin instead of asm DPP scans
   int lineage;         // variant bits TRASE_VARIANT_FEATS_BG / TRASE_VARIANT_DEPTH_NORM (0 = public lineage)
   float feat_bg;
   const float* out_depth;
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(GWPB* WAVE) void render_bwd_gs_kernel(BwdGsArgs a) 
     const float a_ca = -0.5f * Qxx, a_cb = -Qxy, a_cc = -0.5f * Qyy;
     const float a_op = (co.w > 0.0f) ? S0 / co.w : 0.0f;
     // ---- write this chunk's per-Gaussian sums: one row per pair --------------------------------
-    if (lane_valid && !(a.ablate & 1)) {
+    if (lane_valid) {
       float4* row = reinterpret_cast<float4*>(a.rows + (size_t)slot * bwd_row_stride(F));
       if (F > 0) {
 #pragma unroll
@@ -239,14 +238,12 @@ int launch_render_bwd_gs(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
-  a.ablate = (c.variant >> 4) & 0xf;
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the caller has cleared the flags)
   const int blocks = (a.ntiles + GWPB - 1) / GWPB;
   {
     ProfScope ps("render_bwd", c.stream);
     switch (in.F) {
-#define TRASE_BWD_GS(FF) do { if (a.ablate & 2) hipLaunchKernelGGL((render_bwd_gs_kernel<FF, false>), dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); \
-                             else hipLaunchKernelGGL((render_bwd_gs_kernel<FF, true>), dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a); } while (0)
+#define TRASE_BWD_GS(FF) hipLaunchKernelGGL((render_bwd_gs_kernel<FF, true>), dim3(blocks), dim3(GWPB * WAVE), 0, c.stream, a)
       case 0: TRASE_BWD_GS(0); break;
       case 16: TRASE_BWD_GS(16); break;
       case 32: TRASE_BWD_GS(32); break;

@@ -113,7 +113,7 @@ __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ co
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// COUNT (variant 0x8000, diagnostic): lane utilisation.  Header words 40..47 receive, summed over the launch:
+// COUNT (TRASE_VARIANT_AB_COUNT, `make AB=1` builds only): lane utilisation.  Header words 40..47 receive, summed over the launch:
 //   40 list entries walked (sum of chunk lengths)      41 chunks
 //   42 pixel-pair steps executed (of 16 per chunk)     43 steps skipped by the 4-pixel last-contributor test
 //   44 (pixel, Gaussian) lane slots of executed steps that hold a real list entry
@@ -521,10 +521,13 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
 
 int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const GeomBuf& g,
                          const BinBuf& bb, const ImgBuf& im, const TraseRastGrads& gr, float* rows, uint8_t* row_flags,
-                         void* chan, size_t flag_bytes, const float* out_depth) {
+                         size_t flag_bytes, const float* out_depth) {
   BwdHwArgs a;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg; a.out_depth = out_depth;
-  a.order_mode = (c.variant & 0x40000) ? 0 : ((c.variant & 0x80000) ? 8 : 16);
+  a.order_mode = 16;
+#ifdef TRASE_AB
+  a.order_mode = (c.variant & TRASE_VARIANT_AB_ORDER_IMAGE) ? 0 : ((c.variant & TRASE_VARIANT_AB_ORDER_8) ? 8 : 16);
+#endif
   if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && gr.dL_ddepth && !out_depth) {
     set_error("render_bwd: the normalised-depth switch with a depth cotangent needs the forward's depth map (outputs.depth)");
     return TRASE_ERR_INVALID;
@@ -537,15 +540,16 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
-  (void)chan;                                            // (the channel table of the 64-entry-chunk kernel: not used here)
   TRASE_CHECK(hipMemsetAsync(row_flags, 0, flag_bytes, c.stream));
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the flags are cleared)
   {
     ProfScope ps("render_bwd", c.stream);
     const dim3 grid((a.ntiles + HW_WPB - 1) / HW_WPB), block(HW_WPB * WAVE);
-    if (c.variant & 0x400) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);   // feature gradients only
-    else if (c.variant & 0x1000) hipLaunchKernelGGL((render_bwd_hw_kernel<false, true>), grid, block, 0, c.stream, a);   // phase timing
-    else if (c.variant & 0x8000) hipLaunchKernelGGL((render_bwd_hw_kernel<false, false, true>), grid, block, 0, c.stream, a);   // lane-utilisation counters
+    if (c.variant & TRASE_VARIANT_FEATURES_ONLY_BWD) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);
+#ifdef TRASE_AB                                          // diagnostic instantiations: `make AB=1`
+    else if (c.variant & TRASE_VARIANT_AB_TIMING) hipLaunchKernelGGL((render_bwd_hw_kernel<false, true>), grid, block, 0, c.stream, a);        // phase timing
+    else if (c.variant & TRASE_VARIANT_AB_COUNT) hipLaunchKernelGGL((render_bwd_hw_kernel<false, false, true>), grid, block, 0, c.stream, a);  // lane-utilisation counters
+#endif
     else hipLaunchKernelGGL((render_bwd_hw_kernel<false, false>), grid, block, 0, c.stream, a);
   }
   TRASE_POST_LAUNCH("render_bwd", c.stream, c.debug);

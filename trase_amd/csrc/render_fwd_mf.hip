@@ -1,5 +1,5 @@
 // render_fwd_mf.hip -- forward compositing with the 36-channel accumulation on the matrix cores (default for F = 32;
-// render.hip keeps the packed-FP32 formulation for F = 0 / 16 and as the A/B reference, variant bit 0x2000).
+// render.hip keeps the packed-FP32 formulation for F = 0 / 16 and as the cross-check, TRASE_VARIANT_VALU_FORWARD).
 //
 // One WORKGROUP of two waves per 8x8 sub-tile: wave w composites the 32 pixels of rows 4w .. 4w+3, both share one
 // staged copy of the list chunk.  The list is walked front to back in chunks of 64 entries.  The blend
@@ -379,7 +379,10 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
   a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
-  a.order_mode = (c.variant & 0x40000) ? 0 : ((c.variant & 0x80000) ? 8 : 16);
+  a.order_mode = 16;
+#ifdef TRASE_AB
+  a.order_mode = (c.variant & TRASE_VARIANT_AB_ORDER_IMAGE) ? 0 : ((c.variant & TRASE_VARIANT_AB_ORDER_8) ? 8 : 16);
+#endif
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip

@@ -51,7 +51,7 @@ def _fill_weights(tensors, dev, keep, is_blender=False, is_6dof=False) -> "_lib.
     w = _lib.MlpWeights()
     w.D, w.W, w.xyz_multires, w.t_multires = 8, 256, 10, (6 if is_blender else 10)
     w.is_blender, w.is_6dof = int(is_blender), int(is_6dof)
-    w.variant = int(os.environ.get("TRASE_MLP_VARIANT", "0"), 0)
+    w.variant = 0
     for i in range(8):
         wt, bs = P(2 * i), P(2 * i + 1)
         want = (256, _EMB) if i == 0 else ((256, _EMB + 256) if i == 5 else (256, 256))

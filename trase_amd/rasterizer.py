@@ -92,7 +92,10 @@ def set_variant(v: int):
     _Policy.variant = int(v)
 
 
-VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x20000
+# bits of TraseRastSettings.variant (include/trase_rast.h `TraseVariant`)
+VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x20000      # lineage switches
+VARIANT_FEATURES_ONLY_BWD = 0x400                                                       # backward scope
+VARIANT_VALU_BACKWARD, VARIANT_VALU_FORWARD, VARIANT_SLOT_LISTS = 0x40, 0x2000, 0x100000  # cross-check formulations
 
 
 def set_lineage(feats_bg: Optional[float] = None, depth_normalised: bool = False, depth_grad: bool = False):

@@ -32,8 +32,8 @@ def set_backward_scope(scope: str = "all") -> None:
     from . import rasterizer as _r
     if scope not in ("all", "features"):
         raise ValueError("scope must be 'all' or 'features'")
-    v = _r._Policy.variant & ~0x400
-    _r.set_variant(v | (0x400 if scope == "features" else 0))
+    v = _r._Policy.variant & ~_r.VARIANT_FEATURES_ONLY_BWD
+    _r.set_variant(v | (_r.VARIANT_FEATURES_ONLY_BWD if scope == "features" else 0))
 
 
 _FORWARD_SCOPE = "all"
