@@ -205,3 +205,95 @@ def test_overlapped_range_exchange_plus_the_rest_equals_one_allreduce():
     out = mgr.dict()
     mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _algo_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket
+    ok = True
+    results = {}
+    for algo in ("allreduce", "rs_ag", "direct"):
+        torch.manual_seed(0)
+        # sizes that do not divide by the world size or by 64: the padded shards must not leak into / lose payload
+        params = [torch.randn(37, 3, requires_grad=True), torch.randn(37, 1, 32, requires_grad=True), torch.randn(5, 7, requires_grad=True)]
+        bucket = FlatGradBucket(params, exchange=algo)
+        bucket.zero()
+        # integer-valued gradients: the sums are exact in any order, so the three algorithms must agree BIT FOR BIT
+        loss = sum((p.detach().mul(8).round() * p).sum() * float(rank + 1) for p in params)
+        loss.backward()
+        bucket.allreduce()
+        results[algo] = bucket.flat.clone()
+        want = torch.cat([(p.detach().mul(8).round() * float(sum(range(1, world + 1)))).reshape(-1) for p in params])
+        ok = ok and torch.equal(bucket.flat, want)
+        ok = ok and all(bucket._owns(p.grad) for p in params)
+        # the padding behind the payload took part in the shards: it must still be zeros
+        ok = ok and float(bucket._store[bucket.numel:].abs().max()) == 0.0
+    ok = ok and torch.equal(results["allreduce"], results["rs_ag"]) and torch.equal(results["allreduce"], results["direct"])
+    # replicas hold identical bytes after the direct exchange (each shard is summed by ONE rank, then distributed)
+    mine = results["direct"].clone()
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    ok = ok and all(torch.equal(o, mine) for o in other)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_and_direct_exchange_equal_the_plain_allreduce():
+    """the exchange step is selectable -- one all-reduce, reduce-scatter + all-gather on the padded flat
+    bucket, or the same two phases as grouped point-to-point transfers to every peer at once (all seven xGMI links of a
+    GPU busy instead of a ring's one).  All three must produce the same sums; world size 3 so that the shards are ragged."""
+    world = 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_algo_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True, 2: True}
+
+
+def test_exchange_model_and_chunk_recommendation():
+    from trase_amd.dp import exchange_model_ms, recommended_chunks
+    b = 300_000 * 364                                   # S4 bucket, every parameter: 109 MB
+    ring, direct = exchange_model_ms(b, 8, "ring"), exchange_model_ms(b, 8, "direct")
+    assert direct < ring / 3 and exchange_model_ms(b, 1, "ring") == 0.0
+    assert 0.3 < direct < 0.7 and 2.0 < ring < 4.0      # ms, from the link figures of SURVEY.md section 5
+    assert recommended_chunks(b, 8, "direct") >= 2      # longer than the backward's tail: overlap pays
+    assert recommended_chunks(1 << 20, 8, "direct") == 1
+
+
+def test_inplace_accumulation_into_another_slice_does_not_trip_the_overlap_check():
+    """all views of one flat tensor share ONE version counter, so an `extra` parameter (the deformation
+    MLP) accumulating in place into ITS bucket slice after the fused backward used to look like a modification of every
+    range-exchanged gradient.  The slices now count their own writes: no spurious error; a real in-place write to an
+    exchanged slice still raises."""
+    from trase_amd.dp import FlatGradBucket
+    torch.manual_seed(2)
+    P = 128
+    gauss = [torch.randn(P, 3, requires_grad=True), torch.randn(P, 1, 32, requires_grad=True)]
+    extra = [torch.randn(9, 4, requires_grad=True)]
+    bucket = FlatGradBucket(gauss + extra)
+    kw = bucket.overlapped(2, force_collectives=False)
+    bucket._collectives_on = lambda: True                # single process: pretend the ranges are being exchanged
+    bucket._reduce_many = staticmethod(lambda tensors: [])
+    bucket._exchange_flat = lambda: None
+    import trase_amd.dp as dp_mod
+    for p in gauss:
+        p.grad = None
+    # the extra parameter keeps its attached bucket view: autograd accumulates into it IN PLACE
+    extra[0].grad.zero_()
+    loss = _WritesIntoSinkInRanges.apply(kw, 1.0, *gauss) + (extra[0] * extra[0]).sum()
+    loss.backward()
+    (extra[0].sum()).backward()                          # a second in-place accumulation into the extra's slice, after the hand-off
+    bucket.allreduce()                                   # must NOT raise
+    assert torch.allclose(extra[0].grad, 2 * extra[0].detach() + 1)
+    # ... whereas touching an exchanged gradient after its ranges left does raise
+    for p in gauss:
+        p.grad = None
+    loss = _WritesIntoSinkInRanges.apply(kw, 1.0, *gauss)
+    loss.backward()
+    gauss[0].grad.add_(1.0)
+    try:
+        bucket.allreduce()
+        raise AssertionError("an in-place write to an exchanged gradient must raise")
+    except RuntimeError as e:
+        assert "modified in place" in str(e)

@@ -17,6 +17,46 @@ import torch
 GAUSSIAN_STATE_ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 FEATURE_STATE_ATTRS = ("_gaussian_features",)
 
+# ---- the exchange step as a design ------------------------------------------------------------------------------------
+# MI355X: every GPU of a node has ONE xGMI link to each of the other seven (7 links x ~153.6 GB/s
+# bidirectional, i.e. ~76.8 GB/s per direction per link).  A ring all-reduce moves 2 (W-1)/W of the bucket over ONE link
+# per GPU at a time; the direct algorithms (every rank reduces its own 1/W shard from W-1 peers at once, then hands the
+# shard to W-1 peers at once) move (W-1)/W of the bucket per phase spread over W-1 links.
+XGMI_LINK_GBS_PER_DIR = 76.8
+XGMI_LINK_EFFICIENCY = 0.8          # achievable fraction of the link rate for MB-sized messages (assumption, unmeasured here)
+COLLECTIVE_LATENCY_MS = 0.02        # launch + handshake of one collective (assumption)
+EXCHANGE_ALGOS = ("allreduce", "rs_ag", "direct")
+
+
+def exchange_model_ms(nbytes: int, world: int, algo: str = "direct") -> float:
+    """Predicted duration of one gradient exchange of `nbytes` over `world` GPUs of one xGMI node (see the constants above;
+    UNMEASURED on multi-GPU hardware -- profiles/r4_scaling_model.json tabulates it).  "ring": what a ring all-reduce or a
+    ring reduce-scatter + ring all-gather costs; "direct": both phases over all W-1 links at once."""
+    if world <= 1:
+        return 0.0
+    link = XGMI_LINK_GBS_PER_DIR * XGMI_LINK_EFFICIENCY * 1e9
+    shard = nbytes / world
+    if algo in ("ring", "allreduce", "rs_ag"):
+        # 2 (W-1) steps, each moving one shard over one link per GPU
+        return 2 * (world - 1) * (shard / link * 1e3 + COLLECTIVE_LATENCY_MS / (world - 1)) 
+    if algo == "direct":
+        # 2 phases, each moving one shard over each of the W-1 links concurrently
+        return 2 * (shard / link * 1e3 + COLLECTIVE_LATENCY_MS)
+    raise ValueError(algo)
+
+
+def recommended_chunks(nbytes: int, world: int, algo: str, tail_ms: float = 0.18, chunk_cost_ms: float = 0.027, max_chunks: int = 4) -> int:
+    """How many Gaussian-index ranges the overlapped exchange should use: ranges only pay where the modelled exchange is
+    longer than what they cost (every extra range adds ~0.027 ms of kernel ramp / tail at S4, measured at N = 1) and can
+    hide at most (K-1)/K of the backward's per-Gaussian tail (reduce_rows + preprocess_bwd, ~0.18 ms at S4)."""
+    t = exchange_model_ms(nbytes, world, algo)
+    best, best_gain = 1, 0.0
+    for k in range(2, max_chunks + 1):
+        gain = min(t, tail_ms) * (k - 1) / k - chunk_cost_ms * (k - 1)
+        if gain > best_gain:
+            best, best_gain = k, gain
+    return best
+
 
 class FlatGradBucket:
     """Makes ``.grad`` of every parameter a view into one contiguous buffer, so that the step ends
@@ -33,34 +73,49 @@ class FlatGradBucket:
     that received NO gradient has its slice zeroed instead of reducing stale bytes.  When the parameter set itself changed
     (densify / prune replaces every nn.Parameter) it raises: build a new bucket (``for_state``)."""
 
-    def __init__(self, params: Iterable[torch.Tensor]):
+    PAD = 64 * 64       # slack behind the payload: shards of any world size <= 64 can be rounded up to 64 floats
+
+    def __init__(self, params: Iterable[torch.Tensor], exchange: str = "allreduce"):
         self.params: List[torch.Tensor] = list(params)
         assert self.params, "no parameters"
+        if exchange not in EXCHANGE_ALGOS:
+            raise ValueError(f"exchange must be one of {EXCHANGE_ALGOS}")
+        self.exchange = exchange
+        self.time_exchange = False          # record HIP events around the collective(s) of allreduce()
+        self.last_exchange_ms: Optional[float] = None
+        self._ev = None
         dev, dt = self.params[0].device, self.params[0].dtype
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dt)
+        self.numel = sum(p.numel() for p in self.params)
+        self._store = torch.zeros(self.numel + self.PAD, device=dev, dtype=dt)
+        self.flat = self._store[:self.numel]
         self._shapes = [tuple(p.shape) for p in self.params]
         self._refs = [weakref.ref(p) for p in self.params]
         self._views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
+            # NOT a view of self.flat: a tensor of its own on the same storage.  Views of one base share ONE version counter
+            # (an in-place write through any of them -- AccumulateGrad into another parameter's slice, flat.zero_() -- bumps
+            # all), which made the overlapped exchange's modified-after-hand-off check fire spuriously; tensors made with
+            # set_() alias the bytes but count their own in-place writes.
+            v = torch.empty(0, device=dev, dtype=dt).set_(self._store.untyped_storage(), off, tuple(p.shape))
             self._views.append(v)
             p.grad = v
             off += p.numel()
 
     @classmethod
-    def for_state(cls, pc, state: str, extra: Optional[Iterable[torch.Tensor]] = None) -> "FlatGradBucket":
+    def for_state(cls, pc, state: str, extra: Optional[Iterable[torch.Tensor]] = None, exchange: str = "allreduce") -> "FlatGradBucket":
         """Bucket over what the given optimisation state trains (``"GAUSSIAN"`` / ``"FEATURE"``,
         scene/gaussian_model.py:303-315) plus ``extra`` (e.g. the deformation MLP's parameters)."""
         attrs = {"GAUSSIAN": GAUSSIAN_STATE_ATTRS, "FEATURE": FEATURE_STATE_ATTRS}[state.upper()]
-        return cls([getattr(pc, a) for a in attrs] + list(extra or []))
+        return cls([getattr(pc, a) for a in attrs] + list(extra or []), exchange=exchange)
 
     @property
     def bytes_per_step(self) -> int:
         return self.flat.numel() * self.flat.element_size()
 
     def zero(self):
-        self.flat.zero_()
+        for v in self._views:      # through the parameters' own tensors: their version counters see it
+            v.zero_()
 
     def sink(self):
         """{id(param): (weakref(param), view of its slice)} for ``trase_amd.renderer.set_grad_sink``.  Keyed by the
@@ -172,8 +227,13 @@ class FlatGradBucket:
         self.gather_grads()
         if not self._collectives_on():
             return
+        timed = self.time_exchange and self.flat.is_cuda
+        if timed:
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
         if not done:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self._exchange_flat()
         else:
             # what the ranges did not cover, as maximal contiguous runs of the flat buffer
             runs, off, start = [], 0, None
@@ -189,8 +249,69 @@ class FlatGradBucket:
                 runs.append(self.flat[start:off])
             for w in self._reduce_many(runs):
                 w.wait()
+        if timed:
+            self._ev[1].record()
+            self._timed_pending = True
         if average:
             self.flat.div_(dist.get_world_size())
+
+    def exchange_ms(self) -> Optional[float]:
+        """Duration of the most recent allreduce()'s collectives on the device (HIP events on the current stream, which waits
+        for the process group's stream); needs ``time_exchange = True``.  Synchronises on the end event."""
+        if getattr(self, "_timed_pending", False):
+            self._ev[1].synchronize()
+            self.last_exchange_ms = float(self._ev[0].elapsed_time(self._ev[1]))
+            self._timed_pending = False
+        return self.last_exchange_ms
+
+    # ---- the whole-bucket exchange ------------------------------------------------------------------------------------
+    def _exchange_flat(self):
+        """SUM of the flat bucket over the ranks, by the configured algorithm:
+        "allreduce"  one dist.all_reduce (RCCL picks ring / tree itself);
+        "rs_ag"      reduce_scatter_tensor + all_gather_into_tensor on the padded buffer (each rank reduces 1/W of it);
+        "direct"     the same two phases as grouped point-to-point transfers to / from EVERY peer at once (on RCCL one
+                     ncclGroup per phase = all W-1 xGMI links busy; the shard sums are formed in rank order by ONE rank and
+                     then distributed, so the replicas' results are bit-identical by construction).
+        gloo (the CPU tests) has no reduce_scatter: "rs_ag" takes the point-to-point route there."""
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        if self.exchange == "allreduce" or world == 1 and self.exchange == "direct":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            return
+        shard = (self.numel + world - 1) // world
+        shard = (shard + 63) // 64 * 64
+        assert shard * world <= self._store.numel()
+        buf = self._store[:shard * world]
+        rank = dist.get_rank()
+        mine = buf[rank * shard:(rank + 1) * shard]
+        if self.exchange == "rs_ag" and dist.get_backend() != "gloo":
+            out = torch.empty_like(mine)
+            dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(buf, out)
+            return
+        # phase 1: every rank receives its shard from every peer and sums in rank order
+        tmp = getattr(self, "_tmp", None)
+        if tmp is None or tmp.numel() != shard * world:
+            self._tmp = tmp = torch.empty(shard * world, device=buf.device, dtype=buf.dtype)
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            ops.append(dist.P2POp(dist.isend, buf[peer * shard:(peer + 1) * shard], peer))
+            ops.append(dist.P2POp(dist.irecv, tmp[peer * shard:(peer + 1) * shard], peer))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        tmp[rank * shard:(rank + 1) * shard].copy_(mine)
+        torch.sum(tmp.view(world, shard), dim=0, out=mine)        # fixed (rank) order on the one rank that owns the shard
+        # phase 2: every rank hands its reduced shard to every peer
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            ops.append(dist.P2POp(dist.isend, mine, peer))
+            ops.append(dist.P2POp(dist.irecv, buf[peer * shard:(peer + 1) * shard], peer))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
 
 
 def allreduce_densify_stats(xyz_gradient_accum, denom, max_radii2D):

@@ -38,8 +38,9 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         # one launch per (betas, eps, device) combination: the reference uses a single one
         batches = {}
-        for group in self.param_groups:
-            for p in group["params"]:
+        stepped = []                             # (group index, parameter index) of what this step touches
+        for gi, group in enumerate(self.param_groups):
+            for pi, p in enumerate(group["params"]):
                 if p.grad is None:
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
@@ -55,6 +56,7 @@ class FusedAdam(torch.optim.Optimizer):
                     g = g.float().contiguous()
                 key = (group["betas"], group["eps"], p.device)
                 batches.setdefault(key, []).append((p, g, st, group["lr"]))
+                stepped.append((gi, pi))
         for (betas, eps, dev), items in batches.items():
             d = dev.index if dev.index is not None else torch.cuda.current_device()
             for i in range(0, len(items), 16):
@@ -70,10 +72,13 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(lib.trase_adam_step_guarded(n, P, G, M, V, N, LR, ST, C.c_double(betas[0]), C.c_double(betas[1]),
                                                        float(eps), gp, d, _stream(dev)), "trase_adam_step_guarded")
         if on_overflow is not None:
-            states = [it[2] for items in batches.values() for it in items]
-
             def undo():                  # the device skipped this step: the bias corrections must not count it
-                for st_ in states:
-                    st_["step"] -= 1
+                # looked up NOW, by position: densify / prune may have replaced the parameters and their state dicts between
+                # this step and the report of the overflow
+                for gi_, pi_ in stepped:
+                    if gi_ < len(self.param_groups) and pi_ < len(self.param_groups[gi_]["params"]):
+                        st_ = self.state.get(self.param_groups[gi_]["params"][pi_])
+                        if st_ and "step" in st_ and float(st_["step"]) > 0:
+                            st_["step"] -= 1
             on_overflow(undo)
         return loss

@@ -56,6 +56,8 @@ class _Policy:
     last_geom: Optional[torch.Tensor] = None
     last_bin: Optional[torch.Tensor] = None     # bin workspace of the most recent forward (for last_tile_row_loads)
     last_hw = None
+    last_strip = (0, 0)         # tile-row strip the most recent forward ran with
+    guard_reduced = None        # (id(pinned header), device int32[64]) -- the header MAX-reduced over the ranks (see current_guard)
     last_capacity = 0
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
     rollbacks: dict = {}        # id(pinned header) -> callbacks to run if that forward turns out to have overflowed
@@ -154,8 +156,10 @@ def _header_verdict(h, cap: int, what: str):
         raise RuntimeError(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
                            f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
                            f"has been grown to {_Policy.capacity}.  Guarded consumers of that iteration (FusedAdam.step, "
-                           f"add_densification_stats) skipped it on the device: parameters and moments are unchanged -- "
-                           f"carry on with the next iteration, or re-run this one (or use set_sync(True)).")
+                           f"add_densification_stats) skipped it on the device on every rank (under data parallelism the "
+                           f"flag is MAX-reduced over the ranks first): parameters and moments are unchanged.  Consumers "
+                           f"that are NOT guarded (torch.optim.Adam, your own statistics) have used the incomplete "
+                           f"gradients: re-run the iteration from a checkpoint, or use set_sync(True).")
 
 
 def _poll_pending(block: bool = False):
@@ -190,8 +194,24 @@ def current_guard():
     registers host-side bookkeeping to undo once the overflow is reported."""
     if _Policy.sync or _Policy.last_geom is None or not _Policy.pending:
         return None
-    pin = _Policy.pending[-1][1]
-    return _Policy.last_geom, _Policy.rollbacks.setdefault(id(pin), []).append
+    ev, pin, _cap = _Policy.pending[-1]
+    guard = _Policy.last_geom
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # Data-parallel replicas must take the SAME decision: the gradients every rank applies are the all-reduced ones, so
+        # an overflow on ANY rank contaminates all of them.  The header is MAX-reduced over the ranks once per forward (a
+        # 256-byte collective, stream-ordered, no host synchronisation); the guarded kernels test that copy, and the pinned
+        # host copy the overflow report reads is refreshed from it, so the host-side rollbacks agree across ranks as well.
+        # Every rank calls this the same number of times in the same order (FusedAdam.step / add_densification_stats).
+        red = _Policy.guard_reduced
+        if red is None or red[0] != id(pin):
+            buf = guard[:256].view(torch.int32).clone()
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+            pin.copy_(buf[:32], non_blocking=True)
+            ev.record(torch.cuda.current_stream(guard.device))     # the poll now waits for the reduced copy
+            _Policy.guard_reduced = red = (id(pin), buf)
+        guard = red[1]
+    return guard, _Policy.rollbacks.setdefault(id(pin), []).append
 
 
 def check_overflow():
@@ -233,6 +253,7 @@ def _sizes(lib, P: int, W: int, H: int, F: int, capacity: int):
 def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor] = None, hw=None):
     _Policy.last_geom, _Policy.last_capacity = geom, capacity
     _Policy.last_bin, _Policy.last_hw = binb, hw
+    _Policy.last_strip = tuple(_Policy.tile_rows)
     if not _Policy.sync:
         if _PIN_RING:
             pin, ev = _PIN_RING.pop()
@@ -257,12 +278,21 @@ def last_status():
     return int(st[0]), int(st[1]), int(st[2])
 
 
-def last_tile_row_loads() -> torch.Tensor:
+def last_tile_row_loads(allreduce: bool = False) -> torch.Tensor:
     """Binned (8x8 sub-tile, Gaussian) pairs per ROW of 16x16 tiles of the most recent forward -- what a tile-row strip
     costs to composite.  ``trase_amd.dp.tile_row_partition(H, world, loads=...)`` turns the previous view's loads into a
-    load-balanced partition (consecutive training views see similar loads).  Synchronises (one small D2H copy)."""
+    load-balanced partition (consecutive training views see similar loads).  Synchronises (one small D2H copy).
+
+    The loads must describe the WHOLE image on every rank, or the ranks compute different partitions (gaps / overlaps in
+    ``allgather_strips``).  A forward that ran under ``tile_rows`` binned only its own strip: then pass ``allreduce=True``
+    (the ranks' strips are disjoint, their loads are SUMMED over the process group -- every rank must call it), otherwise
+    this raises."""
     if _Policy.last_bin is None or _Policy.last_hw is None:
         raise RuntimeError("no forward has run yet")
+    if _Policy.last_strip != (0, 0) and not allreduce:
+        raise RuntimeError(f"last_tile_row_loads: the last forward rendered only the tile rows {_Policy.last_strip}; its loads "
+                           "cover that strip alone.  Take the loads from a whole-image forward, or pass allreduce=True to sum "
+                           "the ranks' strips")
     H, W = _Policy.last_hw
     gx8, gy8 = (W + 7) // 8, (H + 7) // 8
     cap = int(_Policy.last_capacity)
@@ -271,7 +301,12 @@ def last_tile_row_loads() -> torch.Tensor:
     per_sub_row = (rng[..., 1] - rng[..., 0]).clamp_min(0).sum(dim=1)
     if gy8 % 2:
         per_sub_row = torch.cat([per_sub_row, per_sub_row.new_zeros(1)])
-    return per_sub_row.reshape(-1, 2).sum(dim=1).cpu()
+    loads = per_sub_row.reshape(-1, 2).sum(dim=1)
+    if allreduce and _Policy.last_strip != (0, 0):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(loads, op=dist.ReduceOp.SUM)
+    return loads.cpu()
 
 
 def geom_view(geom: torch.Tensor, P: int) -> dict:
