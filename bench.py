@@ -139,11 +139,18 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference's PyTorch prep ops around GaussianRasterizer instead of the fused render()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange-chunks", type=int, default=1,
+    ap.add_argument("--exchange-chunks", type=int, default=0,
                     help="Gaussian-index ranges of the overlapped gradient exchange (sink bucket): the all-reduce of a range "
-                         "starts while the backward's per-Gaussian tail is still computing the next one; 1 (default) = one "
-                         "all-reduce after the backward.  Every extra range costs ~0.025 ms of kernel ramp/tail at S4 "
-                         "(measured at N=1), so this only pays where the exchange is long compared with that")
+                         "starts while the backward's per-Gaussian tail is still computing the next one; 1 = one all-reduce "
+                         "after the backward; 0 (default) = chosen from the exchange model (trase_amd.dp.recommended_chunks: "
+                         "ranges whenever the modelled exchange is longer than they cost -- every extra range costs ~0.027 ms "
+                         "of kernel ramp/tail at S4, measured at N=1)")
+    ap.add_argument("--exchange", choices=["allreduce", "rs_ag", "direct"], default="allreduce",
+                    help="algorithm of the gradient exchange (trase_amd.dp.FlatGradBucket): one RCCL all-reduce (default; RCCL "
+                         "picks ring / tree), reduce-scatter + all-gather on the padded flat bucket, or the same two phases as "
+                         "grouped point-to-point transfers to every peer at once (all seven xGMI links of a GPU busy)")
+    ap.add_argument("--no-iteration-window", action="store_true",
+                    help="skip the secondary window (SURVEY.md 8d: whole GAUSSIAN- / FEATURE-state iterations, `iteration_ms`)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N=1 only: create a one-rank RCCL process group and issue the exchange collectives anyway")
     ap.add_argument("--bucket", choices=["auto", "sink", "accumulate"], default="auto",
@@ -219,9 +226,15 @@ def main():
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
     # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
-    bucket = FlatGradBucket(params) if (world > 1 or args.bucket != "auto") else None
+    bucket = FlatGradBucket(params, exchange=args.exchange) if (world > 1 or args.bucket != "auto" or args.force_collectives) else None
     if bucket is not None:
         bucket._force = bool(args.force_collectives)      # one-rank RCCL group: issue the collectives anyway
+        bucket.time_exchange = True                       # HIP events around the collective(s): `exchange_ms` of the bench line
+        if args.exchange_chunks == 0:
+            from trase_amd.dp import recommended_chunks
+            args.exchange_chunks = recommended_chunks(bucket.bytes_per_step, max(world, 1), "direct" if args.exchange == "direct" else "ring") \
+                if (world > 1 and args.shard == "views") else 1
+    args.exchange_chunks = max(args.exchange_chunks, 1)
     use_sink = bucket is not None and not args.unfused and args.bucket != "accumulate"
     if use_sink:
         # the fused backward writes every gradient once, straight into the bucket: no zero-fill, no accumulation pass
@@ -395,6 +408,7 @@ def main():
     t1 = time.perf_counter()
     prof = R.profile_report()
     R.profile_enable(0)
+    exchange_ms = bucket.exchange_ms() if bucket is not None else None      # the last timed step's collective(s)
     status = R.last_status()
     assert status[1] == 0, "pair buffer overflowed inside the timed region; result invalid"
     elapsed = t1 - t0
@@ -406,14 +420,46 @@ def main():
     views_per_s = (1 if tiles_mode else world) * args.steps / elapsed     # tiles mode: the whole job renders ONE view per step
     log(f"timed: {ms_per_step:.3f} ms/step, {views_per_s:.1f} views/s")
 
-    breakdown = None
+    breakdown, launches = None, None
     if args.kernel_breakdown or True:
         R.profile_enable(1)
-        for i in range(min(4, n_views)):
+        nb = min(4, n_views)
+        for i in range(nb):
             step(i)
         torch.cuda.synchronize()
-        breakdown = {k: round(v["ms"] * v["n"] / min(4, n_views), 4) for k, v in R.profile_report().items()}
+        rep_ = R.profile_report()
+        breakdown = {k: round(v["ms"] * v["n"] / nb, 4) for k, v in rep_.items()}
+        # kernel launches per view of the library's own launch sequences (one profiling scope = one launch, except scan_tiles
+        # = 2); memsets and the torch-side kernels of the wrapper are not counted
+        per_scope = {k: (2 if k == "scan_tiles" else 1) * v["n"] / nb for k, v in rep_.items()}
+        chain = ("radix_hist", "radix_scan", "radix_scatter", "depth_sort", "emit_pairs", "scan_tiles", "tile_ranges")
+        launches = {"binning_chain": round(sum(v for k, v in per_scope.items() if k in chain), 2),
+                    "all_kernels": round(sum(per_scope.values()), 2)}
         R.profile_enable(0)
+
+    # ---- secondary window: whole training iterations, iter_start -> iter_end of train.py:157-303 -------
+    iteration_ms = None
+    if world == 1 and not tiles_mode and not args.no_iteration_window and not args.unfused and (N, W, H, F) == (300_000, 1920, 1080, 32):
+        try:
+            from trase_amd.bench_iterations import make_feature_iteration, make_gaussian_iteration, time_iterations
+            log("secondary window: 8 GAUSSIAN-state + 8 FEATURE-state iterations ...")
+            cams8 = cams_dev[::2]
+            it_g = make_gaussian_iteration(pc, cams8, W, H, device)
+            t_g = time_iterations(it_g, iters=8, warm=3)
+            it_f, restore = make_feature_iteration(pc, cams8, W, H, device)
+            try:
+                t_f = time_iterations(it_f, iters=8, warm=3)
+            finally:
+                restore()
+            iteration_ms = {"gaussian": round(t_g, 3), "feature": round(t_f, 3),
+                            "what": "one whole training iteration without the optimizer step (train.py:157-303), all-HIP path: "
+                                    "GAUSSIAN state = deformation MLP with gradients + render() (image scope) + L1/SSIM + backward; "
+                                    "FEATURE state = MLP under no_grad + render(KNN-smoothed normalised features) + contrastive "
+                                    "head on 100 masks / 5000 sampled pixels + backward; 8 iterations each after 3 warm-ups"}
+            for p_ in params:
+                p_.grad = None
+        except Exception as e:                                  # the headline line must not depend on the secondary window
+            iteration_ms = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         r_used = sum(r_list[i % n_views] for i in range(args.steps)) / args.steps
@@ -451,7 +497,8 @@ def main():
                        else f"views/sec (fwd+bwd), {W}x{H}, {N} Gaussians, {F}-d feat") + (", one view tile-row sharded over the ranks" if tiles_mode else ""),
             "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None,
+            "dtype": "f32 (channel contractions: 3-product bf16-split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{'S4 headline' if (N, W, H, F) == (300_000, 1920, 1080, 32) else 'custom'}: {N} Gaussians, {W}x{H}, F={F}, SH deg 3, one view per step per GPU"
                                    + (", view-DP + RCCL all-reduce of Gaussian grads" if (world > 1 and not tiles_mode) else "")
                                    + (f", ONE view per step sharded by load-balanced tile-row strips {strip['part']}, RGB strips all-gathered, "
@@ -462,6 +509,9 @@ def main():
                        "graph_replay": (R.graph_stats() if args.graph else None),
                        "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
                                 else "gaussian_renderer.render() drop-in, A1 prep fused",
+                       "bucket_bytes": (None if bucket is None else bucket.bytes_per_step),
+                       "exchange_ms": (None if exchange_ms is None else round(exchange_ms, 4)),
+                       "exchange_algo": (None if bucket is None else args.exchange),
                        "exchange": (None if bucket is None else
                                     f"flat bucket {bucket.bytes_per_step} B/step, "
                                     + ("zero + accumulate" if not use_sink else
@@ -475,7 +525,15 @@ def main():
                          "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": int(a_bytes),
                          "view_frac": round(view_bytes(N, r_used, P, F) * views_per_s / (1 if tiles_mode else world) / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms_per_view": breakdown,
+            "launches_per_view": launches,
+            "iteration_ms": iteration_ms,
         }
+        if breakdown and breakdown.get("render_bwd") and breakdown.get("reduce_rows") and dom == "render_bwd":
+            # SURVEY 8(d) charges the per-Gaussian gradient write to the backward compositing; in this design reduce_rows does
+            # that write (and re-reads the per-pair rows): backward compositing as 8(d) defines it = render_bwd + reduce_rows
+            both_ms = breakdown["render_bwd"] + breakdown["reduce_rows"]
+            out["roofline"]["backward_frac"] = round(a_bytes / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            out["roofline"]["backward_ms"] = round(both_ms, 4)
         if world == 1 and not args.no_cpu_baseline:
             host = os.cpu_count() or 1
             # the reference's Python preprocess is a chain of small elementwise torch ops: with one thread per core of a

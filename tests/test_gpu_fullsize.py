@@ -171,6 +171,34 @@ def test_mfma_backward_matches_fp32_valu_backward_full_size(monkeypatch):
         assert torch.equal(grads["mfma"][k], grads["mfma2"][k]), f"{k}: MFMA backward is not bit-reproducible"
 
 
+def test_image_only_mfma_backward_matches_fp32_valu_backward_full_size():
+    """A GAUSSIAN-state iteration back-propagates an image-only loss (train.py:235-243, :299): no feature cotangent.  That
+    call takes the image-only scope of the MFMA backward (render_bwd_hw.hip: GEMM 1 over channels 32..35 only, 12-column
+    gradient rows); at the headline size every gradient must agree with the packed-FP32 kernel (TRASE_VARIANT_VALU_BACKWARD)
+    to 5e-5 of its scale, be bit-reproducible, and the feature gradient must be exactly zero."""
+    from trase_amd import rasterizer as R
+    act, cam, dev, settings_for = _setup(300_000, 1920, 1080)
+    st = settings_for(cam, bg=(0.2, 0.4, 0.6), device=dev)
+    torch.manual_seed(6)
+    g_img = torch.randn(3, 1080, 1920, device=dev)
+    grads = {}
+    try:
+        for name, var in (("valu", 0x40), ("mfma", 0), ("mfma2", 0)):
+            R.set_variant(var)
+            (img, radii, feats, depth), a, m2d = _render(act, st, need_grad=True)
+            torch.autograd.backward([img], [g_img])
+            grads[name] = {k: v.grad.clone() for k, v in a.items() if v.grad is not None}
+            grads[name]["means2D"] = m2d.grad.clone()
+    finally:
+        R.set_variant(0)
+    assert float(grads["mfma"]["sh_objs"].abs().max()) == 0.0
+    for k, ref in grads["valu"].items():
+        scale = float(ref.abs().max())
+        err = float((grads["mfma"][k] - ref).abs().max())
+        assert err <= 5e-5 * scale + 0.0, f"{k}: max abs diff {err:.3e} vs scale {scale:.3e}"
+        assert torch.equal(grads["mfma"][k], grads["mfma2"][k]), f"{k}: image-only MFMA backward is not bit-reproducible"
+
+
 @pytest.mark.parametrize("name,n,w,h,with_mlp,loss", [
     ("config 3: Neu3D size, deform MLP, RGB + features", 1_000_000, 1352, 1014, True, "l1ssim+feat"),
     ("config 4: HyperNeRF size, features + contrastive loss", 300_000, 536, 960, False, "contrastive"),

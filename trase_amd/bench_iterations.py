@@ -1,0 +1,109 @@
+"""The secondary measurement window of SURVEY.md 8(d): one whole training iteration (train.py:157-303, iter_start ->
+iter_end, without the optimizer step) in the two optimisation states, with every piece on the HIP path.  Used by
+bench.py (the `iteration_ms` key of the bench line) and by profiles/bench_iteration*.py (which also time the reference's
+own composition around the same rasterizer operator)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def _small_deform_net(dev):
+    from .synthetic import SynthDeformNetwork
+    net = SynthDeformNetwork().to(dev)
+    with torch.no_grad():                       # small deformations, as after the warm-up of the reference
+        for m in (net.gaussian_warp, net.gaussian_rotation, net.gaussian_scaling):
+            m.weight.mul_(0.01)
+            m.bias.zero_()
+    return net
+
+
+def make_gaussian_iteration(pc, cams, W: int, H: int, dev, image_scope: bool = True):
+    """GAUSSIAN state (train.py:196-243, :299): deformation MLP with gradients -> render() -> L1 + SSIM -> backward.
+    image_scope: the state never reads the feature map (train.py:211), so the forward composites colour + depth only
+    (trase_amd.renderer.set_forward_scope("image")) and the backward takes the image-only MFMA scope."""
+    from .deform import DeformNetworkHIP
+    from .losses import l1_ssim
+    from .renderer import render, set_forward_scope
+    from .synthetic import SynthPipe
+    N = pc.get_xyz.shape[0]
+    net = _small_deform_net(dev)
+    hip_net = DeformNetworkHIP(net)
+    params = pc.parameters() + list(net.parameters())
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(7)
+    gts = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(2)]
+    pipe = SynthPipe()
+
+    def it(i):
+        for p in params:
+            p.grad = None
+        cam = cams[i % len(cams)]
+        t = torch.tensor([[float(getattr(cam, "fid", 0.3))]], device=dev).expand(N, -1)
+        d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
+        set_forward_scope("image" if image_scope else "all")
+        try:
+            out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)
+        finally:
+            set_forward_scope("all")
+        l1, ss = l1_ssim(out["render"], gts[i % 2])
+        (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+        return out
+    return it
+
+
+def make_feature_iteration(pc, cams, W: int, H: int, dev, n_masks: int = 100):
+    """FEATURE state (train.py:189-299 after the warm-up): MLP under no_grad -> render(normalised, KNN-smoothed features,
+    smooth_K = 16) -> regulariser + sampling + pair losses + similarities on `n_masks` masks, 5000 sampled pixels ->
+    backward.  Returns (callable, restore): the state trains the features only (scene/gaussian_model.py:303-315);
+    restore() puts requires_grad back."""
+    from .deform import DeformNetworkHIP
+    from .feature_head import contrastive_head, get_sample_pixel_and_mask, mask_stats
+    from .renderer import render
+    from .synthetic import SynthPipe
+    N = pc.get_xyz.shape[0]
+    before = [(p, p.requires_grad) for p in pc.parameters()]
+    for p in pc.parameters():
+        p.requires_grad_(p is pc._gaussian_features)
+    hip_net = DeformNetworkHIP(_small_deform_net(dev))
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(0)
+    sam = torch.zeros(n_masks, H, W, dtype=torch.bool, device=dev)
+    for n in range(n_masks):
+        y0, x0 = int(torch.randint(0, max(H - 50, 1), (1,), generator=g)), int(torch.randint(0, max(W - 50, 1), (1,), generator=g))
+        h, w = int(torch.randint(40, 500, (1,), generator=g)), int(torch.randint(40, 700, (1,), generator=g))
+        sam[n, y0:y0 + h, x0:x0 + w] = True
+    pipe = SynthPipe()
+
+    def it(i):
+        pc._gaussian_features.grad = None
+        cam = cams[i % len(cams)]
+        with torch.no_grad():
+            t = torch.tensor([[float(getattr(cam, "fid", 0.3))]], device=dev).expand(N, -1)
+            d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
+        out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale, norm_gaussian_features=True, is_smooth_gaussian_features=True, smooth_K=16)
+        cover, size = mask_stats(sam)
+        sp, sm = get_sample_pixel_and_mask(sam, 5000, 50, cover_count=cover, rng="cuda")
+        lp, ln, ps, ns, reg = contrastive_head(out["render_gaussian_features"], sam, sp, sm, "soft", 0.75, 0.5, mask_size=size,
+                                               with_norm_reg=True)
+        (lp + ln + 1.0 * reg).backward()
+        return out
+
+    def restore():
+        for p, rg in before:
+            p.requires_grad_(rg)
+    return it, restore
+
+
+def time_iterations(fn, iters: int = 8, warm: int = 3) -> float:
+    """ms per iteration (host clock around `iters` calls, device synchronised on both sides)."""
+    import time
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3

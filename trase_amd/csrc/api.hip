@@ -441,7 +441,8 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
   if (zero_feats) TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
   // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
   // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
-  if (in2.F == 32 && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+  // F == 0 here also means "no feature cotangent" (GAUSSIAN-state iterations): the MFMA kernel's image-only scope
+  if ((in2.F == 32 || in2.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
     rc = launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
   } else {
     TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
@@ -554,7 +555,7 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
   if (phase & 1) {
     if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0)
       TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
-    if (in.F == 32 && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+    if ((in.F == 32 || in.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
       rc = launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
     } else {
       TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));

@@ -33,6 +33,7 @@ constexpr int HW_WPB = 2;     // waves (sub-tiles) per workgroup
 constexpr int HW_LD = 40;     // LDS row pitch in bf16 (80 B)
 constexpr int HW_G = 32;      // list entries per chunk
 
+template <int LD>
 struct HwWaveLds {
   // Pixel-major cotangent image, hi and lo bf16 halves, pitch 40: 36 channels + 4 columns that only pad the row to 16 bytes.
   // Those padding columns carry the per-pixel scan state, so that a wave's LDS is exactly 10 KB and SIXTEEN waves fit a CU
@@ -41,8 +42,10 @@ struct HwWaveLds {
   //   lo row p, columns 36..37 (4 bytes): n_contrib;  38..39: zero
   // GEMM 1 would multiply them with the B fragment's zeros -- raw fp32 bits are not finite bf16 -- so its last K-step
   // masks those two dwords of its A fragments; GEMM 2 only produces unused output rows from them.
-  __bf16 hi[WAVE * HW_LD];
-  __bf16 lo[WAVE * HW_LD];
+  // IMG_ONLY instantiation (no feature cotangent: GAUSSIAN-state iterations, train.py:235-243): pitch 8 -- columns 0..3 =
+  // channels 32..35 (r g b depth), columns 4..7 = the scan state: 2 KB per wave, the residency is then bound by registers.
+  __bf16 hi[WAVE * LD];
+  __bf16 lo[WAVE * LD];
 };
 
 struct BwdHwArgs {
@@ -103,6 +106,7 @@ __device__ __forceinline__ void half_scan_add2_out(float a, float b, float& oa, 
 
 // cot^T fragment of one channel column for a K-step (two pixel rows): the lane half h supplies the pixels of columns
 // 4h..4h+3 -- rows base+0..3 (first pixel row) and base+8..11 (second pixel row) of the pixel-major image.
+template <int HW_LD>
 __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ col) {
   const unsigned short* c = reinterpret_cast<const unsigned short*>(col);
   u32x4 r;
@@ -126,6 +130,7 @@ __device__ __forceinline__ bf16x8 gather_column_hw(const __bf16* __restrict__ co
 // 16-bit reads and two packs.  `p` is this lane's chunk address for the K-step's first four pixel rows; the second four
 // are eight rows further on.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int HW_LD>
 __device__ __forceinline__ bf16x8 gather_column_tr(const __bf16* __restrict__ p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
@@ -135,14 +140,21 @@ __device__ __forceinline__ bf16x8 gather_column_tr(const __bf16* __restrict__ p)
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool FEAT_ONLY, bool TIMING, bool COUNT = false>
+// FEAT_ONLY: only dL/dsh_objs (TRASE_VARIANT_FEATURES_ONLY_BWD).  IMG_ONLY: no feature cotangent at all -- the image (and
+// depth) cotangent only, what a GAUSSIAN-state iteration back-propagates (train.py:235-243, :299): GEMM 1 shrinks to its
+// last K-step (channels 32..35), GEMM 2 to channel block 1, a gradient row to its 12 geometry / colour columns.
+template <bool FEAT_ONLY, bool TIMING, bool COUNT = false, bool IMG_ONLY = false>
 #ifndef HW_OCC
 #define HW_OCC 4
 #endif
 __global__ __launch_bounds__(HW_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(HW_OCC, HW_OCC)))
 void render_bwd_hw_kernel(BwdHwArgs a) {
-  constexpr int F = 32, ROW = F + 12;
-  __shared__ __attribute__((aligned(16))) HwWaveLds s_w[HW_WPB];
+  static_assert(!(FEAT_ONLY && IMG_ONLY), "scopes exclude each other");
+  constexpr int F = IMG_ONLY ? 0 : 32;                   // feature columns of a gradient row
+  constexpr int HW_LD = IMG_ONLY ? 8 : trase::HW_LD;     // LDS row pitch (shadows the namespace constant inside the kernel)
+  constexpr int C0 = IMG_ONLY ? 0 : 32;                  // LDS column of channel 32 (r); the scan state sits at C0 + 4
+  constexpr int ST = C0 + 4;
+  __shared__ __attribute__((aligned(16))) HwWaveLds<HW_LD> s_w[HW_WPB];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int g = lane & 31, h = lane >> 5;
@@ -156,7 +168,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   }
   const int tile = ty * a.gx8 + tx;
   const uint2 range = a.ranges[tile];
-  HwWaveLds& L = s_w[wave];
+  HwWaveLds<HW_LD>& L = s_w[wave];
   uint64_t t_mark = 0, t_acc[5] = {0, 0, 0, 0, 0};
   auto tick = [&](int k) { if constexpr (TIMING) { const uint64_t t = __builtin_readcyclecounter(); t_acc[k] += t - t_mark; t_mark = t; } };
   if constexpr (TIMING) t_mark = __builtin_readcyclecounter();
@@ -176,31 +188,35 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     if (inside) {
       Tf = a.final_T[pix];
       last = a.n_contrib[pix];
-      if (a.d_feat) {
+      if constexpr (!IMG_ONLY) {
+        if (a.d_feat) {
 #pragma unroll
-        for (int c = 0; c < F; ++c) v[c] = a.d_feat[(size_t)c * hw + pix];
+          for (int c = 0; c < 32; ++c) v[c] = a.d_feat[(size_t)c * hw + pix];
+        }
       }
-      if (a.d_img) { v[F] = a.d_img[pix]; v[F + 1] = a.d_img[hw + pix]; v[F + 2] = a.d_img[2 * hw + pix]; }
-      if (a.d_depth) v[F + 3] = a.d_depth[pix];
+      if (a.d_img) { v[C0] = a.d_img[pix]; v[C0 + 1] = a.d_img[hw + pix]; v[C0 + 2] = a.d_img[2 * hw + pix]; }
+      if (a.d_depth) v[C0 + 3] = a.d_depth[pix];
     }
     // Lineage switches: an output of the form X + T_final * b contributes b * cotangent to the pixel's "background" sum.
     float bextra = 0.f;
-    if (a.lineage & TRASE_VARIANT_FEATS_BG) {
-      float sf = 0.f;
+    if constexpr (!IMG_ONLY) {
+      if (a.lineage & TRASE_VARIANT_FEATS_BG) {
+        float sf = 0.f;
 #pragma unroll
-      for (int c = 0; c < F; ++c) sf += v[c];
-      bextra = a.feat_bg * sf;
+        for (int c = 0; c < 32; ++c) sf += v[c];
+        bextra = a.feat_bg * sf;
+      }
     }
     if ((a.lineage & TRASE_VARIANT_DEPTH_NORM) && a.d_depth && inside) {
       // depth_out = D / A, A = 1 - T_final:  dL/dD = g / A,  d depth_out / d T_final = D / A^2 = depth_out / A
-      const float A = 1.0f - Tf, gd = v[F + 3];
+      const float A = 1.0f - Tf, gd = v[C0 + 3];
       const float ga = A > 1e-10f ? gd / A : 0.0f;
-      v[F + 3] = ga;
+      v[C0 + 3] = ga;
       bextra = fmaf(ga, a.out_depth[pix], bextra);
     }
     __bf16* rh = L.hi + lane * HW_LD;
     __bf16* rl = L.lo + lane * HW_LD;
-    const float bdot = a.bg[0] * v[F] + a.bg[1] * v[F + 1] + a.bg[2] * v[F + 2] + bextra;
+    const float bdot = a.bg[0] * v[C0] + a.bg[1] * v[C0 + 1] + a.bg[2] * v[C0 + 2] + bextra;
 #pragma unroll
     for (int c8 = 0; c8 < HW_LD / 8; ++c8) {
       bf16x8 hi, lo;
@@ -240,7 +256,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   // 16 * ((lane >> 4) & 1) + 4 * (lane & 3) of the block; block 1 only has the chunks 32..35 and 36..39 (zeros)
   const int trrow = ((lane & 15) >> 2) * HW_LD;
   const int tr0 = trrow + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int tr1 = trrow + min(32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3), HW_LD - 4);
+  const int tr1 = trrow + min(C0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3), HW_LD - 4);
   tick(0);
   // The list entries of a chunk are requested one chunk ahead (two registers): one level less in the dependent chain
   // entry -> geometry / channel rows at a chunk start.
@@ -263,8 +279,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
   auto store_pending = [&]() {
     if (pend.write) {
       float* row = a.rows + (size_t)pend.slot * bwd_row_stride(F);
+      if constexpr (!IMG_ONLY) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = pend.d[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = pend.d[q];
+      }
       if (h == 0) {
         *reinterpret_cast<float4*>(row + F) = pend.m[0];
         *reinterpret_cast<float4*>(row + F + 4) = pend.m[1];
@@ -297,7 +315,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     const uint32_t* const frow = a.ftab + (size_t)id * 32 + 4 * h;   // this lane's B fragments of GEMM 1: bf16 [hi 32 | lo 32]
     const float4 cs = a.geo[4 * (size_t)id + 3];                     // ... and colour + depth, split the same way
     bf16x8 fbh[2], fbl[2];                                           // (requested here, ahead of the pending row stores)
-    if constexpr (!FEAT_ONLY) {
+    if constexpr (!FEAT_ONLY && !IMG_ONLY) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         fbh[ks] = *reinterpret_cast<const bf16x8*>(frow + ks * 8);
@@ -322,7 +340,7 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     f32x16 Sm[2];
     if constexpr (!FEAT_ONLY) {
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
+      for (int ks = IMG_ONLY ? 2 : 0; ks < 3; ++ks) {
         bf16x8 bh, bl;
         if (ks < 2) {
           bh = fbh[ks]; bl = fbl[ks];
@@ -340,12 +358,19 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           } else {
             // channels 32..39 (h = 0: the state dwords are masked) / 40..47 (h = 1: the next pixel row's first eight columns,
             // multiplied by the B fragment's zeros; the last row of the image reads its own first columns instead)
-            const int off = (mb == 1 && lane == 63) ? 63 * HW_LD : (mb * 32 + g) * HW_LD + 32 + 8 * h;
+            // (IMG_ONLY, pitch 8: every lane reads its pixel's own 16 bytes; the half h = 1 -- channels 40..47, which do not
+            // exist -- and the state dwords are zeroed: the next row's first columns would be ITS state words there)
+            const int off = IMG_ONLY ? (mb * 32 + g) * HW_LD : ((mb == 1 && lane == 63) ? 63 * HW_LD : (mb * 32 + g) * HW_LD + C0 + 8 * h);
             u32x4 rh4 = *reinterpret_cast<const u32x4*>(ahi + off), rl4 = *reinterpret_cast<const u32x4*>(alo + off);
-            rh4[2] &= hmask; rh4[3] &= hmask; rl4[2] &= hmask; rl4[3] &= hmask;
+            if constexpr (IMG_ONLY) {
+              rh4[0] &= ~hmask; rh4[1] &= ~hmask; rl4[0] &= ~hmask; rl4[1] &= ~hmask;
+              rh4[2] = 0u; rh4[3] = 0u; rl4[2] = 0u; rl4[3] = 0u;
+            } else {
+              rh4[2] &= hmask; rh4[3] &= hmask; rl4[2] &= hmask; rl4[3] &= hmask;
+            }
             ph = __builtin_bit_cast(bf16x8, rh4); pl = __builtin_bit_cast(bf16x8, rl4);
           }
-          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, ks == 0 ? ZERO16 : Sm[mb], 0, 0, 0);
+          Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, ks == (IMG_ONLY ? 2 : 0) ? ZERO16 : Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, Sm[mb], 0, 0, 0);
           Sm[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, Sm[mb], 0, 0, 0);
         }
@@ -370,10 +395,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           if constexpr (COUNT) { if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) cnt[2] += 1; else cnt[3] += 1; }
           if ((uint32_t)__builtin_amdgcn_readlane((int)last4, p0) > c0) {
             const int pl = p0 + 4 * h;                     // this lane's first pixel of the step
-            const float2 pa = *reinterpret_cast<const float2*>(L.hi + pl * HW_LD + 36);          // T_end, U_end
-            const float2 pb = *reinterpret_cast<const float2*>(L.hi + (pl + 1) * HW_LD + 36);
-            const uint32_t lasta = *reinterpret_cast<const uint32_t*>(L.lo + pl * HW_LD + 36);
-            const uint32_t lastb = *reinterpret_cast<const uint32_t*>(L.lo + (pl + 1) * HW_LD + 36);
+            const float2 pa = *reinterpret_cast<const float2*>(L.hi + pl * HW_LD + ST);          // T_end, U_end
+            const float2 pb = *reinterpret_cast<const float2*>(L.hi + (pl + 1) * HW_LD + ST);
+            const uint32_t lasta = *reinterpret_cast<const uint32_t*>(L.lo + pl * HW_LD + ST);
+            const uint32_t lastb = *reinterpret_cast<const uint32_t*>(L.lo + (pl + 1) * HW_LD + ST);
             const float ea = poly_eval(k, base, slope, jv[r]);
             const float eb = poly_eval(k, base, slope, jv[r + 1]);
             const bool oka = (ea <= k.thr) && (ea >= LOG2_ALPHA_MIN) && (pos_cmp < lasta);
@@ -395,8 +420,8 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
             const float wa = ala * Ta, wb = alb * Tb;
             if constexpr (FEAT_ONLY) {
               if (g == HW_G - 1) {
-                *reinterpret_cast<float*>(L.hi + pl * HW_LD + 36) = Ta;
-                *reinterpret_cast<float*>(L.hi + (pl + 1) * HW_LD + 36) = Tb;
+                *reinterpret_cast<float*>(L.hi + pl * HW_LD + ST) = Ta;
+                *reinterpret_cast<float*>(L.hi + (pl + 1) * HW_LD + ST) = Tb;
               }
             } else {
               const float sa = S[4 * q + r], sb = S[4 * q + r + 1];
@@ -406,8 +431,8 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
               const float Ua = pa.y + (ia - wsa), Ub = pb.y + (ib - wsb);
               const float dLa = Ta * sa - Ua * roma, dLb = Tb * sb - Ub * romb;
               if (g == HW_G - 1) {                         // carries for the next (nearer) chunk
-                *reinterpret_cast<float2*>(L.hi + pl * HW_LD + 36) = make_float2(Ta, pa.y + ia);
-                *reinterpret_cast<float2*>(L.hi + (pl + 1) * HW_LD + 36) = make_float2(Tb, pb.y + ib);
+                *reinterpret_cast<float2*>(L.hi + pl * HW_LD + ST) = make_float2(Ta, pa.y + ia);
+                *reinterpret_cast<float2*>(L.hi + (pl + 1) * HW_LD + ST) = make_float2(Tb, pb.y + ib);
               }
               const float qa = ra * dLa, qb = rb * dLb;    // == opacity * G * dL/dalpha (straight-through clamp)
               if (r == 0) {                                // local columns jl = 0, 1: weights (1, 0, 0) and (1, 1, 1)
@@ -440,13 +465,13 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
           const int rowoff = ((i >> 1) * 16 + 4 * h) * HW_LD;
           constexpr int NBLK = FEAT_ONLY ? 1 : 2;          // channel block 1 = r g b depth
 #pragma unroll
-          for (int nb = 0; nb < NBLK; ++nb) {
+          for (int nb = IMG_ONLY ? 1 : 0; nb < NBLK; ++nb) {
 #ifdef TRASE_BWD_NO_TR
             const int col = nb == 0 ? col0 : col1;
-            const bf16x8 Ah = gather_column_hw(ahi + rowoff + col), Al = gather_column_hw(alo + rowoff + col);
+            const bf16x8 Ah = gather_column_hw<HW_LD>(ahi + rowoff + col), Al = gather_column_hw<HW_LD>(alo + rowoff + col);
 #else
             const int tro = nb == 0 ? tr0 : tr1;
-            const bf16x8 Ah = gather_column_tr(ahi + rowoff + tro), Al = gather_column_tr(alo + rowoff + tro);
+            const bf16x8 Ah = gather_column_tr<HW_LD>(ahi + rowoff + tro), Al = gather_column_tr<HW_LD>(alo + rowoff + tro);
 #endif
             D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, i == 1 ? ZERO16 : D[nb], 0, 0, 0);
             D[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, D[nb], 0, 0, 0);
@@ -473,8 +498,10 @@ void render_bwd_hw_kernel(BwdHwArgs a) {
     }
     pend.slot = slot; pend.write = write_row;
     // D[0]: lane (g,h), register 4q + r = channel 8q + 4h + r
+    if constexpr (!IMG_ONLY) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pend.d[q] = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
+      for (int q = 0; q < 4; ++q) pend.d[q] = make_float4(D[0][4 * q], D[0][4 * q + 1], D[0][4 * q + 2], D[0][4 * q + 3]);
+    }
     if constexpr (!FEAT_ONLY) {
       // local -> global column index (j = 4h + jl):  sum q j = Sj + 4h S0,  sum q j^2 = Sjj + 8h Sj + 16 h^2 S0,
       // sum q i j = Sij + 4h Si   (h = 0: unchanged)
@@ -545,7 +572,8 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   {
     ProfScope ps("render_bwd", c.stream);
     const dim3 grid((a.ntiles + HW_WPB - 1) / HW_WPB), block(HW_WPB * WAVE);
-    if (c.variant & TRASE_VARIANT_FEATURES_ONLY_BWD) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);
+    if (in.F == 0) hipLaunchKernelGGL((render_bwd_hw_kernel<false, false, false, true>), grid, block, 0, c.stream, a);   // image-only scope
+    else if (c.variant & TRASE_VARIANT_FEATURES_ONLY_BWD) hipLaunchKernelGGL((render_bwd_hw_kernel<true, false>), grid, block, 0, c.stream, a);
 #ifdef TRASE_AB                                          // diagnostic instantiations: `make AB=1`
     else if (c.variant & TRASE_VARIANT_AB_TIMING) hipLaunchKernelGGL((render_bwd_hw_kernel<false, true>), grid, block, 0, c.stream, a);        // phase timing
     else if (c.variant & TRASE_VARIANT_AB_COUNT) hipLaunchKernelGGL((render_bwd_hw_kernel<false, false, true>), grid, block, 0, c.stream, a);  // lane-utilisation counters
