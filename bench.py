@@ -172,6 +172,9 @@ def main():
                          "view per step for the whole job, every rank renders a load-balanced strip of 16x16-tile rows, the RGB "
                          "strips are all-gathered (full-frame style loss) and the strips' partial gradients all-reduced; strong "
                          "scaling; defaults to the S5 size (2.5 M Gaussians, 1280x960) unless sizes are given")
+    ap.add_argument("--dense-strip-grads", action="store_true",
+                    help="tiles mode / strip table: dense per-Gaussian gradients (every row written, zeros included) instead of "
+                         "trase_amd.rasterizer.set_sparse_strip_grads (only the rows of the strip's Gaussians)")
     ap.add_argument("--strip-table", type=str, default="",
                     help="ONE GPU: time every rank's strip (fwd+bwd, load-balanced partition) for world = 1, 2, 4, 8 and write the "
                          "predicted tile-sharding speed-up (communication excluded) to this JSON file; no bench line is printed")
@@ -314,6 +317,9 @@ def main():
     if tiles_mode or args.strip_table:
         from trase_amd import dp
         tiles_mode = True
+        # sparse strip gradients pay where a strip holds a small share of the Gaussians (measured at S5: 45 % of them have a pair
+        # in a half-image strip -- scattered row accesses then lose to the dense kernels; 13 % in an eighth: 1.04 -> 0.93 ms per strip there, but 1.38 -> 1.44 at four strips)
+        R.set_sparse_strip_grads((not args.dense_strip_grads) and world >= 8)
         step_tiles(0, rows=(0, 0))                       # the whole view once: per-tile-row pair loads
         loads = R.last_tile_row_loads()
         full_pairs = R.last_status()[2]
@@ -326,12 +332,16 @@ def main():
         for wsize in (1, 2, 4, 8):
             part = dp.tile_row_partition(H, wsize, loads=loads)
             part_eq = dp.tile_row_partition(H, wsize)
-            rec = {"strips": part, "ms": [], "pairs": [], "equal_rows_strips": part_eq, "equal_rows_ms": []}
+            R.set_sparse_strip_grads((not args.dense_strip_grads) and wsize >= 8)
+            rec = {"strips": part, "ms": [], "pairs": [], "equal_rows_strips": part_eq, "equal_rows_ms": [],
+                   "sparse_strip_grads": bool((not args.dense_strip_grads) and wsize >= 8)}
             for label, pp, dst in (("balanced", part, rec["ms"]), ("equal", part_eq, rec["equal_rows_ms"])):
                 if label == "equal" and (wsize == 1 or pp == part):
                     rec["equal_rows_ms"] = list(rec["ms"])
                     continue
                 for rows in pp:
+                    if wsize == 1:
+                        rows = (0, 0)                # one rank = the whole image, rendered as such (not as a 60-row "strip")
                     R.set_sync(True)
                     caps = []
                     for i in range(min(4, n_views)):

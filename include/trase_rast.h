@@ -91,6 +91,12 @@ typedef enum TraseVariant {
   TRASE_VARIANT_SLOT_LISTS = 0x100000,       /* sub-tile lists always carry emit-order slots (default: packed (id, pair index)
                                               * values whenever every Gaussian has few enough pairs -- decided on the device,
                                               * results identical) */
+  /* -- tile-row strips (tile_row_begin / tile_row_end set) -- */
+  TRASE_VARIANT_SPARSE_STRIP_GRADS = 0x200000, /* trase_rast_backward_raw writes ONLY the gradient rows of the Gaussians that have a
+                                              * pair in the strip (~1 / world of them); the caller guarantees that every other row
+                                              * of the gradient tensors is zero -- persistent tensors, zero-filled once, whose
+                                              * previously written rows trase_rast_zero_live_rows clears.  Default: dense (every
+                                              * row written, zeros included) */
   /* -- diagnostics: compiled only into `make AB=1` builds of the library (-DTRASE_AB), ignored otherwise -- */
   TRASE_VARIANT_AB_TIMING = 0x1000,          /* phase cycle counters of the MFMA backward (geom header words 32..39) */
   TRASE_VARIANT_AB_COUNT = 0x8000,           /* lane-utilisation counters of the MFMA backward (header words 40..47) */
@@ -256,6 +262,11 @@ int trase_rast_graph_stats(int64_t stats[4]);
  * _compose followed by _gaussians over a partition of [0, P) equals trase_rast_backward_raw bit for bit. */
 int trase_rast_backward_raw_compose(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                                     const TraseRastWorkspace* ws, const TraseRastRawGrads* g, trase_stream_t stream);
+/* Sparse strip gradients (TRASE_VARIANT_SPARSE_STRIP_GRADS): sets the rows of every non-NULL gradient tensor in `g` to zero for
+ * the Gaussians that had a pair in the strip of the forward whose `geom` and `pre` workspaces are given -- i.e. exactly the rows
+ * that forward's backward wrote.  Cost: what the strip holds, not what the scene does. */
+int trase_rast_zero_live_rows(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastWorkspace* ws,
+                              const TraseRastRawGrads* g, trase_stream_t stream);
 int trase_rast_backward_raw_gaussians(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                                       const TraseRastWorkspace* ws, const TraseRastRawGrads* g, int32_t p_begin, int32_t p_end,
                                       trase_stream_t stream);

@@ -15,9 +15,12 @@ def _scene(n=6000, w=200, h=150, seed=3, scale_mult=0.9):
     return scene, cam, dev, SynthGaussianModel, SynthPipe
 
 
-@pytest.mark.parametrize("world,size", [(2, "small"), (3, "small"), (4, "S5")], ids=["2", "3", "S5-4-balanced"])
-def test_strips_reassemble_the_full_render(world, size):
-    """size "S5": BASELINE config 5's shape (2.5 M Gaussians, 1280x960), four LOAD-BALANCED strips (unequal heights)."""
+@pytest.mark.parametrize("world,size,sparse", [(2, "small", False), (3, "small", False), (3, "small", True), (4, "S5", False), (4, "S5", True)],
+                         ids=["2", "3", "3-sparse-grads", "S5-4-balanced", "S5-4-balanced-sparse-grads"])
+def test_strips_reassemble_the_full_render(world, size, sparse):
+    """size "S5": BASELINE config 5's shape (2.5 M Gaussians, 1280x960), four LOAD-BALANCED strips (unequal heights).
+    sparse: `set_sparse_strip_grads` -- a strip's backward writes only the rows of the Gaussians with a pair in the strip into
+    persistent zero-elsewhere tensors; consecutive strips exercise the re-zeroing of the previous strip's rows."""
     from gaussian_renderer import render
     from trase_amd import rasterizer as R
     from trase_amd.dp import strip_pixel_rows, tile_row_partition
@@ -36,6 +39,14 @@ def test_strips_reassemble_the_full_render(world, size):
         return out, grads
 
     full, g_full = run((0, 0))
+    R.set_sparse_strip_grads(sparse)
+    try:
+        _check_strips(run, full, g_full, world, size, H, R, tile_row_partition, strip_pixel_rows)
+    finally:
+        R.set_sparse_strip_grads(False)
+
+
+def _check_strips(run, full, g_full, world, size, H, R, tile_row_partition, strip_pixel_rows):
     part = tile_row_partition(H, world)
     if size == "S5":
         loads = R.last_tile_row_loads()

@@ -131,6 +131,8 @@ SYMBOLS = [
                                           C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_void_p]),
     ("trase_rast_backward_raw_compose", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                                   C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_void_p]),
+    ("trase_rast_zero_live_rows", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastWorkspace),
+                                            C.POINTER(RastRawGrads), C.c_void_p]),
     ("trase_rast_backward_raw_gaussians", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                                     C.POINTER(RastWorkspace), C.POINTER(RastRawGrads), C.c_int32, C.c_int32,
                                                     C.c_void_p]),
@@ -212,6 +214,8 @@ def load() -> C.CDLL:
             "There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
+        if os.environ.get("TRASE_RAST_LIB") and os.environ.get("TRASE_RAST_LIB_AB") and not hasattr(lib, name):
+            continue                # an OLDER build loaded for a same-box A/B (both variables set): entry points added since are absent
         fn = getattr(lib, name)     # AttributeError here == header/library mismatch
         fn.restype = restype
         fn.argtypes = argtypes

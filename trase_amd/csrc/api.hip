@@ -238,6 +238,32 @@ static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const
   return check_hip(hipGraphLaunch(exec, stream), "hipGraphLaunch");
 }
 
+// A tile-row strip (second axis) leaves most Gaussians without a pair: their ids are compacted away before the
+// depth sort (binning.hip launch_compact_live), so that the per-Gaussian stages cost what the strip holds, not what the scene does
+static inline bool strip_mode(const TraseRastSettings* s) { return s->tile_row_begin != 0 || s->tile_row_end != 0; }
+
+// depth order of the Gaussians (stable sort of the float32 depth bits; ties keep ascending Gaussian index) + the scan of their
+// sub-tile counts in that order.  `keys` = where the preprocess kernel left the keys (strip mode: the sort's SECOND buffer)
+static int depth_order(const LaunchCtx& c, const TraseRastSettings* s, const GeomBuf& g, const PreBuf& t, int P, const int32_t* radii,
+                       int pack_bits) {
+  int rc, idx = 0;
+  if (strip_mode(s)) {
+    rc = launch_compact_live(c, g, P, t, t.sort.keys[1], t.sort.keys[0], t.sort.vals[0]);
+    if (rc) return rc;
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, 32, false, &idx);
+  } else {
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, 32, true, &idx);   // ids generated on the fly
+  }
+  if (rc) return rc;
+  if (idx != 0) {   // 4 passes: the sorted ids are back in vals[0], where stage 2 reads them
+    set_error("internal: depth sort ended in buffer %d", idx);
+    return TRASE_ERR_INVALID;
+  }
+  // the pair count is compared against the capacity later (stage 2 knows it); 0xffffffff = no limit yet
+  return launch_scan_tiles(c, g, t.sort.vals[0], P, t, 0xffffffffu, radii, (s->image_width + TILE - 1) / TILE,
+                           (s->image_height + TILE - 1) / TILE, pack_bits);
+}
+
 enum { WS_GEOM = 1, WS_PRE = 2, WS_BIN = 4, WS_IMG = 8, WS_TMP = 16 };
 static int check_ws(const TraseRastInputs* in, const TraseRastSettings* s, const TraseRastWorkspace* ws, int need) {
   if (!ws) { set_error("null workspace"); return TRASE_ERR_WORKSPACE; }
@@ -298,19 +324,9 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   PreBuf t = carve_pre(ws->pre, in->P);
   TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
   if (in->P == 0) return TRASE_OK;
-  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[0]);
+  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
   if (rc) return rc;
-  // depth order of the Gaussians: stable sort of float32 depth bits, ids generated on the fly
-  int idx = 0;
-  rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)in->P, 0, 32, true, &idx);
-  if (rc) return rc;
-  if (idx != 0) {   // 4 passes: the sorted ids are back in vals[0], where stage 2 reads them
-    set_error("internal: depth sort ended in buffer %d", idx);
-    return TRASE_ERR_INVALID;
-  }
-  // the pair count is compared against the capacity later (stage 2 knows it); 0xffffffff = no limit yet
-  return launch_scan_tiles(c, g, t.sort.vals[0], in->P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
-                           (s->image_height + TILE - 1) / TILE, list_pack_bits(s, in->P));
+  return depth_order(c, s, g, t, in->P, out->radii, list_pack_bits(s, in->P));
 }
 
 int trase_rast_status(const TraseRastWorkspace* ws, int64_t status[3], trase_stream_t stream_) {
@@ -491,14 +507,9 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   PreBuf t = carve_pre(ws->pre, in.P);
   TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
   if (in.P == 0) return TRASE_OK;
-  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[0]);
+  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
   if (rc) return rc;
-  int idx = 0;
-  rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)in.P, 0, 32, true, &idx);
-  if (rc) return rc;
-  if (idx != 0) { set_error("internal: depth sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
-  return launch_scan_tiles(c, g, t.sort.vals[0], in.P, t, 0xffffffffu, out->radii, (s->image_width + TILE - 1) / TILE,
-                           (s->image_height + TILE - 1) / TILE, list_pack_bits(s, in.P));
+  return depth_order(c, s, g, t, in.P, out->radii, list_pack_bits(s, in.P));
 }
 
 int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
@@ -552,8 +563,10 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
     in.F = 0;
     d_feats = nullptr;
   }
+  // sparse strip gradients: only the rows of the Gaussians with a pair in the strip are written (the caller keeps the others zero)
+  const bool sparse = strip_mode(s) && !ranged && (s->variant & TRASE_VARIANT_SPARSE_STRIP_GRADS) != 0;
   if (phase & 1) {
-    if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0)
+    if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0 && !sparse)
       TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
     if ((in.F == 32 || in.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
       rc = launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
@@ -564,10 +577,15 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
     if (rc) return rc;
   }
   if (phase & 2) {
+    // a tile-row strip: the row reduction walks the Gaussians that have a pair only (their ids were compacted in front of the
+    // depth order); the feature-gradient rows of the others are zeroed by the per-Gaussian kernel, which writes their other
+    // gradients as zeros anyway
+    const int live_only = (strip_mode(s) && !ranged) ? 1 : 0;
     rc = launch_reduce_rows(c, g, pre, in.P, in.F, rows, row_flags, acc, d_feats, raw->gaussian_features, raw->norm_features,
-                            ranged ? p_begin : -1, ranged ? p_end : -1);
+                            ranged ? p_begin : -1, ranged ? p_end : -1, live_only);
     if (rc) return rc;
-    rc = launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr, ranged ? p_begin : 0, ranged ? p_end : raw->P);
+    rc = launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr, ranged ? p_begin : 0, ranged ? p_end : raw->P,
+                                   (live_only && d_feats && !sparse) ? 1 : 0, sparse ? pre.sort.vals[0] : nullptr);
   }
   return rc;
 }
@@ -588,6 +606,19 @@ int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs*
                              if (rc) return rc;
                              return trase_rast_render_raw(s, raw, out, ws, st);
                            });
+}
+
+int trase_rast_zero_live_rows(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastWorkspace* ws,
+                              const TraseRastRawGrads* gr, trase_stream_t stream_) {
+  if (!s || !raw || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  if (!ws->geom || ws->geom_bytes < geom_bytes(raw->P) || !ws->pre || ws->pre_bytes < pre_bytes(raw->P)) {
+    set_error("zero_live_rows: geom / pre workspaces of the forward whose live rows are to be cleared are required");
+    return TRASE_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(s->device));
+  LaunchCtx c{stream, s->debug, s->variant};
+  return launch_zero_live_rows(c, carve_geom(ws->geom, raw->P), carve_pre(ws->pre, raw->P), raw->P, raw->F, *gr);
 }
 
 int trase_rast_backward_raw_compose(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,

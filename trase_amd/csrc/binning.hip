@@ -291,6 +291,94 @@ constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS = 4;
 constexpr int SC_TILE = SC_THREADS * SC_ITEMS;
 
+// ---- compaction of the Gaussians that have a pair (tile-row strips) ---------------------------------------------------
+// A rank that renders one strip of a view (second axis) has pairs for ~1/world of the Gaussians; the depth
+// sort, the scan, emit_pairs and the row reduction then only need THOSE.  Two launches turn the per-Gaussian depth keys into
+// (keys, ids) of the live Gaussians in ascending id order -- a deterministic compaction, so that the stable sort still breaks
+// depth ties by ascending Gaussian index -- followed by the ids without a pair (what "writes every Gaussian" consumers walk
+// behind the live ones).  The live count replaces P in the header word the sort reads its length from.
+__global__ __launch_bounds__(SC_THREADS) void compact_count_kernel(const uint32_t* __restrict__ tiles, int P,
+                                                                   uint32_t* __restrict__ block_cnt) {
+  const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  uint32_t c = 0;
+  if (base + SC_ITEMS <= P) {
+    const uint4 t = *reinterpret_cast<const uint4*>(tiles + base);
+    c = (t.x != 0) + (t.y != 0) + (t.z != 0) + (t.w != 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) c += (base + k < P && tiles[base + k] != 0) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+  __shared__ uint32_t part[SC_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void compact_scatter_kernel(const uint32_t* __restrict__ tiles,
+                                                                     const uint32_t* __restrict__ keys_raw, int P,
+                                                                     const uint32_t* __restrict__ block_cnt, int nblocks,
+                                                                     uint32_t* __restrict__ keys_out,
+                                                                     uint32_t* __restrict__ ids_out,
+                                                                     uint32_t* __restrict__ hdr) {
+  __shared__ uint32_t sh[SC_THREADS / 64];
+  __shared__ uint32_t sh2[SC_THREADS / 64];
+  // live Gaussians in the blocks before this one, and in all blocks
+  uint32_t before = 0, total = 0;
+  for (int b = threadIdx.x; b < nblocks; b += SC_THREADS) {
+    const uint32_t v = block_cnt[b];
+    total += v;
+    before += (b < (int)blockIdx.x) ? v : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { before += (uint32_t)__shfl_xor((int)before, o); total += (uint32_t)__shfl_xor((int)total, o); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = before; sh2[threadIdx.x >> 6] = total; }
+  __syncthreads();
+  before = sh[0] + sh[1] + sh[2] + sh[3];
+  total = sh2[0] + sh2[1] + sh2[2] + sh2[3];
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[HDR_WORDS - 1] = total;       // the depth sort's length: live Gaussians only
+  const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  uint32_t t[SC_ITEMS], k[SC_ITEMS];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < SC_ITEMS; ++j) {
+    const bool in = base + j < P;
+    t[j] = in ? tiles[base + j] : 0u;
+    k[j] = in ? keys_raw[base + j] : 0u;
+    mine += t[j] != 0;
+  }
+  __shared__ uint32_t part[4];
+  const uint32_t incl = block256_incl_scan(mine, part);
+  uint32_t live_before = before + incl - mine;                                 // live Gaussians with a smaller id
+#pragma unroll
+  for (int j = 0; j < SC_ITEMS; ++j) {
+    const int i = base + j;
+    if (i >= P) break;
+    if (t[j] != 0) {
+      keys_out[live_before] = k[j];
+      ids_out[live_before] = (uint32_t)i;
+      ++live_before;
+    } else {
+      ids_out[total + (uint32_t)i - live_before] = (uint32_t)i;               // behind the live ones, ascending
+    }
+  }
+}
+
+int launch_compact_live(const LaunchCtx& c, const GeomBuf& g, int P, const PreBuf& t, const uint32_t* keys_raw,
+                        uint32_t* keys_out, uint32_t* ids_out) {
+  const int nblocks = (P + SC_TILE - 1) / SC_TILE;
+  {
+    ProfScope ps("compact_live", c.stream);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, P, t.block_sums);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, keys_raw, P, t.block_sums,
+                       nblocks, keys_out, ids_out, g.hdr);
+  }
+  TRASE_POST_LAUNCH("compact_live", c.stream, c.debug);
+  return TRASE_OK;
+}
+
 __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* sh /*[SC_THREADS]*/) {
   sh[threadIdx.x] = v;
   __syncthreads();
@@ -314,9 +402,11 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
                                                                   const int32_t* __restrict__ radii,
                                                                   const float2* __restrict__ xy, int gx, int gy,
                                                                   uint32_t* __restrict__ block_R,
-                                                                  uint32_t* __restrict__ block_max) {
+                                                                  uint32_t* __restrict__ block_max,
+                                                                  const uint32_t* __restrict__ n_live_ptr) {
   __shared__ uint32_t sh[SC_THREADS];
   const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+  const int n_live = min(P, (int)*n_live_ptr);              // depth ranks that exist (all of them unless the ids were compacted)
   uint32_t area = 0;
   // every load of the thread is requested before the first is used (a load inside a branch per item was eight dependent round
   // trips; the centre of a culled Gaussian is never written -- whatever is read there is discarded by the select)
@@ -328,7 +418,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
     const int n = blockIdx.x * SC_TILE + i * SC_THREADS + threadIdx.x;     // natural order, coalesced
     rad_[i] = (n < P) ? radii[n] : 0;
     c_[i] = (n < P) ? xy[n] : make_float2(0.f, 0.f);
-    id_[i] = (base + i < P) ? ids[base + i] : 0u;
+    id_[i] = (base + i < n_live) ? ids[base + i] : 0u;
   }
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
@@ -344,7 +434,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int r = base + i;
-    v[i] = (r < P) ? tiles[id_[i]] : 0u;
+    v[i] = (r < n_live) ? tiles[id_[i]] : 0u;
     mx = max(mx, v[i]);
     sum += v[i];
     v[i] = sum;
@@ -366,7 +456,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t
 #pragma unroll
   for (int i = 0; i < SC_ITEMS; ++i) {
     const int r = base + i;
-    if (r < P) offsets[r] = excl + v[i];
+    if (r < n_live) offsets[r] = excl + v[i];
   }
   if (threadIdx.x == SC_THREADS - 1) block_sums[blockIdx.x] = incl;
 }
@@ -421,7 +511,7 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
   {
     ProfScope ps("scan_tiles", c.stream);
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, sorted_ids, P,
-                       t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R, block_max);
+                       t.offsets, t.block_sums, radii, g.xy, gx, gy, block_R, block_max, g.hdr + (HDR_WORDS - 1));
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SC_THREADS), 0, c.stream, t.block_sums, nblocks, g.hdr, cap, block_R,
                        block_max, pack_bits);
   }
@@ -461,7 +551,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
     if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
     hdr[HDR_WORDS - 2] = cap;
   }
-  const bool in = r < P;
+  const bool in = r < min(P, (int)hdr[HDR_WORDS - 1]);      // depth ranks that exist (live Gaussians only when compacted)
   const uint32_t id = in ? sorted_ids[r] : 0;
   const uint32_t nt = in ? tiles[id] : 0;
   // this Gaussian owns exactly [end - nt, end) -- never more, never less.  offsets[] holds block-local inclusive sums
@@ -581,85 +671,92 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc,
                                                           float* __restrict__ d_feats,
                                                           const float* __restrict__ raw_feats, int norm_features,
-                                                          const uint32_t* __restrict__ block_sums) {
+                                                          const uint32_t* __restrict__ block_sums, int live_only) {
   constexpr int F = ROW - 12, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
   // BY_ID: `offsets` is PreBuf::id_end and the groups walk the Gaussian ids [p_begin, P) -- the gradients of an id range
   // are then complete (and can be exchanged) before the rest is reduced; otherwise depth ranks [0, P) through sorted_ids
-  const int r = p_begin + (blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
-  const bool live = r < P;
-  const uint32_t id = live ? (BY_ID ? (uint32_t)r : sorted_ids[r]) : 0;
-  uint32_t k0 = 0, k1 = 0;
-  if (live) {
-    const uint32_t nt = tiles[id];
-    k1 = offsets[r] + (BY_ID ? 0u : block_sums[r / SC_TILE]);   // depth-rank offsets are block-local sums (scan_partial_kernel)
-    k0 = k1 - nt;
-    const uint32_t cap = hdr[HDR_WORDS - 2];        // capacity the lists were built with
-    if (k1 > cap) k1 = cap;                         // pairs dropped by an overflow have no row
-    if (k0 > k1) k0 = k1;
-  }
-  // rows exist only for pairs that were blended somewhere (flag == 1): every group fetches 16 of its flags at a
-  // time, the wave ballot is cut into the four group masks, and a group walks its set bits, four rows in flight
-  constexpr int U = 4;                              // rows in flight per group
-  float4 s[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool col = t < Q;
-  // the flags of the NEXT sixteen pairs are requested before the rows of the current ones (one dependent level less per trip)
-  uint8_t f_cur = (k0 + t < k1) ? flags[k0 + t] : (uint8_t)0;
-  for (uint32_t kb = k0; __any(kb < k1); kb += 16) {
-    const unsigned long long wm = __ballot(f_cur != 0);
-    const uint32_t kn = kb + 16 + t;
-    const uint8_t f_next = (kn < k1) ? flags[kn] : (uint8_t)0;
-    uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
-    const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * bwd_row_stride(F)) + t;
-    while (__any(m != 0)) {
-      int b[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) { b[u] = m ? __builtin_ctz(m) : -1; m &= m - 1; }
-      float4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        v[u] = (col && b[u] >= 0) ? ld_stream(base + (size_t)b[u] * (bwd_row_stride(F) / 4)) : make_float4(0.f, 0.f, 0.f, 0.f);   // read once
-#pragma unroll
-      for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+  // (a loop: with live_only the launch is a fixed number of workgroups that stride over the live ranks -- the count lives on
+  // the device, and workgroups that only find out that they have nothing to do still cost their dispatch, ~4 ns each)
+  const int limit = live_only ? min(P, (int)hdr[HDR_WORDS - 1]) : P;
+  for (int wb = blockIdx.x; p_begin + wb * 16 < limit; wb += gridDim.x) {
+    const int r = p_begin + (wb * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
+    // live_only (tile-row strips, depth-rank order): only the ranks of Gaussians that have a pair -- the ids behind them (no
+    // pair: no rows) are NOT written; the caller zeroes what it needs of them (preprocess_bwd_raw does)
+    const bool live = r < limit;
+    const uint32_t id = live ? (BY_ID ? (uint32_t)r : sorted_ids[r]) : 0;
+    uint32_t k0 = 0, k1 = 0;
+    if (live) {
+      const uint32_t nt = tiles[id];
+      k1 = offsets[r] + (BY_ID ? 0u : block_sums[r / SC_TILE]);   // depth-rank offsets are block-local sums (scan_partial_kernel)
+      k0 = k1 - nt;
+      const uint32_t cap = hdr[HDR_WORDS - 2];        // capacity the lists were built with
+      if (k1 > cap) k1 = cap;                         // pairs dropped by an overflow have no row
+      if (k0 > k1) k0 = k1;
     }
-    f_cur = f_next;
-  }
-  float4 tot;
-  tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x); tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
-  tot.z = (s[0].z + s[1].z) + (s[2].z + s[3].z); tot.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
-  if (F > 0 && d_feats) {
-    const bool fl = t < F / 4;                      // lanes holding feature columns
-    float4 dx = tot;
-    if (raw_feats) {
-      // fused backward of y = x / (||x|| + 1e-9) (gaussian_renderer/__init__.py:120-121): tot holds dL/dy
-      const float4 x = (live && fl) ? *reinterpret_cast<const float4*>(raw_feats + (size_t)id * F + 4 * t)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (norm_features) {
-        float n2 = fl ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
-        float dot = fl ? (x.x * tot.x + x.y * tot.y) + (x.z * tot.z + x.w * tot.w) : 0.f;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {          // all-reduce inside the 16-lane group
-          n2 += __shfl_xor(n2, o);
-          dot += __shfl_xor(dot, o);
-        }
-        const float n = sqrtf(n2), den = n + 1e-9f;
-        const float k = (n > 0.f) ? dot / (n * den * den) : 0.f;
-        dx.x = tot.x / den - x.x * k; dx.y = tot.y / den - x.y * k;
-        dx.z = tot.z / den - x.z * k; dx.w = tot.w / den - x.w * k;
+    // rows exist only for pairs that were blended somewhere (flag == 1): every group fetches 16 of its flags at a
+    // time, the wave ballot is cut into the four group masks, and a group walks its set bits, four rows in flight
+    constexpr int U = 4;                              // rows in flight per group
+    float4 s[U];
+  #pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool col = t < Q;
+    // the flags of the NEXT sixteen pairs are requested before the rows of the current ones (one dependent level less per trip)
+    uint8_t f_cur = (k0 + t < k1) ? flags[k0 + t] : (uint8_t)0;
+    for (uint32_t kb = k0; __any(kb < k1); kb += 16) {
+      const unsigned long long wm = __ballot(f_cur != 0);
+      const uint32_t kn = kb + 16 + t;
+      const uint8_t f_next = (kn < k1) ? flags[kn] : (uint8_t)0;
+      uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
+      const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * bwd_row_stride(F)) + t;
+      while (__any(m != 0)) {
+        int b[U];
+  #pragma unroll
+        for (int u = 0; u < U; ++u) { b[u] = m ? __builtin_ctz(m) : -1; m &= m - 1; }
+        float4 v[U];
+  #pragma unroll
+        for (int u = 0; u < U; ++u)
+          v[u] = (col && b[u] >= 0) ? ld_stream(base + (size_t)b[u] * (bwd_row_stride(F) / 4)) : make_float4(0.f, 0.f, 0.f, 0.f);   // read once
+  #pragma unroll
+        for (int u = 0; u < U; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
       }
+      f_cur = f_next;
     }
-    if (live && fl) *reinterpret_cast<float4*>(d_feats + (size_t)id * F + 4 * t) = dx;
+    float4 tot;
+    tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x); tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+    tot.z = (s[0].z + s[1].z) + (s[2].z + s[3].z); tot.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+    if (F > 0 && d_feats) {
+      const bool fl = t < F / 4;                      // lanes holding feature columns
+      float4 dx = tot;
+      if (raw_feats) {
+        // fused backward of y = x / (||x|| + 1e-9) (gaussian_renderer/__init__.py:120-121): tot holds dL/dy
+        const float4 x = (live && fl) ? *reinterpret_cast<const float4*>(raw_feats + (size_t)id * F + 4 * t)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (norm_features) {
+          float n2 = fl ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
+          float dot = fl ? (x.x * tot.x + x.y * tot.y) + (x.z * tot.z + x.w * tot.w) : 0.f;
+  #pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {          // all-reduce inside the 16-lane group
+            n2 += __shfl_xor(n2, o);
+            dot += __shfl_xor(dot, o);
+          }
+          const float n = sqrtf(n2), den = n + 1e-9f;
+          const float k = (n > 0.f) ? dot / (n * den * den) : 0.f;
+          dx.x = tot.x / den - x.x * k; dx.y = tot.y / den - x.y * k;
+          dx.z = tot.z / den - x.z * k; dx.w = tot.w / den - x.w * k;
+        }
+      }
+      if (live && fl) *reinterpret_cast<float4*>(d_feats + (size_t)id * F + 4 * t) = dx;
+    }
+    // columns F .. F+11 -> acc[0..11] (the last two are zero padding of the row)
+    if (live && t >= F / 4 && t < F / 4 + 3) *reinterpret_cast<float4*>(acc + (size_t)id * BWD_ACC + 4 * (t - F / 4)) = tot;
   }
-  // columns F .. F+11 -> acc[0..11] (the last two are zero padding of the row)
-  if (live && t >= F / 4 && t < F / 4 + 3) *reinterpret_cast<float4*>(acc + (size_t)id * BWD_ACC + 4 * (t - F / 4)) = tot;
 }
 
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats, int norm_features,
-                       int id_begin, int id_end) {
+                       int id_begin, int id_end, int live_only) {
   // id_begin < 0: every Gaussian, in depth-rank order (its rows are then read front to back); otherwise the ids
   // [id_begin, id_end) only
   const bool by_id = id_begin >= 0;
@@ -672,10 +769,10 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
   do {                                                                                                                        \
     if (by_id)                                                                                                                \
       hipLaunchKernelGGL((reduce_rows_kernel<ROW, true>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
-                         g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums);   \
+                         g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, 0);   \
     else                                                                                                                      \
-      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
-                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums);  \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false>), dim3(live_only ? (blocks < 8192 ? blocks : 8192) : blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
+                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, live_only);  \
   } while (0)
     switch (F) {
       case 0: TRASE_RR(12); break;

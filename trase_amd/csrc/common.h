@@ -382,7 +382,8 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
 // Gaussians [p_begin, p_end) only (p_begin a multiple of 64; p_end = P or a multiple of 64)
 int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
                               const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr,
-                              int p_begin = 0, int p_end = -1);
+                              int p_begin = 0, int p_end = -1, int zero_dead_feats = 0, const uint32_t* live_ids = nullptr);
+int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const TraseRastRawGrads& gr);
 
 // stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
@@ -391,6 +392,9 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
 int radix_passes(int bit_lo, int bit_hi);
 
 // pack_bits: 0 = never pack; jb = pack list values as (id << jb | j) when every Gaussian has fewer than 2^jb pairs
+// strip mode: (depth key, id) of the Gaussians with a pair, ascending ids, then the ids without one; hdr[HDR_WORDS - 1] = live count
+int launch_compact_live(const LaunchCtx& c, const GeomBuf& g, int P, const PreBuf& t, const uint32_t* keys_raw,
+                        uint32_t* keys_out, uint32_t* ids_out);
 int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sorted_ids, int P, const PreBuf& t, uint32_t cap,
                       const int32_t* radii, int gx, int gy, int pack_bits = 0);
 int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const GeomBuf& g, const int32_t* radii,
@@ -399,7 +403,7 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
 // raw_feats != null: d_feats receives the gradient of the RAW features (backward of f / (||f|| + 1e-9) fused in)
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
                        const uint8_t* row_flags, float* acc, float* d_feats, const float* raw_feats = nullptr,
-                       int norm_features = 0, int id_begin = -1, int id_end = -1);
+                       int norm_features = 0, int id_begin = -1, int id_end = -1, int live_only = 0);
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg = nullptr, bool clear = true);
 

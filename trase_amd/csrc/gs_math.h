@@ -345,6 +345,21 @@ TRASE_HD bool subtile_live(float gx, float gy, float A, float B, float C, float 
 
 // Forward of one Gaussian.  `sh` points at 48 floats: this Gaussian's (16,3) coefficients,
 // zero-padded beyond the active degree, or is null when `color` (precomputed rgb) is given.  `cov_in` null => from scale/rot.
+// SH -> RGB of one Gaussian: + 0.5, clamp at 0, per-channel clamp flags.  Its own function so that
+// a caller can decide AFTER the geometry whether the colour is needed at all (a tile-row strip: most Gaussians have no pair
+// there and their 192 bytes of coefficients are never read).
+TRASE_HD void splat_colour_sh(const View& v, const float p[3], const float* sh, Splat& o) {
+  float d[3], il, b[16];
+  sh_dir(p, v.cam, d, il);
+  sh_basis(v.deg, d, b);
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;   // basis entries beyond the active degree are 0
+  TRASE_UNROLL
+  for (int k = 0; k < 16; ++k) { r0 += b[k] * sh[3 * k]; r1 += b[k] * sh[3 * k + 1]; r2 += b[k] * sh[3 * k + 2]; }
+  r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+  o.clamped = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
+  o.rgb[0] = fmaxf(r0, 0.f); o.rgb[1] = fmaxf(r1, 0.f); o.rgb[2] = fmaxf(r2, 0.f);
+}
+
 // Returns false (radius 0) when culled.
 // USE_COV / USE_SH are compile-time so that the small per-Gaussian arrays stay in registers.
 template <bool USE_COV, bool USE_SH>
@@ -380,15 +395,7 @@ TRASE_HD bool splat_forward(const View& v, const float p[3], const float* scale,
   if (!USE_SH) {
     o.rgb[0] = color[0]; o.rgb[1] = color[1]; o.rgb[2] = color[2];
   } else {
-    float d[3], il, b[16];
-    sh_dir(p, v.cam, d, il);
-    sh_basis(v.deg, d, b);
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;   // basis entries beyond the active degree are 0
-    TRASE_UNROLL
-    for (int k = 0; k < 16; ++k) { r0 += b[k] * sh[3 * k]; r1 += b[k] * sh[3 * k + 1]; r2 += b[k] * sh[3 * k + 2]; }
-    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-    o.clamped = (r0 < 0.f ? 1u : 0u) | (r1 < 0.f ? 2u : 0u) | (r2 < 0.f ? 4u : 0u);
-    o.rgb[0] = fmaxf(r0, 0.f); o.rgb[1] = fmaxf(r1, 0.f); o.rgb[2] = fmaxf(r2, 0.f);
+    splat_colour_sh(v, p, sh, o);
   }
   o.radius = radius;
   return true;

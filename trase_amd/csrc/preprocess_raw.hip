@@ -23,6 +23,7 @@ struct RawFwdArgs {
   int P, F, deg, W, H, norm_features;
   float tanx, tany, mod;
   int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
+  int strip;                 // forward: a tile-row strip is rendered (most Gaussians have no pair): colour and records only for those that do
   int p_begin, p_end;        // backward only: the Gaussians [p_begin, p_end) (p_begin a multiple of 64)
 };
 
@@ -135,10 +136,15 @@ __device__ __forceinline__ void rest_rows_store(float* __restrict__ base, int ro
   }
 }
 
-constexpr int RAW_BLOCK = 64;                                // one wave per workgroup: 11.5 KB of LDS each
+#ifndef TRASE_RAW_BLOCK
+#define TRASE_RAW_BLOCK 64
+#endif
+constexpr int RAW_BLOCK = TRASE_RAW_BLOCK;                   // waves x 64 per workgroup: 11.5 KB of LDS per wave
 
-template <int F>
-__global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
+// BLOCK: 64 for the whole image; 256 for a tile-row strip -- most waves have nothing to move there and the kernel is bound by
+// the rate at which workgroups can be dispatched (~250 per microsecond: 39k one-wave workgroups = 0.15 ms at 2.5 M Gaussians)
+template <int F, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
                                                                  float2* __restrict__ xy, float4* __restrict__ conic_o,
                                                                  float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ ftab,
                                                                  uint32_t* __restrict__ tiles,
@@ -149,22 +155,27 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
   if (gi == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;
   const bool active = gi < a.P;
   const int i = active ? gi : a.P - 1;
-  __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
-  float* const slab = slabs[threadIdx.x >> 6];
-  const int row0 = gi & ~63;                                  // first Gaussian of this wave (< P: the grid is ceil(P / 64) waves)
+  constexpr bool strip = BLOCK != RAW_BLOCK;                 // the 256-thread instantiation IS the tile-row-strip one
+  __shared__ __attribute__((aligned(16))) float slabs[strip ? 1 : BLOCK / 64][strip ? 4 : REST_SLAB];   // (the strip path moves no slab)
+  float* const slab = slabs[strip ? 0 : (threadIdx.x >> 6)];
+  const int row0 = gi & ~63;                                  // first Gaussian of this wave
+  if (row0 >= a.P) return;                                    // (a whole wave past the end: BLOCK > 64 only)
   const bool rest16 = ((reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0);
   RestRegs rr;
-  rest_rows_load(a.f_rest, row0, a.P, rest16, rr);
+  if (!strip) rest_rows_load(a.f_rest, row0, a.P, rest16, rr);   // (requested first: the geometry arithmetic hides the trip)
   View v;
   raw_view(a, v);
   Activated act;
   activate(a, i, act);
-  rest_rows_to_lds(rr, slab);
   float shl[48];
-  load_sh_split(a, i, slab, shl);
   const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
   Splat o;
-  const bool vis = splat_forward<false, true>(v, act.p, act.sc, act.q, cv, shl, col, o) && active;
+  // Geometry and colour are two call sites that BOTH modes go through (whole image / tile-row strip): a strip must reproduce
+  // the full render bit for bit, and two inlined copies of the same arithmetic are not guaranteed to contract alike (measured:
+  // a second copy of splat_forward differed by one ulp in 15 % of the conics).  What differs between the modes is only WHICH
+  // Gaussians get a colour and a record: every visible one, or -- strip -- those with a pair in the strip (~1 / world of them;
+  // the 192 bytes of SH coefficients are 1/3 of what a Gaussian moves through this kernel).
+  bool vis = splat_forward<false, false>(v, act.p, act.sc, act.q, cv, shl, col, o) && active;
   if (active) radii[i] = vis ? o.radius : 0;
   uint32_t live = 0;
   if (vis) {
@@ -180,6 +191,28 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_fwd_raw_kernel(RawFwdArg
     tiles[i] = live;
     depth_keys[i] = (vis && live) ? __float_as_uint(o.depth) : 0xffffffffu;
   }
+  const bool want = vis && (live != 0 || !strip);             // gets a colour and a record
+  if (!strip) {
+    rest_rows_to_lds(rr, slab);
+  } else {
+    if (vis && !live) xy[i] = make_float2(o.px, o.py);        // (the lineage pair count R is totalled from radii + centres)
+  }
+  if (want) {
+    if (!strip) {
+      load_sh_split(a, i, slab, shl);
+    } else {
+      // the few lanes that have a pair read their own rows (all 45 loads in flight at once; a cooperative copy of the rows one
+      // by one is a memory round trip per row, the slab copy moves eight times what is needed)
+      const int n3 = 3 * ncoef(a.deg);
+      const float* dc = a.f_dc + 3 * (size_t)i;
+      const float* rw = a.f_rest + (size_t)i * REST_W;
+      shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
+#pragma unroll
+      for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? rw[k - 3] : 0.f;
+    }
+    splat_colour_sh(v, act.p, shl, o);
+  }
+  vis = want;
   if (vis) {
     xy[i] = make_float2(o.px, o.py);
     conic_o[i] = make_float4(o.ca, o.cb, o.cc, act.opac);
@@ -245,11 +278,14 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.P = raw.P; a.F = raw.F; a.deg = s.sh_degree; a.W = s.image_width; a.H = s.image_height;
   a.norm_features = raw.norm_features; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.mod = s.scale_modifier;
   strip_subtile_rows(s, a.sy_lo, a.sy_hi);
+  a.strip = (s.tile_row_begin != 0 || s.tile_row_end != 0) ? 1 : 0;
   a.p_begin = 0; a.p_end = raw.P;
-  const dim3 grid((raw.P + RAW_BLOCK - 1) / RAW_BLOCK), block(RAW_BLOCK);
+  const int blk = a.strip ? 256 : RAW_BLOCK;
+  const dim3 grid((raw.P + blk - 1) / blk), block(blk);
   {
     ProfScope ps("preprocess_fwd", c.stream);
-#define TRASE_PRF(FF) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr)
+#define TRASE_PRF(FF) do { if (a.strip) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF, 256>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr); \
+                           else hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF, RAW_BLOCK>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr); } while (0)
     switch (raw.F) {
       case 0: TRASE_PRF(0); break;
       case 16: TRASE_PRF(16); break;
@@ -266,22 +302,35 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
 struct RawBwdOut {
   float* d_xyz; float* d_dxyz; float* d_means2D; float* d_f_dc; float* d_f_rest; float* d_opacity;
   float* d_scaling; float* d_dscaling; float* d_rotation; float* d_drotation;
+  float* d_feat_zero;        // tile-row strips: dL/dgaussian_features rows of the Gaussians WITHOUT a pair are zeroed here
+  int F;                     // (reduce_rows only walked the ones that have one), F floats per row
 };
 
-__global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
-                                                                       const uint32_t* __restrict__ clamped,
-                                                                       const uint32_t* __restrict__ tiles,
-                                                                       const float* __restrict__ acc, RawBwdOut o) {
+// LIVE (tile-row strips with sparse gradients, TRASE_VARIANT_SPARSE_STRIP_GRADS): thread k handles the k-th Gaussian of the
+// live list `ids` (those with a pair in the strip, hdr[HDR_WORDS - 1] of them) and ONLY their rows of the gradient tensors are
+// written -- the caller keeps every other row zero (trase_rast_zero_live_rows).  The f_rest rows are gathered / scattered row by
+// row (one coalesced 180-byte access each) instead of moved as the wave's contiguous slab.
+template <bool LIVE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
+                                                                   const uint32_t* __restrict__ clamped,
+                                                                   const uint32_t* __restrict__ tiles,
+                                                                   const float* __restrict__ acc, RawBwdOut o,
+                                                                   const uint32_t* __restrict__ ids,
+                                                                   const uint32_t* __restrict__ n_live_ptr) {
   const int gidx = a.p_begin + blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = gidx < a.p_end;                               // no early return: the wave moves the f_rest rows together
-  const int i = active ? gidx : a.P - 1;
+  const int p_end = LIVE ? min(a.P, (int)*n_live_ptr) : a.p_end;
+  if (LIVE && (gidx & ~63) >= p_end) return;                        // a whole wave behind the live list
+  const bool active = gidx < p_end;                                 // no early return inside a wave: it moves the f_rest rows together
+  const int i = LIVE ? (active ? (int)ids[gidx] : 0) : (active ? gidx : a.P - 1);
   // (no pair -- culled, fainter than 1/255 everywhere, or outside the strip being rendered -- means exact zero gradients)
   const bool vis = active && radii[i] > 0 && tiles[i] > 0;
-  __shared__ __attribute__((aligned(16))) float slabs[RAW_BLOCK / 64][REST_SLAB];
+  __shared__ __attribute__((aligned(16))) float slabs[BLOCK / 64][REST_SLAB];
   float* const slab = slabs[threadIdx.x >> 6];
   const int row0 = gidx & ~63;
   const bool wave_vis = __ballot(vis) != 0ull;
-  if (wave_vis) {
+  if (LIVE) {
+    // (every lane reads and writes its own 180-byte rows: the ids are scattered, there is no slab to move)
+  } else if (wave_vis) {
     RestRegs rr;
     rest_rows_load(a.f_rest, row0, a.P, (reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0, rr);
     rest_rows_to_lds(rr, slab);
@@ -314,7 +363,16 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArg
     raw_view(a, v);
     activate(a, i, act);
     float shl[48];
-    load_sh_split(a, i, slab, shl);
+    if (LIVE) {
+      const int n3 = 3 * ncoef(a.deg);
+      const float* dc = a.f_dc + 3 * (size_t)i;
+      const float* rw = a.f_rest + (size_t)i * REST_W;
+      shl[0] = dc[0]; shl[1] = dc[1]; shl[2] = dc[2];
+#pragma unroll
+      for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? rw[k - 3] : 0.f;
+    } else {
+      load_sh_split(a, i, slab, shl);
+    }
     const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     splat_backward<false, true>(v, act.p, act.sc, act.q, cv, shl, clamped[i], gi, go, dsh);
   }
@@ -339,6 +397,24 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArg
   }
   if (o.d_f_dc) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
   }
+  if (o.d_feat_zero) {
+    // eight lanes per 128-byte row (F = 32; four for F = 16): the wave's rows as contiguous runs
+    const int lpg = o.F / 4, gpi = 64 / lpg;
+    const unsigned long long dead = __ballot(active && !vis);
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < lpg; ++k) {
+      const int gl = k * gpi + lane / lpg;
+      if ((dead >> gl) & 1ull) reinterpret_cast<float4*>(o.d_feat_zero + (size_t)(row0 + gl) * o.F)[lane % lpg] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (LIVE) {
+    if (o.d_f_rest && active) {
+      float* rw = o.d_f_rest + (size_t)i * REST_W;
+#pragma unroll
+      for (int k = 0; k < REST_W; ++k) rw[k] = dsh[3 + k];
+    }
+    return;
+  }
   if (o.d_f_rest) {
     // 180-byte rows: through the wave's slab (each lane rewrites ITS row, already consumed above), then contiguous stores
     float* row = slab + (threadIdx.x & 63) * REST_W;
@@ -349,9 +425,42 @@ __global__ __launch_bounds__(RAW_BLOCK) void preprocess_bwd_raw_kernel(RawFwdArg
   }
 }
 
+// rows of the live Gaussians of a PREVIOUS strip backward back to zero (sparse strip gradients keep every other row zero)
+struct ZeroRowsArgs { float* t[12]; int w[12]; int n; };
+__global__ __launch_bounds__(256) void zero_live_rows_kernel(ZeroRowsArgs z, const uint32_t* __restrict__ ids,
+                                                             const uint32_t* __restrict__ n_live_ptr, int P) {
+  const int n_live = min(P, (int)*n_live_ptr);
+  // 16 lanes per Gaussian: a row of up to 45 floats is cleared by one (or three) partial-wave stores.  A fixed grid strides over
+  // the list: the count lives on the device, and workgroups that only find out that there is nothing to do still cost their dispatch
+  const int t = threadIdx.x & 15;
+  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; k < n_live; k += (gridDim.x * blockDim.x) >> 4) {
+    const size_t id = ids[k];
+    for (int j = 0; j < z.n; ++j)
+      for (int c = t; c < z.w[j]; c += 16) z.t[j][id * z.w[j] + c] = 0.f;
+  }
+}
+
+int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const TraseRastRawGrads& gr) {
+  ZeroRowsArgs z;
+  z.n = 0;
+  auto add = [&](float* p, int w) { if (p && w > 0) { z.t[z.n] = p; z.w[z.n] = w; ++z.n; } };
+  add(gr.dL_dxyz, 3); add(gr.dL_dd_xyz, 3); add(gr.dL_dmeans2D, 3); add(gr.dL_dfeatures_dc, 3); add(gr.dL_dfeatures_rest, 45);
+  add(gr.dL_dopacity, 1); add(gr.dL_dscaling, 3); add(gr.dL_dd_scaling, 3); add(gr.dL_drotation, 4); add(gr.dL_dd_rotation, 4);
+  add(gr.dL_dgaussian_features, F);
+  if (z.n == 0 || P == 0) return TRASE_OK;
+  {
+    ProfScope ps("zero_live_rows", c.stream);
+    const size_t nb = ((size_t)P * 16 + 255) / 256;
+    hipLaunchKernelGGL(zero_live_rows_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, c.stream, z, pre.sort.vals[0],
+                       g.hdr + (HDR_WORDS - 1), P);
+  }
+  TRASE_POST_LAUNCH("zero_live_rows", c.stream, c.debug);
+  return TRASE_OK;
+}
+
 int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
                               const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr,
-                              int p_begin, int p_end) {
+                              int p_begin, int p_end, int zero_dead_feats, const uint32_t* live_ids) {
   if (p_end < 0) p_end = raw.P;
   if (p_end <= p_begin) return TRASE_OK;
   RawFwdArgs a;
@@ -368,9 +477,16 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   o.d_xyz = gr.dL_dxyz; o.d_dxyz = gr.dL_dd_xyz; o.d_means2D = gr.dL_dmeans2D; o.d_f_dc = gr.dL_dfeatures_dc;
   o.d_f_rest = gr.dL_dfeatures_rest; o.d_opacity = gr.dL_dopacity; o.d_scaling = gr.dL_dscaling;
   o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
+  o.d_feat_zero = (zero_dead_feats && (raw.F == 16 || raw.F == 32)) ? gr.dL_dgaussian_features : nullptr; o.F = raw.F;
+  a.strip = 0;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    hipLaunchKernelGGL(preprocess_bwd_raw_kernel, dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0, c.stream, a, radii, g.clamped, g.tiles, acc, o);
+    if (live_ids)     // sparse strip gradients: the live list only (grid for P -- the count lives on the device; whole waves behind it leave at once)
+      hipLaunchKernelGGL((preprocess_bwd_raw_kernel<true, 256>), dim3((raw.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped, g.tiles,
+                         acc, o, live_ids, g.hdr + (HDR_WORDS - 1));
+    else
+      hipLaunchKernelGGL((preprocess_bwd_raw_kernel<false, RAW_BLOCK>), dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0,
+                         c.stream, a, radii, g.clamped, g.tiles, acc, o, nullptr, nullptr);
   }
   TRASE_POST_LAUNCH("preprocess_bwd", c.stream, c.debug);
   return TRASE_OK;

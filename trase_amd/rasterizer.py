@@ -98,6 +98,19 @@ def set_variant(v: int):
 VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x20000      # lineage switches
 VARIANT_FEATURES_ONLY_BWD = 0x400                                                       # backward scope
 VARIANT_VALU_BACKWARD, VARIANT_VALU_FORWARD, VARIANT_SLOT_LISTS = 0x40, 0x2000, 0x100000  # cross-check formulations
+VARIANT_SPARSE_STRIP_GRADS = 0x200000                                                   # tile-row strips: live rows only
+
+
+def set_sparse_strip_grads(flag: bool = True):
+    """Tile-row strips (``tile_rows``) through the fused ``render()``: the backward writes ONLY the gradient rows of the
+    Gaussians that have a pair in the strip (~1 / world of them) into persistent per-parameter tensors that are zero
+    everywhere else -- zero-filled once; the rows a backward wrote are cleared again before the next one writes
+    (``trase_rast_zero_live_rows``).  The per-Gaussian tail of a strip's backward then costs what the strip holds instead
+    of what the scene does (2.5 M Gaussians: 0.53 -> 0.16 ms at 8 strips).  The returned gradients are the usual dense
+    tensors -- but, as with ``set_grad_sink``, they are REUSED: a ``.grad`` kept from an earlier iteration is overwritten by
+    the next strip backward.  Off by default."""
+    v = _Policy.variant & ~VARIANT_SPARSE_STRIP_GRADS
+    _Policy.variant = v | (VARIANT_SPARSE_STRIP_GRADS if flag else 0)
 
 
 def set_lineage(feats_bg: Optional[float] = None, depth_normalised: bool = False, depth_grad: bool = False):

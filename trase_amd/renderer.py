@@ -17,6 +17,7 @@ import torch
 from . import _lib
 from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
+from .rasterizer import VARIANT_SPARSE_STRIP_GRADS as _r_VARIANT_SPARSE
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _bytes, _fill_settings,
                          _output_maps, _pick_capacity, _prep, _sizes, _stream)
 
@@ -49,6 +50,22 @@ def set_forward_scope(scope: str = "all") -> None:
     if scope not in ("all", "image"):
         raise ValueError("scope must be 'all' or 'image'")
     _FORWARD_SCOPE = scope
+
+
+# sparse strip gradients (rasterizer.set_sparse_strip_grads): persistent gradient tensors, zero outside the rows the most recent
+# strip backward wrote; `prev` = (geom, pre) workspaces of the forward whose backward wrote them (its live-Gaussian list)
+_SPARSE: dict = {"bufs": {}, "prev": None}
+
+
+def _sparse_buf(name: str, like: torch.Tensor) -> torch.Tensor:
+    key = (name, tuple(like.shape), like.device)
+    b = _SPARSE["bufs"].get(key)
+    if b is None:
+        if any(k[0] == name for k in _SPARSE["bufs"]):        # the parameter set changed (densify / prune): start over
+            _SPARSE["bufs"] = {k: v for k, v in _SPARSE["bufs"].items() if k[0] != name}
+            _SPARSE["prev"] = None
+        b = _SPARSE["bufs"][key] = torch.zeros_like(like)
+    return b
 
 
 _GRAD_SINK: dict = {}
@@ -200,9 +217,15 @@ class _RenderRaw(torch.autograd.Function):
         pid = ctx.param_ids
         used_sink: set = set()
 
-        def alloc(flag, like, name=None):
+        sparse = bool(s.variant & _r_VARIANT_SPARSE) and (s.tile_row_begin != 0 or s.tile_row_end != 0) and _GRAD_CHUNKS is None and P > 0
+        sparse_used: dict = {}
+
+        def alloc(flag, like, name=None, sname=None):
             if not flag:
                 return None
+            if sparse and sname:
+                b = sparse_used[sname] = _sparse_buf(sname, like)
+                return b.view(b.shape)
             ent = _GRAD_SINK.get(pid[name]) if (_GRAD_SINK and name) else None
             if ent is not None:
                 ref, buf = ent
@@ -216,14 +239,15 @@ class _RenderRaw(torch.autograd.Function):
             return torch.empty_like(like)
 
         # the kernel always produces dL/dxyz (the position chain needs it); it only lands in the sink when it is asked for
-        g_xyz = alloc(True, xyz, "xyz" if need[0] else None)
-        g_dxyz = alloc(need[1] and has_dxyz, xyz)                  # the deformation offsets are not bucket parameters
-        g_m2d = torch.empty(P, 3, device=device)
-        g_dc, g_rest = alloc(need[2], f_dc, "f_dc"), alloc(need[3], f_rest, "f_rest")
-        g_op, g_sc, g_rot = alloc(need[4], opacity, "opacity"), alloc(need[5], scaling, "scaling"), alloc(need[6 + 1], rotation, "rotation")
-        g_dsc = alloc(need[6] and has_dscale, scaling)
-        g_drot = alloc(need[8] and has_drot, rotation)
-        g_feat = alloc(need[9] and has_feat and F > 0, gfeat, "gfeat") if has_feat else None
+        g_xyz = alloc(True, xyz, "xyz" if need[0] else None, "xyz")
+        g_dxyz = alloc(need[1] and has_dxyz, xyz, None, "dxyz")    # the deformation offsets are not bucket parameters
+        g_m2d = alloc(True, xyz, None, "m2d") if sparse else torch.empty(P, 3, device=device)
+        g_dc, g_rest = alloc(need[2], f_dc, "f_dc", "f_dc"), alloc(need[3], f_rest, "f_rest", "f_rest")
+        g_op, g_sc, g_rot = (alloc(need[4], opacity, "opacity", "opacity"), alloc(need[5], scaling, "scaling", "scaling"),
+                             alloc(need[6 + 1], rotation, "rotation", "rotation"))
+        g_dsc = alloc(need[6] and has_dscale, scaling, None, "dscaling")
+        g_drot = alloc(need[8] and has_drot, rotation, None, "drotation")
+        g_feat = alloc(need[9] and has_feat and F > 0, gfeat, "gfeat", "gfeat") if has_feat else None
         g = _lib.RastRawGrads()
         g.dL_dimage = _lib.ptr(_prep(grad_image, "grad_image", device))
         g.dL_dfeats = _lib.ptr(_prep(grad_feats, "grad_feats", device)) if F > 0 else None
@@ -233,6 +257,27 @@ class _RenderRaw(torch.autograd.Function):
         g.dL_dscaling, g.dL_dd_scaling = _lib.ptr(g_sc), _lib.ptr(g_dsc)
         g.dL_drotation, g.dL_dd_rotation = _lib.ptr(g_rot), _lib.ptr(g_drot)
         g.dL_dgaussian_features = _lib.ptr(g_feat)
+        if sparse:
+            # the rows the PREVIOUS strip backward wrote go back to zero first (every buffer of the cache, whether or not this
+            # backward uses it); then this one writes the rows of its own live Gaussians
+            prev = _SPARSE["prev"]
+            if prev is not None and prev[2] == P:
+                pgeom, ppre, _, pF = prev
+                zg = _lib.RastRawGrads()
+                by = {k[0]: v for k, v in _SPARSE["bufs"].items()}
+                zg.dL_dxyz, zg.dL_dd_xyz, zg.dL_dmeans2D = _lib.ptr(by.get("xyz")), _lib.ptr(by.get("dxyz")), _lib.ptr(by.get("m2d"))
+                zg.dL_dfeatures_dc, zg.dL_dfeatures_rest, zg.dL_dopacity = _lib.ptr(by.get("f_dc")), _lib.ptr(by.get("f_rest")), _lib.ptr(by.get("opacity"))
+                zg.dL_dscaling, zg.dL_dd_scaling = _lib.ptr(by.get("scaling")), _lib.ptr(by.get("dscaling"))
+                zg.dL_drotation, zg.dL_dd_rotation = _lib.ptr(by.get("rotation")), _lib.ptr(by.get("drotation"))
+                zg.dL_dgaussian_features = _lib.ptr(by.get("gfeat"))
+                zraw = _lib.RastRawInputs()
+                zraw.P, zraw.F = P, (by["gfeat"].shape[-1] if by.get("gfeat") is not None else 0)
+                zws = _lib.RastWorkspace()
+                zws.geom, zws.geom_bytes = _lib.ptr(pgeom), pgeom.numel()
+                zws.pre, zws.pre_bytes = _lib.ptr(ppre), ppre.numel()
+                _lib.check(lib.trase_rast_zero_live_rows(C.byref(s), C.byref(zraw), C.byref(zws), C.byref(zg), _stream(device)),
+                           "trase_rast_zero_live_rows")
+            _SPARSE["prev"] = (geom, pre, P, F)
         if _GRAD_CHUNKS is not None and P > 0:
             # compositing backward once, then the per-Gaussian tail range by range: the caller's hook sees every range as
             # soon as it is in the stream (the view-parallel exchange of that range overlaps the rest of the tail)
