@@ -164,9 +164,11 @@ def main():
     ap.add_argument("--policy", choices=["free", "sync"], default="free",
                     help="capacity policy of the timed steps: free = set_sync(False) with a measured capacity (default, what the "
                          "metric is quoted on); sync = the drop-in default (pair count read back every forward, exact allocation)")
-    ap.add_argument("--graph", action="store_true",
-                    help="launch-graph replay of the forward / backward launch sequences (trase_amd.rasterizer.set_graph): for the "
-                         "small BASELINE configurations, which are host-bound otherwise")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], nargs="?", const="on", default="auto",
+                    help="launch-graph replay of the forward / backward launch sequences (trase_amd.rasterizer.set_graph).  auto "
+                         "(default): on for the small BASELINE configurations (<= 200k Gaussians), which are host-bound otherwise; "
+                         "off at the headline size, where it changes nothing (measured 902.9 vs 903.0 views/s) and the per-kernel "
+                         "HIP events of the timed region -- which the roofline figure needs -- cannot be recorded inside a graph")
     ap.add_argument("--shard", choices=["views", "tiles"], default="views",
                     help="'views' (default, the headline): every rank renders a different view.  'tiles' (BASELINE config 5): ONE "
                          "view per step for the whole job, every rank renders a load-balanced strip of 16x16-tile rows, the RGB "
@@ -179,6 +181,8 @@ def main():
                     help="ONE GPU: time every rank's strip (fwd+bwd, load-balanced partition) for world = 1, 2, 4, 8 and write the "
                          "predicted tile-sharding speed-up (communication excluded) to this JSON file; no bench line is printed")
     args = ap.parse_args()
+    args.graph = (args.graph == "on") or (args.graph == "auto" and args.gaussians <= 200_000 and args.shard == "views" and not args.strip_table
+                                          and args.policy == "free" and not args.unfused and args.gpus == 1)
     if (args.shard == "tiles" or args.strip_table) and "--gaussians" not in " ".join(sys.argv) and "--width" not in " ".join(sys.argv):
         args.gaussians, args.width, args.height = 2_500_000, 1280, 960          # S5: Google Immersive size
 
@@ -408,7 +412,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-    R.profile_enable(2)          # HIP events around the compositing kernels only, on the launch stream
+    if not args.graph:           # (a replayed launch graph has no per-kernel events: --graph takes the kernel times of the untimed pass below)
+        R.profile_enable(2)      # HIP events around the compositing kernels only, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -416,7 +421,7 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    prof = R.profile_report()
+    prof = R.profile_report() if not args.graph else {}
     R.profile_enable(0)
     exchange_ms = bucket.exchange_ms() if bucket is not None else None      # the last timed step's collective(s)
     status = R.last_status()
@@ -474,7 +479,7 @@ def main():
     if rank == 0:
         r_used = sum(r_list[i % n_views] for i in range(args.steps)) / args.steps
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"] * kv[1]["n"])[0] if prof else "render_bwd"
-        dom_ms = prof[dom]["ms"] if prof else float("nan")
+        dom_ms = prof[dom]["ms"] if prof else (breakdown or {}).get(dom, float("nan"))
         a_bytes = algorithmic_bytes(dom, N, r_used, P, F)
         achieved = a_bytes / (dom_ms * 1e-3) / 1e9
         # per-launch PMC figures of the same command (profiles/run_pmc.sh -> profiles/pmc_per_launch.json):

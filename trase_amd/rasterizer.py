@@ -263,6 +263,15 @@ def _sizes(lib, P: int, W: int, H: int, F: int, capacity: int):
     return v
 
 
+def _release_last():
+    """Called at the START of a forward: drop the references to the previous forward's geom / bin workspaces (kept for
+    last_status / last_tile_row_loads / current_guard, all of which are asked between a forward and the next one).  Holding
+    them across the next forward's allocations made the caching allocator alternate between two sets of blocks: every
+    second launch-graph record missed, and the peak memory was one bin buffer higher."""
+    _Policy.last_geom = None
+    _Policy.last_bin = None
+
+
 def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor] = None, hw=None):
     _Policy.last_geom, _Policy.last_capacity = geom, capacity
     _Policy.last_bin, _Policy.last_hw = binb, hw
@@ -396,9 +405,10 @@ def _fill_settings(rs: GaussianRasterizationSettings, device, keep: list) -> _li
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
+    def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,  # noqa: C901
                 cov3Ds_precomp, raster_settings):
         lib = _lib.load()
+        _release_last()
         device = means3D.device
         if device.type != "cuda":
             raise RuntimeError("trase_amd rasterizer runs on the GPU only (there is no CPU path); "

@@ -18,7 +18,7 @@ from . import _lib
 from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
 from .rasterizer import VARIANT_SPARSE_STRIP_GRADS as _r_VARIANT_SPARSE
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _bytes, _fill_settings,
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _release_last, _bytes, _fill_settings,
                          _output_maps, _pick_capacity, _prep, _sizes, _stream)
 
 
@@ -112,6 +112,7 @@ class _RenderRaw(torch.autograd.Function):
         device = xyz.device
         if device.type != "cuda":
             raise RuntimeError("trase_amd render runs on the GPU only (there is no CPU path)")
+        _release_last()
         param_ids = dict(xyz=id(xyz), f_dc=id(f_dc), f_rest=id(f_rest), opacity=id(opacity), scaling=id(scaling),
                          rotation=id(rotation), gfeat=id(gfeat))
         T = lambda t, n: _prep(t, n, device)
