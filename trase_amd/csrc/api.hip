@@ -183,7 +183,7 @@ static int g_graph_mode = 0;
 static std::map<uint64_t, std::vector<GraphEntry>> g_graphs;
 static size_t g_graph_count = 0;
 static int64_t g_graph_hits = 0, g_graph_misses = 0;
-static hipStream_t g_capture_stream = nullptr;
+static std::map<int, hipStream_t> g_capture_streams;      // one capture stream per device (created with that device current)
 
 static uint64_t fnv1a(const std::string& s) {
   uint64_t h = 1469598103934665603ull;
@@ -199,7 +199,7 @@ static void graph_clear_locked() {
 
 // Runs body(stream) either directly, or -- graph mode, profiler off, no per-kernel debug sync -- as a cached graph.
 template <class Body>
-static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const void*, size_t>> parts, int debug,
+static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const void*, size_t>> parts, int debug, int device,
                              hipStream_t stream, Body&& body) {
   if (!g_graph_mode || debug || prof_on()) return body(stream);
   std::string key((const char*)&entry_id, sizeof(entry_id));
@@ -219,15 +219,18 @@ static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const
   // records that never repeat (an allocator handing out new blocks every iteration): give up, a capture per call is a loss
   if (g_graph_misses > 512 && g_graph_hits < g_graph_misses) { g_graph_mode = 0; graph_clear_locked(); return body(stream); }
   if (g_graph_count >= 256) graph_clear_locked();
-  if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) return body(stream);
-  if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return body(stream); }
-  const int rc = body(g_capture_stream);
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return body(stream); }
+  hipStream_t& cap = g_capture_streams[device];
+  if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) { cap = nullptr; (void)hipGetLastError(); return body(stream); }
+  if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return body(stream); }
+  const int rc = body(cap);
   hipGraph_t graph = nullptr;
-  const hipError_t ec = hipStreamEndCapture(g_capture_stream, &graph);
+  const hipError_t ec = hipStreamEndCapture(cap, &graph);
   if (rc != TRASE_OK || ec != hipSuccess || !graph) {
+    // whatever went wrong while capturing: run the sequence directly (a genuine argument error fails again, with its message)
     if (graph) hipGraphDestroy(graph);
     (void)hipGetLastError();
-    return rc != TRASE_OK ? rc : body(stream);
+    return body(stream);
   }
   hipGraphExec_t exec = nullptr;
   const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -391,7 +394,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
 int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                        const TraseRastWorkspace* ws, trase_stream_t stream) {
   if (!s || !in || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(1, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, (hipStream_t)stream,
+  return run_maybe_graphed(1, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream,
                            [&](hipStream_t st) {
                              int rc = trase_rast_preprocess(s, in, out, ws, st);
                              if (rc) return rc;
@@ -420,7 +423,7 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
 int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
   if (!s || !in || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(2, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug,
+  return run_maybe_graphed(2, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug, s->device,
                            (hipStream_t)stream_, [&](hipStream_t st) { return backward_impl(s, in, out, ws, gr, st); });
 }
 
@@ -593,14 +596,14 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
 int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                             const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream) {
   if (!s || !raw || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(4, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug,
+  return run_maybe_graphed(4, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug, s->device,
                            (hipStream_t)stream, [&](hipStream_t st) { return backward_raw_phases(s, raw, out, ws, gr, st, 3, -1, -1); });
 }
 
 int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                            const TraseRastWorkspace* ws, trase_stream_t stream) {
   if (!s || !raw || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(3, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, (hipStream_t)stream,
+  return run_maybe_graphed(3, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream,
                            [&](hipStream_t st) {
                              int rc = trase_rast_preprocess_raw(s, raw, out, ws, st);
                              if (rc) return rc;

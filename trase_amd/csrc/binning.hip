@@ -662,7 +662,14 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
 // its rows (ROW/4 <= 11 lanes active), so a row is read with 16-byte loads, sums never cross lanes, and the chain
 // of dependent loads (rank -> id -> pair range -> flags -> rows) is paid once per four Gaussians.  Writes every
 // Gaussian (zeros where it has no pairs), so neither output needs a memset and the sums are bit-reproducible.
-template <int ROW, bool BY_ID>
+// GW = lanes per Gaussian: 16 (four Gaussians per wave; default) or 12 (five: a 44-column row is eleven 16-byte pieces, so 55 of
+// the 64 lanes of a row-load instruction carry data instead of 44).  Measured, same box, two alternations: 0.148 / 0.149 ms with
+// 16 against 0.150 / 0.150 with 12 -- the kernel is bound by the cache lines its sparse rows touch (1.9 M rows among 6.0 M slots:
+// ~2.4 lines of 128 bytes per 176-byte row), not by the lanes an instruction keeps busy.
+#ifndef TRASE_RR_GW
+#define TRASE_RR_GW 16
+#endif
+template <int ROW, bool BY_ID, int GW>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ tiles, int p_begin, int P,
@@ -674,17 +681,19 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ block_sums, int live_only) {
   constexpr int F = ROW - 12, Q = ROW / 4;
   const int lane = threadIdx.x & 63;
-  const int grp = lane >> 4, t = lane & 15;
+  constexpr int GPW = WAVE / GW, GPB = GPW * (256 / WAVE);   // Gaussians per wave / per workgroup
+  static_assert(ROW / 4 <= GW, "a row's 16-byte pieces must fit the lane group");
+  const int grp = lane / GW, t = lane - grp * GW;              // (GW = 12: lanes 60..63 idle, grp == 5)
   // BY_ID: `offsets` is PreBuf::id_end and the groups walk the Gaussian ids [p_begin, P) -- the gradients of an id range
   // are then complete (and can be exchanged) before the rest is reduced; otherwise depth ranks [0, P) through sorted_ids
   // (a loop: with live_only the launch is a fixed number of workgroups that stride over the live ranks -- the count lives on
   // the device, and workgroups that only find out that they have nothing to do still cost their dispatch, ~4 ns each)
   const int limit = live_only ? min(P, (int)hdr[HDR_WORDS - 1]) : P;
-  for (int wb = blockIdx.x; p_begin + wb * 16 < limit; wb += gridDim.x) {
-    const int r = p_begin + (wb * (256 / WAVE) + (threadIdx.x >> 6)) * 4 + grp;
+  for (int wb = blockIdx.x; p_begin + wb * GPB < limit; wb += gridDim.x) {
+    const int r = p_begin + (wb * (256 / WAVE) + (threadIdx.x >> 6)) * GPW + grp;
     // live_only (tile-row strips, depth-rank order): only the ranks of Gaussians that have a pair -- the ids behind them (no
     // pair: no rows) are NOT written; the caller zeroes what it needs of them (preprocess_bwd_raw does)
-    const bool live = r < limit;
+    const bool live = r < limit && grp < GPW;
     const uint32_t id = live ? (BY_ID ? (uint32_t)r : sorted_ids[r]) : 0;
     uint32_t k0 = 0, k1 = 0;
     if (live) {
@@ -704,11 +713,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
     const bool col = t < Q;
     // the flags of the NEXT sixteen pairs are requested before the rows of the current ones (one dependent level less per trip)
     uint8_t f_cur = (k0 + t < k1) ? flags[k0 + t] : (uint8_t)0;
-    for (uint32_t kb = k0; __any(kb < k1); kb += 16) {
+    for (uint32_t kb = k0; __any(kb < k1); kb += GW) {
       const unsigned long long wm = __ballot(f_cur != 0);
-      const uint32_t kn = kb + 16 + t;
+      const uint32_t kn = kb + GW + t;
       const uint8_t f_next = (kn < k1) ? flags[kn] : (uint8_t)0;
-      uint32_t m = (uint32_t)(wm >> (16 * grp)) & 0xffffu;
+      uint32_t m = (uint32_t)(wm >> (GW * grp)) & ((1u << GW) - 1u);
       const float4* base = reinterpret_cast<const float4*>(rows + (size_t)kb * bwd_row_stride(F)) + t;
       while (__any(m != 0)) {
         int b[U];
@@ -736,10 +745,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
         if (norm_features) {
           float n2 = fl ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : 0.f;
           float dot = fl ? (x.x * tot.x + x.y * tot.y) + (x.z * tot.z + x.w * tot.w) : 0.f;
+          if constexpr (GW == 16) {
   #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {          // all-reduce inside the 16-lane group
-            n2 += __shfl_xor(n2, o);
-            dot += __shfl_xor(dot, o);
+            for (int o = 1; o < 16; o <<= 1) {        // all-reduce inside the 16-lane group
+              n2 += __shfl_xor(n2, o);
+              dot += __shfl_xor(dot, o);
+            }
+          } else {                                    // the F / 4 feature lanes of this group, in lane order
+            float a2 = 0.f, ad = 0.f;
+  #pragma unroll
+            for (int j = 0; j < F / 4; ++j) { a2 += __shfl(n2, grp * GW + j); ad += __shfl(dot, grp * GW + j); }
+            n2 = a2; dot = ad;
           }
           const float n = sqrtf(n2), den = n + 1e-9f;
           const float k = (n > 0.f) ? dot / (n * den * den) : 0.f;
@@ -762,16 +778,17 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
   const bool by_id = id_begin >= 0;
   const int first = by_id ? id_begin : 0, last = by_id ? id_end : P;
   if (last <= first) return TRASE_OK;
-  const int blocks = (last - first + 15) / 16;       // 4 waves x 4 Gaussians per block
+  constexpr int GW = TRASE_RR_GW, GPB = (WAVE / GW) * (256 / WAVE);
+  const int blocks = (last - first + GPB - 1) / GPB; // 4 waves x 4 (GW = 16) or 5 (GW = 12) Gaussians per block
   {
     ProfScope ps("reduce_rows", c.stream);
 #define TRASE_RR(ROW)                                                                                                         \
   do {                                                                                                                        \
     if (by_id)                                                                                                                \
-      hipLaunchKernelGGL((reduce_rows_kernel<ROW, true>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, true, GW>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
                          g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, 0);   \
     else                                                                                                                      \
-      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false>), dim3(live_only ? (blocks < 8192 ? blocks : 8192) : blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false, GW>), dim3(live_only ? (blocks < 8192 ? blocks : 8192) : blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
                          pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, live_only);  \
   } while (0)
     switch (F) {
