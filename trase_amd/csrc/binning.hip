@@ -528,6 +528,13 @@ int launch_scan_tiles(const LaunchCtx& c, const GeomBuf& g, const uint32_t* sort
 // Splats with many rows would make their wave wait for one lane: those (more than EMIT_BIG pairs) are handed to the whole
 // wave afterwards, 64 rows at a time (lane = row, wave prefix sum of the row counts).
 constexpr uint32_t EMIT_BIG = 160;
+// The pairs of a workgroup's 64 consecutive depth ranks are one contiguous stretch of slots.  When it is short enough (and the
+// list values are the packed form) the pairs are assembled in LDS and leave as fully coalesced runs: written straight from the
+// traversal, a store instruction touches 16-32 different lines with four bytes each.
+#ifndef TRASE_EMIT_STAGE
+#define TRASE_EMIT_STAGE 3072
+#endif
+constexpr uint32_t EMIT_STAGE = TRASE_EMIT_STAGE;
 
 __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restrict__ sorted_ids, int P,
                                                          const uint32_t* __restrict__ offsets,
@@ -574,6 +581,19 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   // is: stage 2 may be repeated on one stage 1)
   if (in && q == 0) id_end[id] = end;
   const bool big = nt > EMIT_BIG;
+  // ---- staging decision: the workgroup's stretch [w_lo, w_hi) --------------------------------------------------------
+  __shared__ uint32_t s_lo_hi[2];
+  __shared__ uint32_t s_key[EMIT_STAGE > 0 ? EMIT_STAGE : 1], s_val[EMIT_STAGE > 0 ? EMIT_STAGE : 1];
+  if (threadIdx.x == 0) { s_lo_hi[0] = off0; s_lo_hi[1] = off0; }      // (rank r0 may not exist: then the stretch is empty)
+  __syncthreads();
+  if (in && q == 0) atomicMax(&s_lo_hi[1], end);                       // offsets are monotone in the rank: the last one wins
+  __syncthreads();
+  const uint32_t w_lo = s_lo_hi[0], w_hi = min(s_lo_hi[1], cap);
+  const bool staged = EMIT_STAGE > 0 && jb != 0 && w_hi > w_lo && (w_hi - w_lo) <= EMIT_STAGE;
+  auto put = [&](uint32_t w, uint32_t key, uint32_t val, uint32_t gid) {
+    if (staged) { s_key[w - w_lo] = key; s_val[w - w_lo] = val; }
+    else { keys[w] = key; vals[w] = val; if (!jb) pair_gauss[w] = gid; }
+  };
   if (nt && !big) {
     const SubtileCull cull = subtile_cull_setup(p.x, p.y, co.x, co.y, co.z, co.w);
     // lane q of the quad evaluates the rows q, q+4, ... (one subtile_row_live per four rows and lane); where a row's run
@@ -591,16 +611,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
       const int n3 = __builtin_amdgcn_update_dpp(0, cnt, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
       uint32_t w = pos + (uint32_t)((q > 0 ? n0 : 0) + (q > 1 ? n1 : 0) + (q > 2 ? n2 : 0));
       for (int sx = c0; sx < c1; ++sx, ++w)
-        if (w < end && w < cap) {
-          keys[w] = (uint32_t)(sy * gx8 + sx);
-          if (jb) vals[w] = (id << jb) | (w - off0); else { vals[w] = w; pair_gauss[w] = id; }
-        }
+        if (w < end && w < cap) put(w, (uint32_t)(sy * gx8 + sx), jb ? ((id << jb) | (w - off0)) : w, id);
       pos += (uint32_t)(n0 + n1 + n2 + n3);
     }
     // belt and braces: should the re-evaluation ever find fewer live sub-tiles than were counted, the unused slots go
     // to the sentinel sub-tile `trash_key` that no kernel renders
     for (pos += q; pos < end; pos += 4)
-      if (pos < cap) { keys[pos] = trash_key; pair_gauss[pos] = id; vals[pos] = jb ? (id << jb) : pos; }
+      if (pos < cap) put(pos, trash_key, jb ? (id << jb) : pos, id);
   }
   // ---- big splats: the whole wave, one splat after the other -------------------------------------------------------
   unsigned long long todo = __ballot(big && q == 0);
@@ -629,14 +646,15 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
       }
       uint32_t pos = run + incl - cnt;
       for (int sx = c0; sx < c1; ++sx, ++pos)
-        if (pos < bend && pos < cap) {
-          keys[pos] = (uint32_t)(sy * gx8 + sx);
-          if (jb) vals[pos] = (bid << jb) | (pos - boff0); else { vals[pos] = pos; pair_gauss[pos] = bid; }
-        }
+        if (pos < bend && pos < cap) put(pos, (uint32_t)(sy * gx8 + sx), jb ? ((bid << jb) | (pos - boff0)) : pos, bid);
       run += (uint32_t)__shfl((int)incl, WAVE - 1);
     }
     for (uint32_t o = run + lane; o < bend; o += WAVE)
-      if (o < cap) { keys[o] = trash_key; pair_gauss[o] = bid; vals[o] = jb ? (bid << jb) : o; }
+      if (o < cap) put(o, trash_key, jb ? (bid << jb) : o, bid);
+  }
+  if (staged) {                                                        // workgroup-uniform
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < w_hi - w_lo; i += blockDim.x) { keys[w_lo + i] = s_key[i]; vals[w_lo + i] = s_val[i]; }
   }
 }
 

@@ -147,7 +147,10 @@ template <bool FEAT_ONLY, bool TIMING, bool COUNT = false, bool IMG_ONLY = false
 #ifndef HW_OCC
 #define HW_OCC 4
 #endif
-__global__ __launch_bounds__(HW_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(HW_OCC, HW_OCC)))
+#ifndef HW_OCC_IMG
+#define HW_OCC_IMG 4
+#endif
+__global__ __launch_bounds__(HW_WPB* WAVE) __attribute__((amdgpu_waves_per_eu(IMG_ONLY ? HW_OCC_IMG : HW_OCC, IMG_ONLY ? HW_OCC_IMG : HW_OCC)))
 void render_bwd_hw_kernel(BwdHwArgs a) {
   static_assert(!(FEAT_ONLY && IMG_ONLY), "scopes exclude each other");
   constexpr int F = IMG_ONLY ? 0 : 32;                   // feature columns of a gradient row
