@@ -325,8 +325,7 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   LaunchCtx c{stream, s->debug, s->variant};
   GeomBuf g = carve_geom(ws->geom, in->P);
   PreBuf t = carve_pre(ws->pre, in->P);
-  TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
-  if (in->P == 0) return TRASE_OK;
+  if (in->P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
   rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
   if (rc) return rc;
   return depth_order(c, s, g, t, in->P, out->radii, list_pack_bits(s, in->P));
@@ -508,8 +507,7 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   LaunchCtx c{stream, s->debug, s->variant};
   GeomBuf g = carve_geom(ws->geom, in.P);
   PreBuf t = carve_pre(ws->pre, in.P);
-  TRASE_CHECK(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream));
-  if (in.P == 0) return TRASE_OK;
+  if (in.P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
   rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
   if (rc) return rc;
   return depth_order(c, s, g, t, in.P, out->radii, list_pack_bits(s, in.P));

@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
                                                              uint32_t* __restrict__ depth_keys,
                                                              uint32_t* __restrict__ hdr) {
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi == 0) hdr[HDR_WORDS - 1] = (uint32_t)a.P;   // device-resident copy of P for the depth sort
+  if (gi == 0) {                                     // the header starts clean (nobody else touches it in this kernel: one
+#pragma unroll                                       // memset launch less per view) + a device-resident copy of P for the depth sort
+    for (int k = 0; k < HDR_WORDS - 1; ++k) hdr[k] = 0u;
+    hdr[HDR_WORDS - 1] = (uint32_t)a.P;
+  }
   // no early return: the wave-level reduction below needs lane 63 of every wave alive
   const bool active = gi < a.P;
   const int i = active ? gi : a.P - 1;

@@ -301,6 +301,19 @@ class _RenderRaw(torch.autograd.Function):
                 g_m2d if need[10] else None, None, None)
 
 
+_ZERO_CACHE: dict = {}
+
+
+def _zero_dummy(like: torch.Tensor) -> torch.Tensor:
+    key = (tuple(like.shape), like.dtype, like.device)
+    base = _ZERO_CACHE.get(key)
+    if base is None:
+        if len(_ZERO_CACHE) > 8:
+            _ZERO_CACHE.clear()
+        base = _ZERO_CACHE[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return base.view(base.shape).requires_grad_(True)
+
+
 def _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth) -> bool:
     if is_6dof or override_color is not None or mask is not None:
         return False
@@ -319,11 +332,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
            is_smooth_gaussian_features=False, smooth_K=16):
     """Same contract as the reference's render() (gaussian_renderer/__init__.py:37-155)."""
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # The reference builds `zeros_like(xyz, requires_grad=True) + 0` (gaussian_renderer/__init__.py:48-52): a dummy whose VALUES
+    # nobody reads -- the rasterizer returns the screen-space gradient through it and train.py reads `.grad`.  Here: a fresh
+    # LEAF that aliases a cached block of zeros -- same values, `.grad` filled by autograd, and the fill + add kernels of
+    # every view (~7 us at 300k Gaussians, launch-bound) are gone.
+    screenspace_points = _zero_dummy(xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
