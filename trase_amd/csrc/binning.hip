@@ -11,6 +11,8 @@
 // A stable sort by tile of a depth-ordered sequence is exactly the lineage's
 // (tile<<32 | depth) order.  All kernels take the pair count from device memory
 // so the host never has to synchronise.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace trase {
@@ -687,7 +689,7 @@ int launch_emit_pairs(const LaunchCtx& c, const TraseRastSettings& s, const Geom
 #ifndef TRASE_RR_GW
 #define TRASE_RR_GW 16
 #endif
-template <int ROW, bool BY_ID, int GW>
+template <int ROW, bool BY_ID, int GW, bool LOOP>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ tiles, int p_begin, int P,
@@ -707,7 +709,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
   // (a loop: with live_only the launch is a fixed number of workgroups that stride over the live ranks -- the count lives on
   // the device, and workgroups that only find out that they have nothing to do still cost their dispatch, ~4 ns each)
   const int limit = live_only ? min(P, (int)hdr[HDR_WORDS - 1]) : P;
-  for (int wb = blockIdx.x; p_begin + wb * GPB < limit; wb += gridDim.x) {
+  // LOOP = false: one workgroup per GPB Gaussians, no loop in the code (the loop costs the common whole-image launch ~2 %)
+  int wb = blockIdx.x;
+  if (p_begin + wb * GPB >= limit) return;
+  do {
     const int r = p_begin + (wb * (256 / WAVE) + (threadIdx.x >> 6)) * GPW + grp;
     // live_only (tile-row strips, depth-rank order): only the ranks of Gaussians that have a pair -- the ids behind them (no
     // pair: no rows) are NOT written; the caller zeroes what it needs of them (preprocess_bwd_raw does)
@@ -785,7 +790,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const uint32_t* __rest
     }
     // columns F .. F+11 -> acc[0..11] (the last two are zero padding of the row)
     if (live && t >= F / 4 && t < F / 4 + 3) *reinterpret_cast<float4*>(acc + (size_t)id * BWD_ACC + 4 * (t - F / 4)) = tot;
-  }
+    wb += gridDim.x;
+  } while (LOOP && p_begin + wb * GPB < limit);
 }
 
 int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, int P, int F, const float* rows,
@@ -797,16 +803,23 @@ int launch_reduce_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pre, 
   const int first = by_id ? id_begin : 0, last = by_id ? id_end : P;
   if (last <= first) return TRASE_OK;
   constexpr int GW = TRASE_RR_GW, GPB = (WAVE / GW) * (256 / WAVE);
+  // a bounded grid that strides (LOOP) where the launch would otherwise be very large: tile-row strips (the live count is on the
+  // device; most workgroups of a P-sized grid would only find out that they have nothing to do) and scenes beyond ~0.5 M Gaussians
+  // (S5: 156 k workgroups, 0.46 -> 0.43 ms with 16 k striding ones; no effect at 300 k)
+  const int grid_cap = live_only ? 8192 : 16384;
   const int blocks = (last - first + GPB - 1) / GPB; // 4 waves x 4 (GW = 16) or 5 (GW = 12) Gaussians per block
   {
     ProfScope ps("reduce_rows", c.stream);
 #define TRASE_RR(ROW)                                                                                                         \
   do {                                                                                                                        \
     if (by_id)                                                                                                                \
-      hipLaunchKernelGGL((reduce_rows_kernel<ROW, true, GW>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, true, GW, false>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0], pre.id_end, \
                          g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, 0);   \
+    else if (live_only ? blocks > grid_cap : blocks > 2 * grid_cap)                                                           \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false, GW, true>), dim3(grid_cap), dim3(256), 0, c.stream, pre.sort.vals[0],            \
+                         pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, live_only);  \
     else                                                                                                                      \
-      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false, GW>), dim3(live_only ? (blocks < 8192 ? blocks : 8192) : blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
+      hipLaunchKernelGGL((reduce_rows_kernel<ROW, false, GW, false>), dim3(blocks), dim3(256), 0, c.stream, pre.sort.vals[0],            \
                          pre.offsets, g.tiles, first, last, g.hdr, rows, row_flags, acc, d_feats, raw_feats, norm_features, pre.block_sums, live_only);  \
   } while (0)
     switch (F) {
