@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 NAMES = {"render_bwd": "trase::render_bwd_hw_kernel<false, false, false, false>", "render_fwd": "trase::render_fwd_mf_kernel",
-         "reduce_rows": "trase::reduce_rows_kernel<44, false, 16>", "preprocess_fwd": "trase::preprocess_fwd_raw_kernel<32, 64>",
+         "reduce_rows": "trase::reduce_rows_kernel<44, false, 16, false>", "preprocess_fwd": "trase::preprocess_fwd_raw_kernel<32, 64>",
          "preprocess_bwd": "trase::preprocess_bwd_raw_kernel<false, 64>", "emit_pairs": "trase::emit_pairs_kernel"}
 
 
