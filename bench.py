@@ -525,6 +525,8 @@ def main():
                        "entry": "GaussianRasterizer + PyTorch prep (reference render() body)" if args.unfused
                                 else "gaussian_renderer.render() drop-in, A1 prep fused",
                        "bucket_bytes": (None if bucket is None else bucket.bytes_per_step),
+                       # HIP events on the compute stream: one exchange = the collective(s) of allreduce(); with overlapped
+                       # ranges the window opens at the first range's hand-off, i.e. it includes the backward tail underneath
                        "exchange_ms": (None if exchange_ms is None else round(exchange_ms, 4)),
                        "exchange_algo": (None if bucket is None else args.exchange),
                        "exchange": (None if bucket is None else

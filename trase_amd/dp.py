@@ -195,6 +195,13 @@ class FlatGradBucket:
             self._exchanged = set()
         if not self._collectives_on():
             return
+        if p_begin == 0 and self.time_exchange and self.flat.is_cuda:
+            # the timed window opens where the first range is handed off: with overlapped ranges `exchange_ms` spans first
+            # hand-off -> last collective done, i.e. it INCLUDES the part of the backward's tail that runs underneath
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+            self._window_open = True
         slices = []
         for p, v in zip(self.params, self._views):
             if id(p) in used_ids and p.dim() >= 1 and p.shape[0] == P:
@@ -228,10 +235,11 @@ class FlatGradBucket:
         if not self._collectives_on():
             return
         timed = self.time_exchange and self.flat.is_cuda
-        if timed:
+        if timed and not getattr(self, "_window_open", False):
             if self._ev is None:
                 self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self._ev[0].record()
+        self._window_open = False
         if not done:
             self._exchange_flat()
         else:
