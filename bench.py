@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--dense-strip-grads", action="store_true",
                     help="tiles mode / strip table: dense per-Gaussian gradients (every row written, zeros included) instead of "
                          "trase_amd.rasterizer.set_sparse_strip_grads (only the rows of the strip's Gaussians)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="tiles mode / strip table: time the forward alone (rendering a frame: the use the tile-row axis is for -- "
+                         "no backward, no gradient exchange)")
     ap.add_argument("--strip-table", type=str, default="",
                     help="ONE GPU: time every rank's strip (fwd+bwd, load-balanced partition) for world = 1, 2, 4, 8 and write the "
                          "predicted tile-sharding speed-up (communication excluded) to this JSON file; no bench line is printed")
@@ -298,6 +301,12 @@ def main():
         for p_ in params:
             p_.grad = None
         b, e = rows if rows is not None else strip["part"][rank]
+        if args.forward_only:          # rendering one frame (inference / GUI / evaluation): no backward, no gradient exchange
+            with torch.no_grad(), (R.tile_rows(b, e) if (b, e) != (0, 0) else _nullctx()):
+                out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
+                if world > 1:
+                    dp.allgather_strips(out["render"], strip["part"], H)
+            return out["radii"]
         with R.tile_rows(b, e) if (b, e) != (0, 0) else _nullctx():
             out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
             img, radii, feats = out["render"], out["radii"], out["render_gaussian_features"]
@@ -331,7 +340,8 @@ def main():
         log(f"tile rows {len(loads)}, pairs {full_pairs}; load-balanced strips {strip['part']}")
     if args.strip_table:
         # ONE GPU: every rank's strip of world = 1, 2, 4, 8 timed in turn (communication excluded)
-        table = {"workload": f"{N} Gaussians, {W}x{H}, F={F}, one view sharded by load-balanced tile-row strips", "steps": args.steps,
+        table = {"workload": f"{N} Gaussians, {W}x{H}, F={F}, one view sharded by load-balanced tile-row strips"
+                             + (", FORWARD ONLY (rendering)" if args.forward_only else ", forward + backward"), "steps": args.steps,
                  "tile_row_loads": [int(x) for x in loads.tolist()], "world": {}}
         for wsize in (1, 2, 4, 8):
             part = dp.tile_row_partition(H, wsize, loads=loads)
