@@ -26,20 +26,26 @@ __global__ __launch_bounds__(128) void aggressor(int iters, uint32_t* sink) {
   // 16 lanes cooperate on a 16 x 4 block: row = lane & 15, 8-byte column block = lane >> 4, row pitch 192 halves (384 bytes)
   const unsigned short* p = tile + (lane & 15) * 192 + (lane >> 4) * 4 + (threadIdx.x >> 6) * 3200;
   uint32_t acc = 0;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s16x4 v;
-      if (TR) v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * k));
-      else v = *(const lds_s16x4*)(p + 16 * k);
-      acc += (uint32_t)v[0] + (uint32_t)v[1] * 3u + (uint32_t)v[2] * 5u + (uint32_t)v[3] * 7u;
+    for (int k = 0; k < 8; k += 2) {
+      s16x4 v, w;
+      if (TR) { v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * k)); w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * k + 16)); }
+      else { v = *(const lds_s16x4*)(p + 16 * k); w = *(const lds_s16x4*)(p + 16 * k + 16); }
+      const s16x8 q = {v[0], v[1], v[2], v[3], w[0], w[1], w[2], w[3]};
+      const bf16x8 B = __builtin_bit_cast(bf16x8, q);
+      D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B, B, D, 0, 0, 0);      // the fragments feed the matrix pipe, as in the forward
     }
-    asm volatile("" : "+v"(acc));
   }
+  for (int k = 0; k < 16; ++k) acc += __float_as_uint(D[k]);
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-// patterns: 0 = b32 at a 45-word lane stride (the rasterizer's SH slab), 1 = b32 at stride 1, 2 = b128 at stride 4 words, 3 = a VALU chain evaluated twice
+// patterns: 0 = b32 at a 45-word lane stride (the rasterizer's SH slab), 1 = b32 at stride 1, 2 = b128 at stride 4 words, 3 = 80 live registers incremented in place
 __global__ __launch_bounds__(64) void victim(int iters, unsigned long long* bad /* [4][64] */) {
   __shared__ __attribute__((aligned(16))) uint32_t slab[2880];             // 11 520 bytes
   const int lane = threadIdx.x;
@@ -67,25 +73,22 @@ __global__ __launch_bounds__(64) void victim(int iters, unsigned long long* bad 
       nbad[2] += (q.x != salt + e * 2246822519u) + (q.y != salt + (e + 1) * 2246822519u) + (q.z != salt + (e + 2) * 2246822519u) + (q.w != salt + (e + 3) * 2246822519u);
     }
     {
-      // VALU only: the same chain (fma, rsq, rcp, sqrt) evaluated twice from copies of the same registers
-      float x0 = __uint_as_float(0x3f800000u | ((salt + lane * 977u) & 0x7fffffu)), x1 = x0;
-      asm volatile("" : "+v"(x0));
-      asm volatile("" : "+v"(x1));
-      float a0 = 0.f, a1 = 0.f;
+      // registers only: 80 live counters, each incremented 64 times by its own constant; a lost write, a foreign write or a
+      // stale read shows as a wrong final value
+      // (under a PARTIAL exec mask, like the colour of the visible Gaussians in the preprocess kernel, and with fp32 fmac
+      // against literals, like its SH basis)
+      const bool active = (((salt >> 7) + lane * 2654435761u) >> 13 & 3u) != 0u;
+      if (active) {
+        float r[80];
 #pragma unroll
-      for (int k = 0; k < 48; ++k) {
-        const float c = 0.37f + 0.01f * k;
-        a0 = fmaf(a0, 0.5f, c * __builtin_amdgcn_rsqf(x0 + c) + __builtin_amdgcn_sqrtf(fmaf(x0, c, 1.f)) * __builtin_amdgcn_rcpf(x0 + 2.f * c));
-        x0 = fmaf(x0, 1.0001f, 0.001f);
-      }
-      asm volatile("" : "+v"(a0));
+        for (int k = 0; k < 80; ++k) { r[k] = (float)((lane + k) & 15); asm volatile("" : "+v"(r[k])); }
+        for (int rep = 0; rep < 64; ++rep) {
 #pragma unroll
-      for (int k = 0; k < 48; ++k) {
-        const float c = 0.37f + 0.01f * k;
-        a1 = fmaf(a1, 0.5f, c * __builtin_amdgcn_rsqf(x1 + c) + __builtin_amdgcn_sqrtf(fmaf(x1, c, 1.f)) * __builtin_amdgcn_rcpf(x1 + 2.f * c));
-        x1 = fmaf(x1, 1.0001f, 0.001f);
+          for (int k = 0; k < 80; ++k) { r[k] = fmaf(r[(k + 1) % 80 < 80 ? k : k], 1.0f, 3.0f); asm volatile("" : "+v"(r[k])); }
+        }
+#pragma unroll
+        for (int k = 0; k < 80; ++k) nbad[3] += r[k] != (float)((lane + k) & 15) + 192.0f;
       }
-      nbad[3] += __float_as_uint(a0) != __float_as_uint(a1);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -110,7 +113,7 @@ static void run(const char* label, int mode /* 0 none, 1 plain, 2 transposing */
   printf("%-28s victim stream: %.2f ms for 10 launches\n", label, ms);
   unsigned long long h[256];
   CK(hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost));
-  const char* names[4] = {"b32 stride 45", "b32 stride 1", "b128", "VALU twice"};
+  const char* names[4] = {"b32 stride 45", "b32 stride 1", "b128", "80 registers"};
   for (int p = 0; p < 4; ++p) {
     unsigned long long tot = 0, q[4] = {0, 0, 0, 0};
     for (int l = 0; l < 64; ++l) { tot += h[p * 64 + l]; q[l >> 4] += h[p * 64 + l]; }
