@@ -351,8 +351,24 @@ def last_geom_view(P: int) -> dict:
     return geom_view(_Policy.last_geom, P)
 
 
+_LAST_STREAM: dict = {}     # device index -> the stream of the library's most recent launch sequence on that device
+
+
 def _stream(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The caller's current HIP stream -- every launch sequence of the library goes to it, in order.
+
+    Launch sequences of ONE device are also kept in order ACROSS streams: when the current stream is not the one the previous
+    sequence went to, it first waits (on the device, no host synchronisation) for that stream.  Two sequences of the library
+    sharing the chip is not a supported mode: measured in round 4, the per-Gaussian kernels produce wrong values while a
+    compositing kernel (transposing LDS reads, `ds_read_b64_tr_b16`) of another sequence is resident on their CU
+    (profiles/r4_two_streams.md).  Costs nothing while the caller stays on one stream."""
+    cur = torch.cuda.current_stream(device)
+    prev = _LAST_STREAM.get(cur.device_index)
+    if prev is None or prev.cuda_stream != cur.cuda_stream:
+        if prev is not None:
+            cur.wait_stream(prev)
+        _LAST_STREAM[cur.device_index] = cur
+    return C.c_void_p(cur.cuda_stream)
 
 
 def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
