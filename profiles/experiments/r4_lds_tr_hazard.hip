@@ -45,7 +45,7 @@ __global__ __launch_bounds__(128) void aggressor(int iters, uint32_t* sink) {
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-// patterns: 0 = b32 at a 45-word lane stride (the rasterizer's SH slab), 1 = b32 at stride 1, 2 = b128 at stride 4 words, 3 = 80 live registers incremented in place
+// patterns: 0 = b32 at a 45-word lane stride (the rasterizer's SH slab), 1 = b32 at stride 1, 2 = fp32 fmacs while 45 LDS reads are outstanding, 3 = 80 live registers incremented in place
 __global__ __launch_bounds__(64) void victim(int iters, unsigned long long* bad /* [4][64] */) {
   __shared__ __attribute__((aligned(16))) uint32_t slab[2880];             // 11 520 bytes
   const int lane = threadIdx.x;
@@ -65,12 +65,29 @@ __global__ __launch_bounds__(64) void victim(int iters, unsigned long long* bad 
     for (int k = 0; k < 45; ++k) v[k] = ((volatile uint32_t*)slab)[k * 64 + lane];
 #pragma unroll
     for (int k = 0; k < 45; ++k) nbad[1] += v[k] != salt + (uint32_t)(k * 64 + lane) * 2246822519u;
+    {
+      // fp32 fmacs on live registers WHILE 45 LDS reads of this wave are still outstanding (the preprocess kernel evaluates the
+      // SH basis while its coefficient reads are in flight), under a partial exec mask
+      const bool act2 = (((salt >> 5) + lane * 2246822519u) >> 11 & 3u) != 0u;
+      if (act2) {
+        uint32_t w[45];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-      const u4 q = *(volatile u4*)(slab + 4 * (k * 64 + lane));
-      const uint32_t e = 4 * (k * 64 + lane);
-      nbad[2] += (q.x != salt + e * 2246822519u) + (q.y != salt + (e + 1) * 2246822519u) + (q.z != salt + (e + 2) * 2246822519u) + (q.w != salt + (e + 3) * 2246822519u);
+        for (int k = 0; k < 45; ++k) w[k] = slab[lane * 45 + k];
+        float r[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { r[k] = (float)((lane + k) & 15); asm volatile("" : "+v"(r[k])); }
+#pragma unroll
+        for (int rep = 0; rep < 6; ++rep) {
+#pragma unroll
+          for (int k = 0; k < 24; ++k) { r[k] = fmaf(r[k], 1.0f, 3.0f); asm volatile("" : "+v"(r[k])); }
+        }
+        uint32_t ok = 0;
+#pragma unroll
+        for (int k = 0; k < 45; ++k) ok += w[k] == salt + (uint32_t)(lane * 45 + k) * 2246822519u;
+        nbad[2] += 45 - ok;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) nbad[2] += r[k] != (float)((lane + k) & 15) + 18.0f;
+      }
     }
     {
       // registers only: 80 live counters, each incremented 64 times by its own constant; a lost write, a foreign write or a
@@ -113,7 +130,7 @@ static void run(const char* label, int mode /* 0 none, 1 plain, 2 transposing */
   printf("%-28s victim stream: %.2f ms for 10 launches\n", label, ms);
   unsigned long long h[256];
   CK(hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost));
-  const char* names[4] = {"b32 stride 45", "b32 stride 1", "b128", "80 registers"};
+  const char* names[4] = {"b32 stride 45", "b32 stride 1", "fmac under reads", "80 registers"};
   for (int p = 0; p < 4; ++p) {
     unsigned long long tot = 0, q[4] = {0, 0, 0, 0};
     for (int l = 0; l < 64; ++l) { tot += h[p * 64 + l]; q[l >> 4] += h[p * 64 + l]; }

@@ -352,6 +352,7 @@ def last_geom_view(P: int) -> dict:
 
 
 _LAST_STREAM: dict = {}     # device index -> the stream of the library's most recent launch sequence on that device
+_UNORDERED_STREAMS = os.environ.get("TRASE_UNORDERED_STREAMS", "0") != "0"   # experiments only (profiles/r4_two_streams.md): no cross-stream wait
 
 
 def _stream(device) -> C.c_void_p:
@@ -365,7 +366,7 @@ def _stream(device) -> C.c_void_p:
     cur = torch.cuda.current_stream(device)
     prev = _LAST_STREAM.get(cur.device_index)
     if prev is None or prev.cuda_stream != cur.cuda_stream:
-        if prev is not None:
+        if prev is not None and not _UNORDERED_STREAMS:
             cur.wait_stream(prev)
         _LAST_STREAM[cur.device_index] = cur
     return C.c_void_p(cur.cuda_stream)
