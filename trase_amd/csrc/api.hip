@@ -113,7 +113,7 @@ static int list_pack_bits(const TraseRastSettings* s, int P) {
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 6 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p);
+  return align_up(sizeof(uint32_t) * p) * 7 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -123,6 +123,7 @@ PreBuf carve_pre(void* ptr, int P) {
   for (int i = 0; i < 2; ++i) { t.sort.vals[i] = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p); }
   t.offsets = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
+  t.live_ids = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3);
   t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
@@ -586,7 +587,7 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
                             ranged ? p_begin : -1, ranged ? p_end : -1, live_only);
     if (rc) return rc;
     rc = launch_preprocess_bwd_raw(c, *s, *raw, out->radii, g, acc, *gr, ranged ? p_begin : 0, ranged ? p_end : raw->P,
-                                   (live_only && d_feats && !sparse) ? 1 : 0, sparse ? pre.sort.vals[0] : nullptr);
+                                   (live_only && d_feats && !sparse) ? 1 : 0, sparse ? pre.live_ids : nullptr);
   }
   return rc;
 }

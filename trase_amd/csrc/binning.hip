@@ -323,6 +323,7 @@ __global__ __launch_bounds__(SC_THREADS) void compact_scatter_kernel(const uint3
                                                                      const uint32_t* __restrict__ block_cnt, int nblocks,
                                                                      uint32_t* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ ids_out,
+                                                                     uint32_t* __restrict__ live_ids,
                                                                      uint32_t* __restrict__ hdr) {
   __shared__ uint32_t sh[SC_THREADS / 64];
   __shared__ uint32_t sh2[SC_THREADS / 64];
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(SC_THREADS) void compact_scatter_kernel(const uint3
     if (t[j] != 0) {
       keys_out[live_before] = k[j];
       ids_out[live_before] = (uint32_t)i;
+      live_ids[live_before] = (uint32_t)i;        // (ids_out is re-ordered by the depth sort; this copy stays ascending)
       ++live_before;
     } else {
       ids_out[total + (uint32_t)i - live_before] = (uint32_t)i;               // behind the live ones, ascending
@@ -375,7 +377,7 @@ int launch_compact_live(const LaunchCtx& c, const GeomBuf& g, int P, const PreBu
     ProfScope ps("compact_live", c.stream);
     hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, P, t.block_sums);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(SC_THREADS), 0, c.stream, g.tiles, keys_raw, P, t.block_sums,
-                       nblocks, keys_out, ids_out, g.hdr);
+                       nblocks, keys_out, ids_out, t.live_ids, g.hdr);
   }
   TRASE_POST_LAUNCH("compact_live", c.stream, c.debug);
   return TRASE_OK;

@@ -311,6 +311,8 @@ struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
   uint32_t* offsets;       // (P) inclusive scan of tiles in depth-rank order
   uint32_t* id_end;        // (P) the same, indexed by Gaussian id: the pairs of Gaussian i are [id_end[i] - tiles[i], id_end[i])
   uint32_t* block_sums;    // scan partials: (P/1024 + 2) of the live sub-tile counts, then as many of the rect areas
+  uint32_t* live_ids;      // (P) tile-row strips: the ids of the Gaussians with a pair in the strip, ASCENDING (the sorted list in
+                           // sort.vals[0] visits memory in depth order: scattered rows; this one walks it monotonically)
 };
 struct PairBuf {           // stage-2 scratch (capacity-sized)
   SortBufs sort;           // vals[] = {spare, bin.pair_slot} arranged by the caller

@@ -455,7 +455,7 @@ int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pr
   {
     ProfScope ps("zero_live_rows", c.stream);
     const size_t nb = ((size_t)P * 16 + 255) / 256;
-    hipLaunchKernelGGL(zero_live_rows_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, c.stream, z, pre.sort.vals[0],
+    hipLaunchKernelGGL(zero_live_rows_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, c.stream, z, pre.live_ids,
                        g.hdr + (HDR_WORDS - 1), P);
   }
   TRASE_POST_LAUNCH("zero_live_rows", c.stream, c.debug);
