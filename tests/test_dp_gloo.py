@@ -297,3 +297,57 @@ def test_inplace_accumulation_into_another_slice_does_not_trip_the_overlap_check
         raise AssertionError("an in-place write to an exchanged gradient must raise")
     except RuntimeError as e:
         assert "modified in place" in str(e)
+
+
+class _FakeEvent:
+    def record(self, *_):
+        pass
+
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+
+def _guard_worker(rank, world, port, out):
+    """the MAX-reduced guard header must be refreshed for EVERY forward although the pinned header buffer
+    (and hence its id) is the same object for consecutive forwards; and only the flag words are shared."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd import rasterizer as R
+    saved = (R._Policy.sync, R._Policy.capacity, R._Policy.pending, R._Policy.rollbacks)
+    R._Policy.sync, R._Policy.capacity = False, 1000 + rank
+    pin = torch.zeros(32, dtype=torch.int32)                 # ONE pin object recycled for every forward (the LIFO ring)
+    seen = []
+    # which rank overflows in which iteration: 1 -> rank 1 only; 2 -> nobody; 3 -> rank 0 only; 4 -> rank 1 again
+    plan = [(1,), (), (0,), (1,)]
+    for it, who in enumerate(plan):
+        R._release_last()
+        hdr = torch.zeros(64, dtype=torch.int32)
+        hdr[1] = int(rank in who)                            # overflow flag
+        hdr[2] = 100 * (it + 1) + rank                       # pairs needed
+        hdr[62] = 5000 + rank                                # a per-rank word (capacity): must stay local
+        geom = hdr.view(torch.uint8).clone()
+        R._Policy.pending = [(_FakeEvent(), pin, 1000 + rank)]
+        R._Policy.rollbacks = {id(pin): []}
+        R._Policy.last_geom = geom
+        R._Policy.forward_seq += 1                           # what _after_render does for a sync-free forward
+        g1, _ = R.current_guard()
+        g2, _ = R.current_guard()                            # FusedAdam.step + add_densification_stats: ONE collective
+        assert g1 is g2
+        seen.append((int(g1[1]), int(g1[2]), int(g1[62]), int(pin[1])))
+    want = [(1, 101, 5000 + rank, 1), (0, 201, 5000 + rank, 0), (1, 301, 5000 + rank, 1), (1, 401, 5000 + rank, 1)]
+    out[rank] = seen == want
+    R._Policy.sync, R._Policy.capacity, R._Policy.pending, R._Policy.rollbacks = saved
+    R._Policy.last_geom = None
+    dist.destroy_process_group()
+
+
+def test_guard_header_is_reduced_for_every_forward_with_a_recycled_pin():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_guard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

@@ -57,7 +57,8 @@ class _Policy:
     last_bin: Optional[torch.Tensor] = None     # bin workspace of the most recent forward (for last_tile_row_loads)
     last_hw = None
     last_strip = (0, 0)         # tile-row strip the most recent forward ran with
-    guard_reduced = None        # (id(pinned header), device int32[64]) -- the header MAX-reduced over the ranks (see current_guard)
+    guard_reduced = None        # (forward_seq, device int32[64]) -- header with its FLAG words MAX-reduced over the ranks (see current_guard)
+    forward_seq = 0             # counts sync-free forwards: the key of guard_reduced (pinned buffers are recycled, ids repeat)
     last_capacity = 0
     pending: list = []          # [(event, pinned int32[32] header copy, capacity of that call)]
     rollbacks: dict = {}        # id(pinned header) -> callbacks to run if that forward turns out to have overflowed
@@ -216,15 +217,36 @@ def current_guard():
         # 256-byte collective, stream-ordered, no host synchronisation); the guarded kernels test that copy, and the pinned
         # host copy the overflow report reads is refreshed from it, so the host-side rollbacks agree across ranks as well.
         # Every rank calls this the same number of times in the same order (FusedAdam.step / add_densification_stats).
+        # The cache is keyed on the forward's sequence number: pinned header buffers are recycled (LIFO) as soon as their
+        # verdict has been read, so the SAME pin object serves consecutive forwards and its id says nothing (with
+        # id(pin) as the key the all-reduce was skipped for every later forward on the ranks that happened to reuse a pin --
+        # stale flags, and a collective some ranks issued and others did not).
         red = _Policy.guard_reduced
-        if red is None or red[0] != id(pin):
+        if red is None or red[0] != _Policy.forward_seq:
             buf = guard[:256].view(torch.int32).clone()
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+            # only the FLAG words are shared (overflow, pairs needed, key / slot guards): the rest of the header (capacity,
+            # live count, pack bits of THIS rank's strip) stays local, so reports and capacity growth describe this rank
+            idx = _flag_index(buf.device)
+            flags = buf.index_select(0, idx)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            buf.index_copy_(0, idx, flags)
             pin.copy_(buf[:32], non_blocking=True)
-            ev.record(torch.cuda.current_stream(guard.device))     # the poll now waits for the reduced copy
-            _Policy.guard_reduced = red = (id(pin), buf)
+            if guard.is_cuda:
+                ev.record(torch.cuda.current_stream(guard.device))     # the poll now waits for the reduced copy
+            _Policy.guard_reduced = red = (_Policy.forward_seq, buf)
         guard = red[1]
     return guard, _Policy.rollbacks.setdefault(id(pin), []).append
+
+
+_FLAG_WORDS = (1, 2, 16, 20)     # geom header: overflow flag, pairs needed, key guard, slot guard (common.h GeomHeader)
+_FLAG_INDEX: dict = {}
+
+
+def _flag_index(device) -> torch.Tensor:
+    t = _FLAG_INDEX.get(device)
+    if t is None:
+        t = _FLAG_INDEX[device] = torch.tensor(_FLAG_WORDS, dtype=torch.int64, device=device)
+    return t
 
 
 def check_overflow():
@@ -270,13 +292,16 @@ def _release_last():
     second launch-graph record missed, and the peak memory was one bin buffer higher."""
     _Policy.last_geom = None
     _Policy.last_bin = None
+    _Policy.guard_reduced = None
 
 
 def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor] = None, hw=None):
     _Policy.last_geom, _Policy.last_capacity = geom, capacity
     _Policy.last_bin, _Policy.last_hw = binb, hw
     _Policy.last_strip = tuple(_Policy.tile_rows)
+    _Policy.guard_reduced = None
     if not _Policy.sync:
+        _Policy.forward_seq += 1
         if _PIN_RING:
             pin, ev = _PIN_RING.pop()
         else:

@@ -54,17 +54,23 @@ def set_forward_scope(scope: str = "all") -> None:
 
 # sparse strip gradients (rasterizer.set_sparse_strip_grads): persistent gradient tensors, zero outside the rows the most recent
 # strip backward wrote; `prev` = (geom, pre) workspaces of the forward whose backward wrote them (its live-Gaussian list)
-_SPARSE: dict = {"bufs": {}, "prev": None}
+# `where` = (P, device) every cached buffer was made for; `fwd_seq` = number of the most recent strip forward that asked for
+# sparse gradients (a backward of an OLDER forward allocates densely: the persistent buffers belong to the newest one)
+_SPARSE: dict = {"bufs": {}, "prev": None, "where": None, "fwd_seq": 0}
 
 
 def _sparse_buf(name: str, like: torch.Tensor) -> torch.Tensor:
-    key = (name, tuple(like.shape), like.device)
-    b = _SPARSE["bufs"].get(key)
-    if b is None:
-        if any(k[0] == name for k in _SPARSE["bufs"]):        # the parameter set changed (densify / prune): start over
-            _SPARSE["bufs"] = {k: v for k, v in _SPARSE["bufs"].items() if k[0] != name}
+    where = (int(like.shape[0]), like.device)
+    if _SPARSE["where"] != where:
+        # the parameter set changed (densify / prune) or moved: EVERY cached buffer is for the old Gaussian count, also the
+        # ones this backward does not ask for -- the row-clearing pass takes all of them and indexes rows up to the new P
+        # (an out-of-bounds device write when only the same-named buffer was dropped)
+        _SPARSE["bufs"], _SPARSE["prev"], _SPARSE["where"] = {}, None, where
+    b = _SPARSE["bufs"].get(name)
+    if b is None or b.shape != like.shape:
+        if b is not None:                                     # same P, another trailing shape (feature width changed)
             _SPARSE["prev"] = None
-        b = _SPARSE["bufs"][key] = torch.zeros_like(like)
+        b = _SPARSE["bufs"][name] = torch.zeros_like(like)
     return b
 
 
@@ -168,6 +174,9 @@ class _RenderRaw(torch.autograd.Function):
         _after_render(geom, capacity, binb, (H, W))
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
         ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
+        if (s.variant & _r_VARIANT_SPARSE) and (s.tile_row_begin != 0 or s.tile_row_end != 0):
+            _SPARSE["fwd_seq"] += 1
+            ctx.sparse_seq = _SPARSE["fwd_seq"]
         ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
         ctx.norm_features = bool(norm_features)
         ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
@@ -219,6 +228,12 @@ class _RenderRaw(torch.autograd.Function):
         used_sink: set = set()
 
         sparse = bool(s.variant & _r_VARIANT_SPARSE) and (s.tile_row_begin != 0 or s.tile_row_end != 0) and _GRAD_CHUNKS is None and P > 0
+        if sparse and getattr(ctx, "sparse_seq", -1) != _SPARSE["fwd_seq"]:
+            # another strip forward has run since this one: the persistent buffers (and the rows to clear) belong to ITS
+            # backward; handing them out here would overwrite gradients autograd has not consumed yet.  Dense tensors instead.
+            sparse = False
+        leaf_of = {"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation,
+                   "gfeat": gfeat}
         sparse_used: dict = {}
 
         def alloc(flag, like, name=None, sname=None):
@@ -226,6 +241,14 @@ class _RenderRaw(torch.autograd.Function):
                 return None
             if sparse and sname:
                 b = sparse_used[sname] = _sparse_buf(sname, like)
+                leaf = leaf_of.get(sname)
+                if leaf is not None and leaf.grad is not None and leaf.grad.data_ptr() == b.data_ptr():
+                    raise RuntimeError(
+                        f"trase_amd: sparse strip gradients: the .grad of `{sname}` still IS the persistent gradient buffer of the "
+                        "previous strip backward (kept, or zeroed in place).  This backward clears and rewrites that buffer, and "
+                        "autograd would then add it to itself.  Drop the gradients between backwards "
+                        "(`p.grad = None` / `zero_grad(set_to_none=True)`), clone what you keep, or accumulate with "
+                        "set_sparse_strip_grads(False).")
                 return b.view(b.shape)
             ent = _GRAD_SINK.get(pid[name]) if (_GRAD_SINK and name) else None
             if ent is not None:
@@ -265,7 +288,7 @@ class _RenderRaw(torch.autograd.Function):
             if prev is not None and prev[2] == P:
                 pgeom, ppre, _, pF = prev
                 zg = _lib.RastRawGrads()
-                by = {k[0]: v for k, v in _SPARSE["bufs"].items()}
+                by = {k: v for k, v in _SPARSE["bufs"].items() if v.shape[0] == P}
                 zg.dL_dxyz, zg.dL_dd_xyz, zg.dL_dmeans2D = _lib.ptr(by.get("xyz")), _lib.ptr(by.get("dxyz")), _lib.ptr(by.get("m2d"))
                 zg.dL_dfeatures_dc, zg.dL_dfeatures_rest, zg.dL_dopacity = _lib.ptr(by.get("f_dc")), _lib.ptr(by.get("f_rest")), _lib.ptr(by.get("opacity"))
                 zg.dL_dscaling, zg.dL_dd_scaling = _lib.ptr(by.get("scaling")), _lib.ptr(by.get("dscaling"))
