@@ -337,6 +337,22 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
 int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_xyz, const float* dL_dd_rotation,
                        const float* dL_dd_scaling, const void* saved, size_t saved_bytes, const TraseMlpGrads* grads,
                        void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+/* The same pair with a ROW ORDER: batch row r evaluates Gaussian row_order[r] (a permutation of 0..N-1, int32, device;
+ * NULL = identity = the two entry points above).  Inputs are gathered and outputs / cotangents addressed through it, so the
+ * caller sees the reference's row order on both sides; the saved state is in batch order and the same row_order must be
+ * handed to the backward.  Why: a Gaussian the view culled (radii == 0, gaussian_renderer/__init__.py:152) sends back an
+ * exactly-zero cotangent and contributes nothing to any parameter gradient of utils/time_utils.py:106-131; the backward skips
+ * every 32-row tile whose cotangents are all zero (with or without a row order), and culling is spatially coherent, so an
+ * order that follows a space-filling curve turns the culled quarter of an orbit view into whole dead tiles. */
+int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                                 const int32_t* row_order, float* d_xyz, float* d_rotation, float* d_scaling, void* saved,
+                                 size_t saved_bytes, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* row_order, const float* dL_dd_xyz,
+                            const float* dL_dd_rotation, const float* dL_dd_scaling, const void* saved, size_t saved_bytes,
+                            const TraseMlpGrads* grads, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+/* Introspection: number of live 32-row tiles the backward that last used `bwd_ws` (N rows) worked on, copied
+ * (stream-ordered, device to device) into one int32 of the caller. */
+int trase_mlp_live_tiles(const void* bwd_ws, size_t ws_bytes, int32_t N, int32_t* n_live_device, trase_stream_t stream);
 
 /* ---- KNN feature smoothing of the FEATURE state ------------------------------------
  * GaussianModel.get_smoothed_gaussian_features (scene/gaussian_model.py:79-104; gaussian_renderer/__init__.py:118,

@@ -811,6 +811,65 @@ def test_deform_mlp_training_step_matches_bf16_evaluated_autograd(n):
             assert rel < 5e-2 and err < 1e-1 * scale + 1e-6, f"{use} grad {k}: rel L2 {rel:.3e}, max abs {err:.3e} vs scale {scale:.3e}"
 
 
+def test_deform_mlp_dead_rows_and_row_order():
+    """The training pair with a ROW ORDER and dead-tile skipping (trase_mlp_forward_train_rows / trase_mlp_backward_rows):
+    (a) outputs are bit-identical with and without the Morton row order (every row is the same arithmetic, only its
+    tile neighbours change); (b) with the cotangents of a spatial slab of Gaussians exactly zero -- what a view's culled
+    Gaussians send back -- all 22 parameter gradients equal those of the index order (where no 32-row tile is dead) to
+    fp32 reassociation (the dead rows contribute exact zeros either way; the split of the row reduction differs), and
+    the bf16-evaluated autograd to the usual bound; (c) all cotangents zero gives exactly-zero gradients; (d) the
+    backward really skips: the live-tile count read back from the workspace is well below the tile count."""
+    from trase_amd import deform
+    from trase_amd.deform import DeformNetworkHIP
+    from trase_amd.synthetic import SynthDeformNetwork
+    torch.manual_seed(5)
+    n = 40_037                                              # ragged last tile, ~1250 tiles
+    net = SynthDeformNetwork().cuda()
+    hip = DeformNetworkHIP(net)
+    x = (torch.rand(n, 3, device="cuda") * 2 - 1) * 1.3
+    t = torch.tensor([[0.33]], device="cuda").expand(n, -1)
+    dead = x[:, 1].abs() > 0.9                              # the top and bottom slabs: ~30 % of the rows
+    g = [torch.randn(n, c, device="cuda") * (~dead)[:, None] for c in (3, 4, 3)]
+    assert 0.2 < float(dead.float().mean()) < 0.4
+
+    def run(mode, cot):
+        deform.set_row_order(mode)
+        net.zero_grad()
+        out = hip(x, t)
+        torch.autograd.backward(out, cot)
+        return [o.detach().clone() for o in out], {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    deform.track_live_tiles(True)
+    try:
+        out_m, grad_m = run("morton", g)
+        out_n, grad_n = run("none", g)
+        for a, b in zip(out_m, out_n):
+            assert torch.equal(a, b)
+        for k in grad_n:
+            scale = float(grad_n[k].abs().max())
+            assert float((grad_m[k] - grad_n[k]).abs().max()) <= 2e-5 * scale + 1e-9, k
+        net.zero_grad()
+        a = _bf16_evaluated_net(net, x, t.contiguous())
+        torch.autograd.backward(a, g)
+        for k, p in net.named_parameters():
+            rel = float((grad_m[k] - p.grad).norm() / p.grad.norm())
+            assert rel < 5e-2, f"{k}: rel L2 {rel:.3e} vs the bf16-evaluated autograd"
+        _, grad_z = run("morton", [torch.zeros_like(v) for v in g])
+        assert all(float(v.abs().max()) == 0.0 for v in grad_z.values())
+        # (d) live tiles of the last two Morton-ordered backwards, straight from the library
+        from trase_amd.deform import last_live_tiles
+        tiles = (n + 31) // 32
+        assert last_live_tiles() == 0
+        run("morton", g)
+        live = last_live_tiles()
+        assert 0 < live < 0.85 * tiles, (live, tiles)
+        run("none", g)
+        assert last_live_tiles() == tiles                   # index order: every tile holds a live row
+    finally:
+        deform.set_row_order("morton")
+        deform.track_live_tiles(False)
+
+
 def test_deform_mlp_blender_variant_matches_reference_golden_and_bf16_autograd():
     """is_blender DeformNetwork (D-NeRF scenes: t_multires = 6 and a timenet whose 30 outputs replace PE(t),
     utils/time_utils.py:74-86, :107-109).  (a) Forward against golden vectors from the imported reference

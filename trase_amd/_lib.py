@@ -150,6 +150,13 @@ SYMBOLS = [
     ("trase_mlp_backward", C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.POINTER(MlpGrads), C.c_void_p, C.c_size_t, C.c_int32,
                                      C.c_void_p]),
+    ("trase_mlp_forward_train_rows", C.c_int, [C.POINTER(MlpWeights), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                               C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_mlp_backward_rows", C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.POINTER(MlpGrads), C.c_void_p, C.c_size_t, C.c_int32,
+                                          C.c_void_p]),
+    ("trase_mlp_live_tiles", C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p]),
     ("trase_smooth_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_smooth_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32,

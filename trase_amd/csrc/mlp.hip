@@ -271,7 +271,9 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
                                                  const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                                                  float* __restrict__ d_xyz, float* __restrict__ d_rot,
                                                  float* __restrict__ d_scale, __bf16* __restrict__ actsT,
-                                                 uint32_t* __restrict__ gates) {
+                                                 uint32_t* __restrict__ gates, const int* __restrict__ ro = nullptr) {
+  // ro (row order, training only): batch row r evaluates Gaussian ro[r] -- inputs are gathered and the ten outputs scattered
+  // through it; everything saved for the backward (images, gates) is in BATCH order (see "dead rows" below)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int wr = wave & 1, wc = wave >> 1;
@@ -280,7 +282,8 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
   float px[BRG][4];                            // x, y, z, t of this lane's row in each group: the encoding is generated
 #pragma unroll                                 // on the fly in the six encoding K-steps of layers 0 and 5
   for (int g = 0; g < BRG; ++g) {
-    const int gm = min(row0 + 32 * g + m, N - 1);
+    int gm = min(row0 + 32 * g + m, N - 1);
+    if (ro) gm = ro[gm];
     px[g][0] = x[3 * gm]; px[g][1] = x[3 * gm + 1]; px[g][2] = x[3 * gm + 2]; px[g][3] = t[(size_t)gm * t_stride];
   }
   const bool blender = net.temb != nullptr;
@@ -452,19 +455,27 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
       hacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, hacc[g], 0, 0, 0);
     }
   }
+  // the ten outputs of a row sit in two lanes (h = 0: outputs 0-3, 8, 9; h = 1: 4-7): one cross-half exchange of register 3
+  // (v_permlane32_swap) gives lane h = 0 the rows of d_xyz and d_scaling and lane h = 1 the row of d_rotation -- three wide
+  // stores per row instead of ten dwords (with a row order every dword store touched a line of its own)
 #pragma unroll
   for (int g = 0; g < BRG; ++g) {
-    const int grow = row0 + 32 * g + m;
-    if (grow < N) {
+    int grow = row0 + 32 * g + m;
+    const bool ok = grow < N;
+    if (ok && ro) grow = ro[grow];
+    float o[6];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int o = 8 * (r >> 2) + 4 * h + (r & 3);
-        if (o < 10) {
-          const float v = hacc[g][r] + net.b_head[o];
-          if (o < 3) d_xyz[(size_t)grow * 3 + o] = v;
-          else if (o < 7) d_rot[(size_t)grow * 4 + (o - 3)] = v;
-          else d_scale[(size_t)grow * 3 + (o - 7)] = v;
-        }
+    for (int r = 0; r < 6; ++r) o[r] = hacc[g][r] + net.b_head[8 * (r >> 2) + 4 * h + (r & 3)];
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[3]), __float_as_uint(o[3]), false, false);
+    const float other3 = __uint_as_float(h ? sw[0] : sw[1]);       // h = 0 receives output 7, h = 1 receives output 3
+    if (ok) {
+      if (h == 0) {
+        float* px3 = d_xyz + (size_t)grow * 3;
+        px3[0] = o[0]; px3[1] = o[1]; px3[2] = o[2];
+        float* ps3 = d_scale + (size_t)grow * 3;
+        ps3[0] = other3; ps3[1] = o[4]; ps3[2] = o[5];
+      } else {
+        *reinterpret_cast<float4*>(d_rot + (size_t)grow * 4) = make_float4(other3, o[0], o[1], o[2]);
       }
     }
   }
@@ -481,13 +492,13 @@ void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __
 __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mlp_fwd_train_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                               float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
-                              __bf16* __restrict__ actsT, uint4* __restrict__ gates) {
+                              __bf16* __restrict__ actsT, uint4* __restrict__ gates, const int* __restrict__ ro) {
   __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];
   if ((int)(blockIdx.x + 1) * BROWS <= N)
-    mlp_fwd_blk_body<true, true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
+    mlp_fwd_blk_body<true, true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro);
   else
-    mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates));
+    mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro);
 }
 
 // ---- training backward ------------------------------------------------------------------------------------
@@ -533,53 +544,141 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
 // transposed image of the bf16 positional encoding, [tile][2][96][16] (columns 84..95 and padding rows zero):
 // the GEMM input of layers 0 and 5
 __global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
-                                                     const float* __restrict__ temb, int N, __bf16* __restrict__ peT) {
-  // one thread per (tile, half, column): its 16 rows are 32 contiguous bytes of the image.  A column reads ONE input per
-  // row (its coordinate, or t) -- one thread per element issued four loads and a 2-byte store per value.
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)((N + 31) >> 5) * 2 * EMBP;
-  if (tid >= total) return;
-  const int c = (int)(tid % EMBP), half = (int)((tid / EMBP) & 1);
-  const int row0 = (int)(tid / (2 * EMBP)) * 32 + 16 * half;
-  // which input the column depends on: 0..2 = coordinate, 3 = t, -1 = none (padding / timenet columns)
-  int src = -1;
-  if (c < 3) src = c;
-  else if (c < 63) src = ((c - 3) % 6) % 3;
-  else if (!temb && c < EMB_T) src = 3;
-  bf16x8 o[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + r;
-    float v = 0.f;
+                                                     const float* __restrict__ temb, int N, __bf16* __restrict__ peT,
+                                                     const int* __restrict__ ro) {
+  // A workgroup owns 128 batch rows (four image tiles): their inputs (x, y, z, t -- gathered through the row order) are read
+  // ONCE into LDS, then every thread produces (half-tile, column) pieces: 16 rows of one column = 32 contiguous image bytes,
+  // from sixteen broadcast LDS reads.  (One thread per piece reading its inputs from memory re-read every row 96 times and,
+  // with a row order, through a dependent index load each time.)
+  __shared__ float4 rows[128];
+  const int row_base = blockIdx.x * 128;
+  if (threadIdx.x < 128) {
+    const int row = row_base + threadIdx.x;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < N) {
-      const float in = src < 0 ? 0.f : (src == 3 ? t[(size_t)row * t_stride] : x[3 * (size_t)row + src]);
-      v = pe_value(c, in, in, in, in, temb);               // the column picks the one argument it uses
+      const size_t gr = ro ? ro[row] : row;
+      v = make_float4(x[3 * gr], x[3 * gr + 1], x[3 * gr + 2], temb ? 0.f : t[gr * (size_t)t_stride]);
     }
-    o[r >> 3][r & 7] = (__bf16)v;
+    rows[threadIdx.x] = v;
   }
-  bf16x8* dst = reinterpret_cast<bf16x8*>(peT + tid * 16);
-  dst[0] = o[0]; dst[1] = o[1];
+  __syncthreads();
+  const int tiles = (N + 31) >> 5;
+  for (int piece = threadIdx.x; piece < 8 * EMBP; piece += 256) {      // 8 half-tiles x 96 columns
+    const int hf = piece / EMBP, c = piece % EMBP;
+    const int tile = blockIdx.x * 4 + (hf >> 1);
+    if (tile >= tiles) break;
+    // which input the column depends on: 0..2 = coordinate, 3 = t, -1 = none (padding / timenet columns)
+    int src = -1;
+    if (c < 3) src = c;
+    else if (c < 63) src = ((c - 3) % 6) % 3;
+    else if (!temb && c < EMB_T) src = 3;
+    bf16x8 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = hf * 16 + r;
+      float v = 0.f;
+      if (row_base + lr < N) {
+        const float4 q = rows[lr];
+        const float in = src < 0 ? 0.f : (src == 0 ? q.x : (src == 1 ? q.y : (src == 2 ? q.z : q.w)));
+        v = pe_value(c, in, in, in, in, temb);               // the column picks the one argument it uses
+      }
+      o[r >> 3][r & 7] = (__bf16)v;
+    }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(peT + ((size_t)tile * 2 + (hf & 1)) * (EMBP * 16) + (size_t)c * 16);
+    dst[0] = o[0]; dst[1] = o[1];
+  }
 }
 
-// backward data chain on the block-GEMM organisation of mlp_fwd_blk_body: the workgroup owns 128 rows and stages every
-// slab of the TRANSPOSED weights in LDS once; wave (wr, wc) owns rows wr*64.. x input columns wc*128..; the dZ tile lives in
-// the shared 64 KiB activation tile; every dZ_l leaves as a transposed image.  The head stage is a single K-step whose
-// four weight fragments each wave reads straight from L2.
+// Dead rows.  A Gaussian that the view culled (radii == 0: a quarter of them on the S4 orbit, more with a camera inside the cloud)
+// hands the network an exactly-zero cotangent: its dZ rows are zero in every layer and it adds nothing to any parameter gradient.
+// The backward therefore works on the LIVE 32-row tiles only: mlp_tile_flags / mlp_tile_list compact the ids of the tiles that
+// hold at least one row with a non-zero cotangent (ascending, deterministic); a chain workgroup takes four consecutive list
+// entries (its four 32-row groups need not be neighbours), the weight-gradient GEMMs walk the same list, and the dZ images of
+// dead tiles are neither written nor read.  Skipping works on whole tiles, so it pays when dead rows come in runs: the training
+// forward can evaluate the rows in a caller-given order (`ro`, trase_amd.deform sorts the Gaussians along a Morton curve: culling
+// is spatially coherent) -- batch row r is Gaussian ro[r], the saved state is in batch order, cotangents are gathered through ro.
+__global__ __launch_bounds__(256) void mlp_tile_flags_kernel(const float* __restrict__ g_xyz, const float* __restrict__ g_rot,
+                                                             const float* __restrict__ g_scale, int N,
+                                                             const int* __restrict__ ro, int* __restrict__ flags) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tile >= ((N + 31) >> 5)) return;
+  const int row = tile * 32 + (lane & 31);
+  bool nz = false;
+  if (row < N) {
+    const size_t sr = ro ? ro[row] : row;
+    auto live = [](float v) { return (__float_as_uint(v) & 0x7fffffffu) != 0u; };      // -0 is zero; NaN / Inf are kept
+    if (lane < 32) {
+      if (g_xyz) nz = live(g_xyz[3 * sr]) || live(g_xyz[3 * sr + 1]) || live(g_xyz[3 * sr + 2]);
+      if (g_scale) nz = nz || live(g_scale[3 * sr]) || live(g_scale[3 * sr + 1]) || live(g_scale[3 * sr + 2]);
+    } else if (g_rot) nz = live(g_rot[4 * sr]) || live(g_rot[4 * sr + 1]) || live(g_rot[4 * sr + 2]) || live(g_rot[4 * sr + 3]);
+  }
+  const bool any = __ballot(nz) != 0ull;
+  if (lane == 0) flags[tile] = any ? 1 : 0;
+}
+
+// one workgroup: ascending list of the live tile ids + their count.  Thread i owns the contiguous chunk [i c, (i + 1) c) of the
+// flags (all of its loads in flight at once), one workgroup-wide scan of the chunk counts places the chunks.
+__global__ __launch_bounds__(1024) void mlp_tile_list_kernel(const int* __restrict__ flags, int tiles, int* __restrict__ live,
+                                                             int* __restrict__ n_live) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CH = 16;                                     // flags per thread and pass: 16 K tiles = 524 k Gaussians per pass
+  int base = 0;
+  for (int t0 = 0; t0 < tiles; t0 += 1024 * CH) {
+    const int first = t0 + tid * CH;
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) bits |= (first + k < tiles && flags[first + k] != 0) ? (1u << k) : 0u;
+    const int cnt = __popc(bits);
+    int incl = cnt;                                          // inclusive scan over the wave (DPP row shifts + broadcasts)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = base, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
+    int at = pre + incl - cnt;
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      if (bits & (1u << k)) live[at++] = first + k;
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) *n_live = base;
+}
+
+// backward data chain on the block-GEMM organisation of mlp_fwd_blk_body: the workgroup owns four live 32-row tiles and stages
+// every slab of the TRANSPOSED weights in LDS once; wave (wr, wc) owns the groups 2 wr, 2 wr + 1 x input columns wc*128..; the dZ
+// tile lives in the shared 64 KiB activation tile; every dZ_l leaves as a transposed image.  The head stage is a single K-step
+// whose four weight fragments each wave reads straight from L2.
 __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const float* __restrict__ g_rot,
                              const float* __restrict__ g_scale, int N, const uint32_t* __restrict__ gates,
-                             __bf16* __restrict__ dzT, __bf16* __restrict__ gT) {
+                             __bf16* __restrict__ dzT, __bf16* __restrict__ gT, const int* __restrict__ ro,
+                             const int* __restrict__ live_list, const int* __restrict__ n_live_ptr) {
   __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];                   // 64 KiB
   __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];                 // 16 KiB
+  const int n_live = *n_live_ptr;
+  if ((int)blockIdx.x * (BROWS / 32) >= n_live) return;                             // (the grid covers the all-live case)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
   const int wr = wave & 1, wc = wave >> 1;
   const int lrow0 = wr * (BRG * MROWS);
-  const int row0 = blockIdx.x * BROWS + lrow0;
   const PatchLane pl = patch_lane(lrow0);
-  const int u_row0 = __builtin_amdgcn_readfirstlane(row0), u_wc = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int u_wr = __builtin_amdgcn_readfirstlane(wr), u_wc = __builtin_amdgcn_readfirstlane(wave >> 1);
   const int tiles = (N + 31) >> 5;
   const int sn = threadIdx.x;
+  int tg[BRG];                                                // tile of each 32-row group of this wave (wave-uniform), -1 = none
+#pragma unroll
+  for (int gi = 0; gi < BRG; ++gi) {
+    const int k = (int)blockIdx.x * (BROWS / 32) + BRG * u_wr + gi;
+    tg[gi] = k < n_live ? live_list[k] : -1;
+  }
   // slabs 0 and 1 of the first hidden stage (l = MD - 1) are requested before the head stage
   uint4 sa0, sa1, sb0, sb1;
   {
@@ -593,24 +692,25 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
   int gmr[BRG];
 #pragma unroll
   for (int gi = 0; gi < BRG; ++gi) {
-    const int grow = row0 + 32 * gi + m;
-    const int gm = min(grow, N - 1);
-    live[gi] = grow < N; gmr[gi] = gm;
+    const int grow = max(tg[gi], 0) * 32 + m;                 // batch row
+    const int gb = min(grow, N - 1);
+    live[gi] = tg[gi] >= 0 && grow < N; gmr[gi] = gb;
+    const size_t gm = ro ? ro[gb] : gb;                       // the Gaussian behind it
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
     if (live[gi]) {
       if (h == 0) {
-        if (g_xyz) { g[0] = g_xyz[3 * (size_t)gm]; g[1] = g_xyz[3 * (size_t)gm + 1]; g[2] = g_xyz[3 * (size_t)gm + 2]; }
-        if (g_rot) { g[3] = g_rot[4 * (size_t)gm]; g[4] = g_rot[4 * (size_t)gm + 1]; g[5] = g_rot[4 * (size_t)gm + 2]; g[6] = g_rot[4 * (size_t)gm + 3]; }
-        if (g_scale) g[7] = g_scale[3 * (size_t)gm];
-      } else if (g_scale) { g[0] = g_scale[3 * (size_t)gm + 1]; g[1] = g_scale[3 * (size_t)gm + 2]; }
+        if (g_xyz) { g[0] = g_xyz[3 * gm]; g[1] = g_xyz[3 * gm + 1]; g[2] = g_xyz[3 * gm + 2]; }
+        if (g_rot) { g[3] = g_rot[4 * gm]; g[4] = g_rot[4 * gm + 1]; g[5] = g_rot[4 * gm + 2]; g[6] = g_rot[4 * gm + 3]; }
+        if (g_scale) g[7] = g_scale[3 * gm];
+      } else if (g_scale) { g[0] = g_scale[3 * gm + 1]; g[1] = g_scale[3 * gm + 2]; }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) g8[gi][j] = (__bf16)g[j];
     // transposed image of the cotangent, [tile][2][32 columns][16 rows] (columns 10..31 zero): operand of the head GEMM
-    if (wc == 0 && row0 + 32 * gi < N) {
-      __bf16* gt = gT + (size_t)((row0 + 32 * gi) >> 5) * (HEADP * 32);
+    if (wc == 0 && tg[gi] >= 0) {
+      __bf16* gt = gT + (size_t)tg[gi] * (HEADP * 32);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         gt[timg_off(HEADP, 8 * h + j, m)] = g8[gi][j];
@@ -621,10 +721,10 @@ void mlp_bwd_data_kernel_blk(MlpNetT net, const float* __restrict__ g_xyz, const
   auto dz_read = [&](int piece) { return patch_read(act, pl, (piece >> 3) * 16, u_wc * 128 + (piece & 7) * 16); };
   auto dz_store = [&](int img, int piece, s16x4p v) {
     const int r0 = (piece >> 3) * 16, c0 = u_wc * 128 + (piece & 7) * 16;
-    const int growb = u_row0 + r0;
-    if ((growb & ~31) < N)
-      patch_store(v, pl, dzT + ((size_t)img * tiles + (growb >> 5)) * (MW * 32) + (size_t)((growb >> 4) & 1) * (MW * 16) + (size_t)c0 * 16,
-                  min(max(N - growb, 0), 16));
+    const int tile = tg[r0 >> 5], half = (r0 >> 4) & 1;
+    if (tile >= 0)
+      patch_store(v, pl, dzT + ((size_t)img * tiles + tile) * (MW * 32) + (size_t)half * (MW * 16) + (size_t)c0 * 16,
+                  min(max(N - (tile * 32 + half * 16), 0), 16));
   };
   for (int l = MD; l >= 1; --l) {                         // produces dZ_{l-1}; l == MD is the head stage
     // this stage's ReLU gates (recorded by the forward) are requested now and used in the epilogue
@@ -736,10 +836,12 @@ struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 #endif
 // WM x WN waves, each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
 template <int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, int tiles, int G) {
+__global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, const int* __restrict__ live_list,
+                                                                const int* __restrict__ n_live_ptr, int G) {
   constexpr int M = WM * MB * 32, NK = WN * NB * 32;
   const WgradJob job = jobs.j[blockIdx.y];
   const int g = blockIdx.x;
+  const int tiles = *n_live_ptr;                           // the reduction runs over the LIVE row tiles (see "dead rows")
   const int t_begin = (int)((long long)tiles * g / G), t_end = (int)((long long)tiles * (g + 1) / G);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
@@ -766,9 +868,10 @@ __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, 
   // ~3000 cycles for 512 cycles of MFMA work.
   constexpr int NBUF = WGRAD_NBUF;
   bf16x8 fa[NBUF][MB], fb[NBUF][NB];
-  auto load = [&](int buf, int step) {      // step = tile * 2 + s
-    const size_t ta = (size_t)(step >> 1) * (M * 32) + (size_t)(step & 1) * (M * 16);
-    const size_t tb = (size_t)(step >> 1) * (NK * 32) + (size_t)(step & 1) * (NK * 16);
+  auto load = [&](int buf, int step) {      // step = (position in the live list) * 2 + s
+    const size_t tile = (size_t)live_list[step >> 1];      // wave-uniform index: a scalar load
+    const size_t ta = tile * (M * 32) + (size_t)(step & 1) * (M * 16);
+    const size_t tb = tile * (NK * 32) + (size_t)(step & 1) * (NK * 16);
 #pragma unroll
     for (int a = 0; a < MB; ++a) fa[buf][a] = *reinterpret_cast<const bf16x8*>(pa + ta + (size_t)a * 32 * 16);
 #pragma unroll
@@ -890,8 +993,10 @@ __global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
     for (int e = 0; e < 4; ++e) {
       if (k + e >= job.k_valid) break;
       if (job.head) {
-        const int sg = f < 3 ? 0 : (f < 7 ? 1 : 2), base = f < 3 ? 0 : (f < 7 ? 3 : 7);
-        if (job.head_w[sg]) job.head_w[sg][(f - base) * job.stride + k + e] = o[e];
+        // (selects, not head_w[sg]: a dynamically indexed member of the by-value job record is copied to scratch)
+        const int base = f < 3 ? 0 : (f < 7 ? 3 : 7);
+        float* const hw = f < 3 ? job.head_w[0] : (f < 7 ? job.head_w[1] : job.head_w[2]);
+        if (hw) hw[(f - base) * job.stride + k + e] = o[e];
       } else if (job.out) job.out[(size_t)f * job.stride + job.col_off + k + e] = o[e];
     }
   }
@@ -909,8 +1014,9 @@ __global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
     }
     const float b = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (job.head) {
-      const int sg = bidx < 3 ? 0 : (bidx < 7 ? 1 : 2), base = bidx < 3 ? 0 : (bidx < 7 ? 3 : 7);
-      if (job.head_b[sg]) job.head_b[sg][bidx - base] = b;
+      const int base = bidx < 3 ? 0 : (bidx < 7 ? 3 : 7);
+      float* const hb = bidx < 3 ? job.head_b[0] : (bidx < 7 ? job.head_b[1] : job.head_b[2]);
+      if (hb) hb[bidx - base] = b;
     } else if (job.bias_out) job.bias_out[bidx] = b;
   }
 }
@@ -942,6 +1048,7 @@ static MlpSaved mlp_saved_plan(void* base, int N) {
 
 struct MlpBwdPlan {
   __bf16* wt[MD]; __bf16* wt_head; __bf16* dzT; __bf16* gT;
+  int* tile_flags; int* live_list; int* n_live;   // "dead rows": per 32-row tile flag, compacted ids, count
   float* part_hidden; float* bias_hidden;   // 7 jobs (layers 1..7): [7][Gh][256][256], [7][Gh][256]
   float* part_pe; float* bias_pe;           // 2 jobs (layers 0, 5):  [2][Gp][256][96],  [Gp][256] (layer 0 only)
   float* part_head; float* bias_head;       // 1 job:                 [Gd][32][256],     [Gd][32]
@@ -956,6 +1063,9 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   p.wt_head = (__bf16*)c; c += align_up(sizeof(__bf16) * (size_t)MW * 16);
   p.dzT = (__bf16*)c; c += align_up(sizeof(__bf16) * MD * tiles * MW * 32);
   p.gT = (__bf16*)c;  c += align_up(sizeof(__bf16) * tiles * HEADP * 32);
+  p.tile_flags = (int*)c; c += align_up(sizeof(int) * (tiles + 1));
+  p.live_list = (int*)c;  c += align_up(sizeof(int) * (tiles + 1));
+  p.n_live = (int*)c;     c += align_up(sizeof(int) * 4);
   // one workgroup per CU for the big GEMMs (252 = 7 x 36), more and shorter ones for the narrow jobs
   static const int gh_env = [] { const char* e = getenv("TRASE_MLP_GH"); return e ? atoi(e) : 0; }();
   const int gh_max = gh_env > 0 ? gh_env : 36;
@@ -1060,6 +1170,13 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
 int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
                             float* d_xyz, float* d_rotation, float* d_scaling, void* saved, size_t saved_bytes, void* ws,
                             size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  return trase_mlp_forward_train_rows(w, x, t, t_stride, N, nullptr, d_xyz, d_rotation, d_scaling, saved, saved_bytes, ws, ws_bytes,
+                                      device, stream_);
+}
+
+int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const float* t, int32_t t_stride, int32_t N,
+                                 const int32_t* row_order, float* d_xyz, float* d_rotation, float* d_scaling, void* saved,
+                                 size_t saved_bytes, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
   if (N < 0) { set_error("trase_mlp_forward_train: bad arguments"); return TRASE_ERR_INVALID; }
   if (int rc = mlp_check_weights(w, "trase_mlp_forward_train")) return rc;
   if (N == 0) return TRASE_OK;
@@ -1077,15 +1194,15 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
   }
   {
     ProfScope ps("mlp_pe", stream);
-    const size_t n = (size_t)((N + 31) / 32) * 2 * EMBP;
-    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT);
+    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT,
+                       (const int*)row_order);
   }
   TRASE_POST_LAUNCH("mlp_pe", stream, 0);
   {
     ProfScope ps("mlp_fwd_train", stream);
     const dim3 block(MWAVES * WAVE);
     hipLaunchKernelGGL(mlp_fwd_train_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N,
-                       d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates);
+                       d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order);
   }
   TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
   return TRASE_OK;
@@ -1094,6 +1211,21 @@ int trase_mlp_forward_train(const TraseMlpWeights* w, const float* x, const floa
 int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_xyz, const float* dL_dd_rotation,
                        const float* dL_dd_scaling, const void* saved, size_t saved_bytes, const TraseMlpGrads* grads,
                        void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  return trase_mlp_backward_rows(w, N, nullptr, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling, saved, saved_bytes, grads, ws, ws_bytes,
+                                 device, stream_);
+}
+
+int trase_mlp_live_tiles(const void* bwd_ws, size_t ws_bytes, int32_t N, int32_t* n_live_device, trase_stream_t stream_) {
+  if (!bwd_ws || !n_live_device || N <= 0) { set_error("trase_mlp_live_tiles: bad arguments"); return TRASE_ERR_INVALID; }
+  const MlpBwdPlan bp = mlp_bwd_plan(const_cast<void*>(bwd_ws), N);
+  if (ws_bytes < bp.bytes) { set_error("trase_mlp_live_tiles: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  TRASE_CHECK(hipMemcpyAsync(n_live_device, bp.n_live, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+  return TRASE_OK;
+}
+
+int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* row_order, const float* dL_dd_xyz,
+                            const float* dL_dd_rotation, const float* dL_dd_scaling, const void* saved, size_t saved_bytes,
+                            const TraseMlpGrads* grads, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
   if (N < 0 || !grads) { set_error("trase_mlp_backward: bad arguments"); return TRASE_ERR_INVALID; }
   if (int rc = mlp_check_weights(w, "trase_mlp_backward")) return rc;
   if (N == 0) { set_error("trase_mlp_backward: N == 0 (the caller zero-fills the gradients)"); return TRASE_ERR_INVALID; }
@@ -1117,11 +1249,19 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
     hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(MW * MW / 256, MD), dim3(256), 0, stream, pa);
   }
   TRASE_POST_LAUNCH("mlp_pack_t", stream, 0);
+  {   // "dead rows": the tiles that hold a row with a non-zero cotangent, as an ascending list
+    ProfScope ps("mlp_live_tiles", stream);
+    hipLaunchKernelGGL(mlp_tile_flags_kernel, dim3((tiles + 3) / 4), dim3(256), 0, stream, dL_dd_xyz, dL_dd_rotation, dL_dd_scaling,
+                       N, (const int*)row_order, bp.tile_flags);
+    hipLaunchKernelGGL(mlp_tile_list_kernel, dim3(1), dim3(1024), 0, stream, (const int*)bp.tile_flags, tiles, bp.live_list, bp.n_live);
+  }
+  TRASE_POST_LAUNCH("mlp_live_tiles", stream, 0);
   {
     ProfScope ps("mlp_bwd_data", stream);
-      const dim3 block(MWAVES * WAVE);
+    const dim3 block(MWAVES * WAVE);
     hipLaunchKernelGGL(mlp_bwd_data_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, dL_dd_xyz, dL_dd_rotation,
-                       dL_dd_scaling, N, (const uint32_t*)sv.gates, bp.dzT, bp.gT);
+                       dL_dd_scaling, N, (const uint32_t*)sv.gates, bp.dzT, bp.gT, (const int*)row_order, (const int*)bp.live_list,
+                       (const int*)bp.n_live);
   }
   TRASE_POST_LAUNCH("mlp_bwd_data", stream, 0);
   const size_t img = (size_t)tiles * MW * 32;              // one layer's transposed image, elements
@@ -1146,7 +1286,8 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
       reduce_job(j.partial, j.bias_partial, grads->weight[l], grads->bias[l], MW, MW, kin, l == SKIP ? EMB : 0, MW, MW, bp.Gh);
     }
     ProfScope ps("mlp_wgrad_hidden", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, tiles, bp.Gh);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gh);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_hidden", stream, 0);
   {   // encoding inputs: layer 0 and the first 84 columns of the skip layer
@@ -1161,7 +1302,8 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
                  k == 0 ? EMB : EMB + MW, 0, EMB, MW, bp.Gp);
     }
     ProfScope ps("mlp_wgrad_pe", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, tiles, bp.Gp);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gp);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_pe", stream, 0);
   {   // heads: cotangent image (32 padded columns) x activations of the last layer
@@ -1173,7 +1315,8 @@ int trase_mlp_backward(const TraseMlpWeights* w, int32_t N, const float* dL_dd_x
     r.head_w[0] = grads->w_warp; r.head_w[1] = grads->w_rotation; r.head_w[2] = grads->w_scaling;
     r.head_b[0] = grads->b_warp; r.head_b[1] = grads->b_rotation; r.head_b[2] = grads->b_scaling;
     ProfScope ps("mlp_wgrad_head", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, tiles, bp.Gd);
+    hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gd);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_head", stream, 0);
   {

@@ -101,6 +101,68 @@ def _time_embedding(params, t, n):
     return torch.nn.functional.linear(h, params["timenet.2.weight"], params["timenet.2.bias"]).reshape(30)
 
 
+# ---- row order of the training pair ("dead rows", trase_amd/csrc/mlp.hip) -------------------------------------------------
+# The backward skips every 32-row tile whose cotangents are all zero: the Gaussians a view culls (radii == 0,
+# gaussian_renderer/__init__.py:152) send back exactly zero.  Culling is spatially coherent, Gaussian indices are not; so the
+# training pair evaluates the rows along a Morton curve of their positions.  The order only groups rows into tiles -- every row
+# is computed exactly as before and lands at its own index -- so it may be stale: it is rebuilt when N changes and every
+# ROW_ORDER_REFRESH calls (positions drift slowly; densification changes N).
+ROW_ORDER_REFRESH = 64
+_ROW_ORDER: dict = {"key": None, "age": 0, "perm": None}
+_ROW_ORDER_MODE = os.environ.get("TRASE_MLP_ROW_ORDER", "morton")      # "morton" | "none"
+
+
+def set_row_order(mode: str = "morton"):
+    """"morton" (default): rows of the training pair are evaluated along a Morton curve; "none": in index order."""
+    global _ROW_ORDER_MODE
+    if mode not in ("morton", "none"):
+        raise ValueError("row order must be 'morton' or 'none'")
+    _ROW_ORDER_MODE = mode
+    _ROW_ORDER.update(key=None, age=0, perm=None)
+
+
+def morton_order(x: torch.Tensor) -> torch.Tensor:
+    """int32 permutation that sorts the rows of x (N,3) along a 30-bit Morton curve of their bounding box."""
+    with torch.no_grad():
+        lo, hi = x.min(0).values, x.max(0).values
+        q = ((x - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        return torch.argsort(code, stable=True).to(torch.int32)
+
+
+def _row_order(x: torch.Tensor):
+    n = x.shape[0]
+    if _ROW_ORDER_MODE == "none" or n < 4096:          # a handful of tiles: nothing to skip
+        return None
+    key = (n, x.device)
+    if _ROW_ORDER["key"] != key or _ROW_ORDER["age"] >= ROW_ORDER_REFRESH or _ROW_ORDER["perm"] is None:
+        _ROW_ORDER.update(key=key, age=0, perm=morton_order(x))
+    _ROW_ORDER["age"] += 1
+    return _ROW_ORDER["perm"]
+
+
+_LIVE: dict = {"track": False, "count": None}
+
+
+def track_live_tiles(flag: bool = True):
+    """Tests / benches: have every MLP backward leave its live-tile count (one stream-ordered 4-byte copy) for last_live_tiles()."""
+    _LIVE["track"] = bool(flag)
+    _LIVE["count"] = None
+
+
+def last_live_tiles() -> int:
+    """32-row tiles the most recent MLP backward worked on (the others held only zero cotangents).  Synchronises."""
+    if _LIVE["count"] is None:
+        raise RuntimeError("no MLP backward has run since track_live_tiles(True)")
+    return int(_LIVE["count"].item())
+
+
 class _DeformMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, t, is_blender, *params):
@@ -120,10 +182,13 @@ class _DeformMLP(torch.autograd.Function):
         _lib.check(lib.trase_mlp_train_sizes(n, C.byref(ws_b), C.byref(saved_b), C.byref(bwd_b)), "trase_mlp_train_sizes")
         ws = _bytes(ws_b.value, dev)
         saved = _bytes(saved_b.value, dev)
-        _lib.check(lib.trase_mlp_forward_train(C.byref(w), _lib.ptr(xs), C.c_void_p(tt.data_ptr()), t_stride, n,
-                                               _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scale), _lib.ptr(saved),
-                                               saved.numel(), _lib.ptr(ws), ws.numel(), _dev_index(dev), _stream(dev)),
-                   "trase_mlp_forward_train")
+        order = _row_order(xs)
+        _lib.check(lib.trase_mlp_forward_train_rows(C.byref(w), _lib.ptr(xs), C.c_void_p(tt.data_ptr()), t_stride, n,
+                                                    _lib.ptr(order), _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(d_scale),
+                                                    _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _dev_index(dev),
+                                                    _stream(dev)),
+                   "trase_mlp_forward_train_rows")
+        ctx.order = order                   # the SAME permutation tensor goes to the backward (the cache may move on)
         ctx.save_for_backward(saved, *params)
         ctx.n = n
         ctx.bwd_bytes = bwd_b.value
@@ -154,9 +219,14 @@ class _DeformMLP(torch.autograd.Function):
         gr.w_warp, gr.b_warp, gr.w_rotation, gr.b_rotation, gr.w_scaling, gr.b_scaling = (
             (o.data_ptr() if o is not None else None) for o in out[16:22])
         ws = _bytes(ctx.bwd_bytes, dev)
-        _lib.check(lib.trase_mlp_backward(C.byref(w), n, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(g_scale),
-                                          _lib.ptr(saved), saved.numel(), C.byref(gr), _lib.ptr(ws), ws.numel(),
-                                          _dev_index(dev), _stream(dev)), "trase_mlp_backward")
+        _lib.check(lib.trase_mlp_backward_rows(C.byref(w), n, _lib.ptr(ctx.order), _lib.ptr(g_xyz), _lib.ptr(g_rot),
+                                               _lib.ptr(g_scale), _lib.ptr(saved), saved.numel(), C.byref(gr), _lib.ptr(ws),
+                                               ws.numel(), _dev_index(dev), _stream(dev)), "trase_mlp_backward_rows")
+        if _LIVE["track"]:
+            if _LIVE["count"] is None or _LIVE["count"].device != dev:
+                _LIVE["count"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.trase_mlp_live_tiles(_lib.ptr(ws), ws.numel(), n, _lib.ptr(_LIVE["count"]), _stream(dev)),
+                       "trase_mlp_live_tiles")
         g_t = None
         if need_t:
             # every row sees the same 30 inputs at columns 63..92 of layer 0 and of the skip layer, so
