@@ -156,12 +156,17 @@ FULL_SIZE = [
     ("S5 Immersive size (one rank's share)", 2_500_000, 1280, 960, 0.006, {}),
     ("S4-inside: S4 size, camera inside the cloud", 300_000, 1920, 1080, 0.004, dict(radius=0.9)),
     ("S4-far: S4 size, cloud x12.5 (z in 28..72)", 300_000, 1920, 1080, 0.01, dict(world_scale=12.5)),
+    # the image-only cotangent of every GAUSSIAN-state iteration (train.py:235-243, :299: the loss never reads the feature map):
+    # render_bwd_hw's image-only scope, against the float64 oracle at the headline size
+    ("S4-image-only: S4 headline, cotangent on the image alone", 300_000, 1920, 1080, 0.01, dict(image_only=True)),
 ]
 
 
 @pytest.mark.parametrize("name,n,w,h,share,scene_kw", FULL_SIZE, ids=[c[0].split()[0].rstrip(":") for c in FULL_SIZE])
 def test_fullsize_sampled_tile_parity(name, n, w, h, share, scene_kw):
     """Full-size forward + backward on the GPU; the float64 oracle composites a seeded sample of tiles."""
+    scene_kw = dict(scene_kw)
+    image_only = scene_kw.pop("image_only", False)
     act, cam = small_case(n=n, w=w, h=h, feat=32, seed=0, scale_mult=0.27, angle=0.3, **scene_kw)
     st = settings_for(cam, bg=(0.1, 0.25, 0.4))
     tiles = _sample_tiles(w, h, share, seed=n)
@@ -172,10 +177,16 @@ def test_fullsize_sampled_tile_parity(name, n, w, h, share, scene_kw):
     gen = torch.Generator().manual_seed(n)
     gi = T._masked(torch.randn(3, h, w, generator=gen), o)
     gf = T._masked(torch.randn(32, h, w, generator=gen), o)
-    (o.image * gi.double()).sum().add((o.feats * gf.double()).sum()).backward()
-    torch.autograd.backward([g[0], g[2]], [gi.cuda(), gf.cuda()])
+    if image_only:
+        (o.image * gi.double()).sum().backward()
+        torch.autograd.backward([g[0]], [gi.cuda()])
+        assert gl["sh_objs"].grad is None or float(gl["sh_objs"].grad.abs().max()) == 0.0
+    else:
+        (o.image * gi.double()).sum().add((o.feats * gf.double()).sum()).backward()
+        torch.autograd.backward([g[0], g[2]], [gi.cuda(), gf.cuda()])
     report = {}
-    T._check_grads(gl, ol, o, ["means3D", "means2D", "opacities", "scales", "rotations", "shs", "sh_objs"], report=report)
+    names = ["means3D", "means2D", "opacities", "scales", "rotations", "shs"] + ([] if image_only else ["sh_objs"])
+    T._check_grads(gl, ol, o, names, report=report)
     print(f"{name}: gradient entries failing the original per-entry rule (rtol 1e-3 |b| + 1e-5 max|b|): "
           + ", ".join(f"{k} {v['fail_original_rule']}/{v['entries']}" for k, v in report.items()))
     if os.path.isdir("gpurun_out"):
