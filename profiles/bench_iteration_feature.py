@@ -88,7 +88,7 @@ def main():
         pc._gaussian_features.grad = None
         cam = cams[i % 8]
         with torch.no_grad():
-            t = torch.tensor([[cam.fid if hasattr(cam, "fid") else 0.3]], device=dev).expand(N, -1)
+            t = cam.fid.reshape(1, 1).expand(N, -1)            # train.py:186-196: a stride-0 view of the camera's device-resident fid
             d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
         out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale, norm_gaussian_features=True, is_smooth_gaussian_features=True, smooth_K=16)
         cover, size = mask_stats(sam)
@@ -101,7 +101,7 @@ def main():
         pc._gaussian_features.grad = None
         cam = cams[i % 8]
         with torch.no_grad():
-            t = torch.tensor([[cam.fid if hasattr(cam, "fid") else 0.3]], device=dev).expand(N, -1)
+            t = cam.fid.reshape(1, 1).expand(N, -1)            # train.py:186-196: a stride-0 view of the camera's device-resident fid
             d_xyz, d_rot, d_scale = net(pc.get_xyz.detach(), t.contiguous())
         st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
                                            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,

@@ -19,6 +19,19 @@ def _small_deform_net(dev):
     return net
 
 
+def _time_input(cam, N, dev):
+    """train.py:186-196: `fid = viewpoint_cam.fid` is a DEVICE tensor (scene/cameras.py:58) and
+    `time_input = fid.unsqueeze(0).expand(N, -1)` a stride-0 view of it -- no host round trip.  (Reading the value back to
+    build a new tensor, as this harness did before round 5, synchronised host and device once per iteration: 0.16 ms of idle
+    GPU in front of every iteration's first kernel, profiles/r5_iteration_timeline.md.)"""
+    fid = getattr(cam, "fid", None)
+    if not isinstance(fid, torch.Tensor):
+        fid = torch.tensor([0.3 if fid is None else float(fid)], device=dev)
+    elif fid.device != dev:
+        fid = fid.to(dev)
+    return fid.reshape(1, 1).expand(N, -1)
+
+
 def make_gaussian_iteration(pc, cams, W: int, H: int, dev, image_scope: bool = True):
     """GAUSSIAN state (train.py:196-243, :299): deformation MLP with gradients -> render() -> L1 + SSIM -> backward.
     image_scope: the state never reads the feature map (train.py:211), so the forward composites colour + depth only
@@ -40,7 +53,7 @@ def make_gaussian_iteration(pc, cams, W: int, H: int, dev, image_scope: bool = T
         for p in params:
             p.grad = None
         cam = cams[i % len(cams)]
-        t = torch.tensor([[float(getattr(cam, "fid", 0.3))]], device=dev).expand(N, -1)
+        t = _time_input(cam, N, dev)
         d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
         set_forward_scope("image" if image_scope else "all")
         try:
@@ -80,7 +93,7 @@ def make_feature_iteration(pc, cams, W: int, H: int, dev, n_masks: int = 100):
         pc._gaussian_features.grad = None
         cam = cams[i % len(cams)]
         with torch.no_grad():
-            t = torch.tensor([[float(getattr(cam, "fid", 0.3))]], device=dev).expand(N, -1)
+            t = _time_input(cam, N, dev)
             d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
         out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale, norm_gaussian_features=True, is_smooth_gaussian_features=True, smooth_K=16)
         cover, size = mask_stats(sam)

@@ -13,6 +13,7 @@
 // "transposed images" and the ReLU gates as bits; the backward is a fused data chain of the same shape plus
 // split-N MFMA GEMMs for the parameter gradients (see "training backward" below).
 #include "common.h"
+#include <type_traits>
 
 namespace trase {
 
@@ -271,7 +272,8 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
                                                  const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                                                  float* __restrict__ d_xyz, float* __restrict__ d_rot,
                                                  float* __restrict__ d_scale, __bf16* __restrict__ actsT,
-                                                 uint32_t* __restrict__ gates, const int* __restrict__ ro = nullptr) {
+                                                 uint32_t* __restrict__ gates, const int* __restrict__ ro = nullptr,
+                                                 __bf16* __restrict__ peT = nullptr) {
   // ro (row order, training only): batch row r evaluates Gaussian ro[r] -- inputs are gathered and the ten outputs scattered
   // through it; everything saved for the backward (images, gates) is in BATCH order (see "dead rows" below)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -319,6 +321,40 @@ __device__ __forceinline__ void mlp_fwd_blk_body(__bf16* __restrict__ act, __bf1
     if constexpr (FULL) patch_store(v, pl, patch, 16);
     else if ((growb & ~31) < N) patch_store(v, pl, patch, min(max(N - growb, 0), 16));   // the 32-row image tile exists
   };
+  if constexpr (SAVE) {
+    // The encoding as a transposed image (operand of the weight-gradient GEMMs of layers 0 and 5; a kernel of its own cost 0.04 ms
+    // per step for this).  Done HERE, before any accumulator is live (inside layer 0's K-steps the same code spilled): the two
+    // waves of a row block share the six K-steps (wc = 0: columns 0..47, wc = 1: 48..95), park their fragments in the idle
+    // activation tile -- each wave inside the half of the tile that only its own epilogue overwrites -- and take them out
+    // through the same transposing patch reads as every other image.
+    auto park = [&](auto ks_c) {
+      constexpr int KS = decltype(ks_c)::value;
+#pragma unroll
+      for (int g = 0; g < BRG; ++g)
+        *reinterpret_cast<bf16x8*>(act + act_off(lrow0 + 32 * g + m, (KS % 3) * 16 + 8 * h + 128 * (KS / 3))) =
+            blk_pe_fragment<KS>(h, px[g], blender, tb);
+    };
+    if (u_wc == 0) { park(std::integral_constant<int, 0>{}); park(std::integral_constant<int, 1>{}); park(std::integral_constant<int, 2>{}); }
+    else { park(std::integral_constant<int, 3>{}); park(std::integral_constant<int, 4>{}); park(std::integral_constant<int, 5>{}); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // (every wave reads back only what it wrote itself)
+    constexpr int PP = BRG * 2 * 3;                          // 16-row x 16-column patches per wave: 4 row pieces x 3 column pieces
+#pragma unroll
+    for (int j0 = 0; j0 < PP; j0 += 6) {
+      s16x4p pv[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pv[j] = patch_read(act, pl, ((j0 + j) / 3) * 16, u_wc * 128 + ((j0 + j) % 3) * 16);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int growb = u_row0 + ((j0 + j) / 3) * 16;
+        __bf16* const patch = peT + (size_t)(growb >> 5) * (EMBP * 32) + (size_t)((growb >> 4) & 1) * (EMBP * 16) +
+                              (size_t)(u_wc * 48 + ((j0 + j) % 3) * 16) * 16;
+        if constexpr (FULL) patch_store(pv[j], pl, patch, 16);
+        else if ((growb & ~31) < N) patch_store(pv[j], pl, patch, min(max(N - growb, 0), 16));
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < BRG; ++g) asm volatile("" : "+v"(px[g][0]), "+v"(px[g][1]), "+v"(px[g][2]), "+v"(px[g][3]));   // (no reuse of these values below)
+  }
   for (int l = 0; l < MD; ++l) {
     const bool has_emb = (l == 0 || l == SKIP);
     const int emb_k = has_emb ? EMBP / 16 : 0;
@@ -492,13 +528,14 @@ void mlp_fwd_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __
 __global__ __launch_bounds__(MWAVES* WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mlp_fwd_train_kernel_blk(MlpNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                               float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
-                              __bf16* __restrict__ actsT, uint4* __restrict__ gates, const int* __restrict__ ro) {
+                              __bf16* __restrict__ actsT, uint4* __restrict__ gates, const int* __restrict__ ro,
+                              __bf16* __restrict__ peT) {
   __shared__ __attribute__((aligned(16))) __bf16 act[BROWS * MW];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[2][2][MW * 8];
   if ((int)(blockIdx.x + 1) * BROWS <= N)
-    mlp_fwd_blk_body<true, true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro);
+    mlp_fwd_blk_body<true, true>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro, peT);
   else
-    mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro);
+    mlp_fwd_blk_body<true, false>(act, s_w, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, actsT, reinterpret_cast<uint32_t*>(gates), ro, peT);
 }
 
 // ---- training backward ------------------------------------------------------------------------------------
@@ -943,6 +980,146 @@ __global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, 
   }
 }
 
+// ---- the hidden-layer weight-gradient GEMM with its operand stream parked in LDS ----------------------------------
+// mlp_wgrad_kernel<2, 2, 4, 4> is bound by the HBM stream of its two images (128 flop per byte against the chip's ~400), and
+// what limits the stream is the bytes it can keep in flight: 480 accumulator + fragment registers leave a ring of three
+// K-steps (48 KB unique per CU, every fragment requested twice -- by the two waves that share it).  Here the fragments go
+// global -> LDS directly (global_load_lds_dwordx4: no registers; a fragment load of the transposed image is ONE contiguous
+// kilobyte, and the LDS-DMA writes lane L's 16 bytes at base + 16 L -- exactly the 16 bytes lane L wants back), each fragment
+// is requested ONCE per workgroup (wave w loads fragments 4 w .. 4 w + 3 of the K-step's sixteen), and the ring is WL_NST
+// K-steps deep (16 KB each): 128 KB in flight per CU.  One workgroup barrier per K-step; LDS-DMA completion is counted by hand
+// (hipcc does not see the asm loads): s_waitcnt vmcnt(4 (WL_NST - 2)) = "my four loads of this K-step have landed".
+// STREAM: non-temporal policy -- for images that this launch reads exactly once (the hidden layers' jobs: 0.404 -> 0.354 ms,
+// 6.07 TB/s); the narrow jobs share an operand between jobs (the encoding image) or are short, and lose with it
+template <bool STREAM>
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (STREAM)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// MT / NT: 32-column blocks of the A / B image (M = 32 MT output rows, NK = 32 NT output columns); WM x WN waves, each owning
+// (MT / WM) x (NT / WN) blocks; NST ring slots of one K-step (LPW = ceil((MT + NT) / 4) fragments per wave: the surplus ones
+// re-request the last fragment into a spare kilobyte, so that every wave counts the same number of loads per K-step).
+// Schedule of K-step s: wait for MY loads of K-step s + 1, barrier (everybody's have landed; everybody holds K-step s in
+// registers, so slot s is free), request K-step s + NST into slot s, read K-step s + 1 from LDS into the second register set,
+// multiply K-step s -- the LDS latency of the next fragments hides under this step's MFMAs (one wave per SIMD: nobody else would).
+template <int MT, int NT, int WM, int WN, int NST, bool STREAM>
+__global__ __launch_bounds__(256) void mlp_wgrad_lds_kernel(WgradJobs jobs, const int* __restrict__ live_list,
+                                                            const int* __restrict__ n_live_ptr, int G) {
+  static_assert(WM * WN == 4 && MT % WM == 0 && NT % WN == 0, "four waves");
+  constexpr int M = MT * 32, NK = NT * 32, MB = MT / WM, NB = NT / WN, F = MT + NT, LPW = (F + 3) / 4, SLOT = LPW * 4 * 1024;
+  static_assert(NST * SLOT <= 160 * 1024 && LPW * (NST - 2) < 64, "LDS ring / vmcnt range");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * SLOT];
+  const WgradJob job = jobs.j[blockIdx.y];
+  const int g = blockIdx.x;
+  const int tiles = *n_live_ptr;                           // the reduction runs over the LIVE row tiles (see "dead rows")
+  const int t_begin = (int)((long long)tiles * g / G), t_end = (int)((long long)tiles * (g + 1) / G);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const bool do_bias = job.bias_partial != nullptr && wn == 0;
+  // MB x NB blocks of 32 x 32 (the hidden layers: 16 blocks = all 256 accumulation registers).  The bias sums (db_l = column
+  // sums of dZ_l) do NOT take another MFMA block per row of blocks as in mlp_wgrad_kernel (64 more accumulators: the allocator
+  // then rotates ~100 registers between the two register files in every K-step): a lane holds 8 rows of one column per
+  // fragment -- four packed bf16 dot products against (1, 1) add them up in fp32; the two row halves meet in the epilogue.
+  f32x16 acc[MB][NB];
+  float bsum[MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+    bsum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)ring;
+  // loader role: wave w brings fragments w LPW .. w LPW + LPW - 1 of the K-step's F (A image first, then B)
+  const __bf16* lsrc[LPW];
+  size_t ltile[LPW], lhalf[LPW];
+#pragma unroll
+  for (int b = 0; b < LPW; ++b) {
+    const int fid = min(wave * LPW + b, F - 1);
+    const bool isA = fid < MT;
+    lsrc[b] = (isA ? job.A + (size_t)fid * 512 : job.B + (size_t)(fid - MT) * 512) + (size_t)i * 16 + 8 * h;
+    ltile[b] = isA ? (size_t)M * 32 : (size_t)NK * 32;
+    lhalf[b] = isA ? (size_t)M * 16 : (size_t)NK * 16;
+  }
+  const unsigned my_slot_off = (unsigned)wave * (unsigned)(LPW * 1024);
+  const int s_begin = 2 * t_begin, s_end = 2 * t_end;    // always an even number of steps
+  auto issue = [&](int slot, int step, int tile_id) {    // this wave's fragments of the K-step -> ring slot
+    const size_t tile = (size_t)tile_id;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * (unsigned)SLOT + my_slot_off);
+#pragma unroll
+    for (int b = 0; b < LPW; ++b) glds16<STREAM>(lsrc[b] + tile * ltile[b] + (size_t)(step & 1) * lhalf[b], dst + b * 1024u);
+  };
+  if (s_begin < s_end) {
+    // (steps past the end re-request the last one: the count of loads in flight is then the same in every K-step)
+    for (int k = 0; k < NST; ++k) { const int st = min(s_begin + k, s_end - 1); issue(k, st, live_list[st >> 1]); }
+    // the tile id of the NEXT request is fetched a K-step ahead (a scalar load in front of its use costs its round trip per step)
+    int tile_nx = live_list[min(s_begin + NST, s_end - 1) >> 1];
+    const unsigned char* rd = ring + lane * 16;
+    bf16x8 fa[2][MB], fb[2][NB];
+    auto frags = [&](int set, int slot) {
+      const unsigned char* st = rd + slot * SLOT;
+#pragma unroll
+      for (int a = 0; a < MB; ++a) fa[set][a] = *reinterpret_cast<const bf16x8*>(st + (MB * wm + a) * 1024);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) fb[set][b] = *reinterpret_cast<const bf16x8*>(st + (MT + NB * wn + b) * 1024);
+    };
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(LPW * (NST - 1)) : "memory");     // K-step s_begin is in LDS
+    frags(0, 0);
+    int slot = 0;                                        // ring slot of K-step s
+    auto step = [&](int s, int cur) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(LPW * (NST - 2)) : "memory");
+      issue(slot, min(s + NST, s_end - 1), tile_nx);
+      tile_nx = live_list[min(s + 1 + NST, s_end - 1) >> 1];
+      slot = slot == NST - 1 ? 0 : slot + 1;
+      frags(cur ^ 1, slot);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const bf16x2 v = {fa[cur][a][e], fa[cur][a][e + 1]};
+          bsum[a] = __builtin_amdgcn_fdot2_f32_bf16(v, one2, bsum[a], false);
+        }
+    };
+#pragma nounroll
+    for (int s = s_begin; s < s_end; s += 2) {
+      step(s, 0);
+      step(s + 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the surplus requests of the last K-steps must not outlive the workgroup's LDS
+  }
+  // D[f_local][k_local]: lane = k_local (+32 for the odd f quads), register r = f_local%4 + 4*(f_local/8)
+  float* out = job.partial + (size_t)g * wg_plane(M, NK);
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = (wm * MB + a) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        out[(size_t)f * NK + (wn * NB + b) * 32 + i] = acc[a][b][r];
+      }
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {                         // column f = 32 (wm MB + a) + i: rows 8 h .. of every K-step in this lane
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bsum[a]), __float_as_uint(bsum[a]), false, false);
+    const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);     // (half 0) + (half 1), the same order in both lanes
+    if (do_bias && h == 0) job.bias_partial[(size_t)g * M + (wm * MB + a) * 32 + i] = tot;
+  }
+}
+
 struct WreduceJob {
   const float* partial; const float* bias_partial;   // [G][M][NK], [G][M] (or null)
   float* out; float* bias_out;                        // out[f * stride + col_off + k], k < k_valid, f < m_valid
@@ -1192,7 +1369,8 @@ int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const
     if (t_stride != 0) { set_error("trase_mlp_forward_train: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
     net.temb = t;
   }
-  {
+  static const bool pe_kernel = [] { const char* e = getenv("TRASE_MLP_PE_KERNEL"); return e && atoi(e) != 0; }();   // (A/B only)
+  if (pe_kernel) {
     ProfScope ps("mlp_pe", stream);
     hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT,
                        (const int*)row_order);
@@ -1202,7 +1380,7 @@ int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const
     ProfScope ps("mlp_fwd_train", stream);
     const dim3 block(MWAVES * WAVE);
     hipLaunchKernelGGL(mlp_fwd_train_kernel_blk, dim3((N + BROWS - 1) / BROWS), block, 0, stream, net, x, t, t_stride, N,
-                       d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order);
+                       d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order, sv.peT);
   }
   TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
   return TRASE_OK;
@@ -1286,8 +1464,13 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
       reduce_job(j.partial, j.bias_partial, grads->weight[l], grads->bias[l], MW, MW, kin, l == SKIP ? EMB : 0, MW, MW, bp.Gh);
     }
     ProfScope ps("mlp_wgrad_hidden", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                       (const int*)bp.n_live, bp.Gh);
+    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
+    if (use_lds)
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 8, 2, 2, 9, true>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gh);
+    else
+      hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gh);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_hidden", stream, 0);
   {   // encoding inputs: layer 0 and the first 84 columns of the skip layer
@@ -1302,8 +1485,13 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
                  k == 0 ? EMB : EMB + MW, 0, EMB, MW, bp.Gp);
     }
     ProfScope ps("mlp_wgrad_pe", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                       (const int*)bp.n_live, bp.Gp);
+    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
+    if (use_lds)
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 3, 4, 1, 12, false>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gp);
+    else
+      hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gp);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_pe", stream, 0);
   {   // heads: cotangent image (32 padded columns) x activations of the last layer
@@ -1315,8 +1503,13 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
     r.head_w[0] = grads->w_warp; r.head_w[1] = grads->w_rotation; r.head_w[2] = grads->w_scaling;
     r.head_b[0] = grads->b_warp; r.head_b[1] = grads->b_rotation; r.head_b[2] = grads->b_scaling;
     ProfScope ps("mlp_wgrad_head", stream);
-    hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                       (const int*)bp.n_live, bp.Gd);
+    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
+    if (use_lds)
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<1, 8, 1, 4, 12, false>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gd);
+    else
+      hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                         (const int*)bp.n_live, bp.Gd);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_head", stream, 0);
   {
