@@ -405,8 +405,8 @@ def main():
         R.set_sync(False, capacity=int(max(reff_list) * 1.25) + 1024)
     log(f"pairs per view: lineage R mean {r_mean:.0f} max {r_max} (R/N {r_mean / N:.2f}); binned sub-tile pairs mean {reff_mean:.0f}")
 
+    R.set_graph(bool(args.graph))       # (the library's own default is "auto": <= 200k Gaussians)
     if args.graph:
-        R.set_graph(True)
         for i in range(2 * n_views):      # every view's forward and backward sequence is captured once
             step(i)
     for i in range(args.warmup):

@@ -248,7 +248,8 @@ int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs*
  * the caller's stream when the same record comes back -- which it does in a training loop whose allocator hands out the
  * same blocks every iteration.  Only the sync-free entry points are graphed (nothing in them reads back to the host).
  * The cache holds up to 256 graphs and switches itself off when records stop repeating (a miss costs a capture).
- * trase_rast_graph_stats: {hits, misses, cached, enabled}. */
+ * mode: 0 = off, 1 = every call, 2 = auto -- calls of at most 200 000 Gaussians (environment TRASE_GRAPH_AUTO_P); the library
+ * starts in mode 2 (environment TRASE_GRAPH = 0 | 1 | auto).  trase_rast_graph_stats: {hits, misses, cached, mode}. */
 int trase_rast_graph_mode(int mode);
 int trase_rast_graph_stats(int64_t stats[4]);
 

@@ -38,7 +38,7 @@ def _loop(iters, graph):
         R.check_overflow()
         stats = R.graph_stats()
     finally:
-        R.set_graph(False)
+        R.set_graph("auto")           # the library default
         R.set_sync(True)
     return res, stats
 
@@ -53,6 +53,17 @@ def test_graph_replay_is_bit_identical_and_records_repeat():
     assert stats["enabled"]
 
 
+def test_auto_mode_is_the_default_and_replays_small_scenes():
+    """Round 5: the library starts in the "auto" mode (trase_rast_graph_mode 2) -- a sync-free loop over a small scene (3000
+    Gaussians <= TRASE_GRAPH_AUTO_P) is replayed without the caller asking, bit-identical to the eager launches."""
+    from trase_amd import rasterizer as R
+    assert R.graph_stats()["enabled"], "the library must start (and be left by the other tests) in a replaying mode"
+    eager, _ = _loop(9, graph=False)
+    auto, stats = _loop(9, graph="auto")
+    assert eager == auto
+    assert stats["hits"] > 0, f"auto mode never replayed: {stats}"
+
+
 def test_graph_mode_is_ignored_by_the_synchronising_policy():
     """set_sync(True) reads the pair count between the two stages: nothing is graphed, nothing breaks."""
     from trase_amd import rasterizer as R
@@ -65,6 +76,6 @@ def test_graph_mode_is_ignored_by_the_synchronising_policy():
         a, _ = T._gpu_call(act, st, need_grad=False)
         b, _ = T._gpu_call(act, st, need_grad=False)
     finally:
-        R.set_graph(False)
+        R.set_graph("auto")
     for x, y in zip(a, b):
         assert torch.equal(x, y)

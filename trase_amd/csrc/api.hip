@@ -100,8 +100,9 @@ ImgBuf carve_img(void* ptr, int W, int H) {
   i.n_contrib = (uint32_t*)c;
   return i;
 }
-static size_t sort_bytes_common(size_t n) {   // hist + digit_total
-  return align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n)) + align_up(sizeof(uint32_t) * 256 * 8);
+static size_t sort_bytes_common(size_t n, int digit_bits = 8) {   // hist + digit_total
+  const size_t nd = (size_t)1 << digit_bits;
+  return align_up(sizeof(uint32_t) * nd * (size_t)rs_blocks(n)) + align_up(sizeof(uint32_t) * nd * 8);
 }
 // bits of a packed list value left for the pair index (HDR_PACK); 0 = the variant's kernels need emit-order slots
 static int list_pack_bits(const TraseRastSettings* s, int P) {
@@ -113,7 +114,7 @@ static int list_pack_bits(const TraseRastSettings* s, int P) {
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 7 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p);
+  return align_up(sizeof(uint32_t) * p) * 7 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p, DEPTH_DIGIT_BITS);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -125,7 +126,7 @@ PreBuf carve_pre(void* ptr, int P) {
   t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.live_ids = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3);
-  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(p));
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * ((size_t)1 << DEPTH_DIGIT_BITS) * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(p);
   return t;
@@ -180,7 +181,10 @@ static int validate(const TraseRastSettings* s, const TraseRastInputs* in) {
 // key = every byte of the argument records of a call; value = the instantiated graph of its launch sequence
 struct GraphEntry { std::string key; hipGraphExec_t exec; };
 static std::mutex g_graph_mu;
-static int g_graph_mode = 0;
+// 0 = off, 1 = every sync-free call, 2 = auto (the default): calls with at most g_graph_auto_p Gaussians -- the sizes whose ~45 launches
+// per direction cost more host time than the kernels run (BASELINE configs 1 and 2); TRASE_GRAPH=0|1|auto, TRASE_GRAPH_AUTO_P=<n>
+static int g_graph_mode = [] { const char* e = getenv("TRASE_GRAPH"); return !e || !strcmp(e, "auto") ? 2 : (atoi(e) != 0 ? 1 : 0); }();
+static int g_graph_auto_p = [] { const char* e = getenv("TRASE_GRAPH_AUTO_P"); return e ? atoi(e) : 200000; }();
 static std::map<uint64_t, std::vector<GraphEntry>> g_graphs;
 static size_t g_graph_count = 0;
 static int64_t g_graph_hits = 0, g_graph_misses = 0;
@@ -201,8 +205,8 @@ static void graph_clear_locked() {
 // Runs body(stream) either directly, or -- graph mode, profiler off, no per-kernel debug sync -- as a cached graph.
 template <class Body>
 static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const void*, size_t>> parts, int debug, int device,
-                             hipStream_t stream, Body&& body) {
-  if (!g_graph_mode || debug || prof_on()) return body(stream);
+                             hipStream_t stream, int P, Body&& body) {
+  if (!g_graph_mode || debug || prof_on() || (g_graph_mode == 2 && P > g_graph_auto_p)) return body(stream);
   std::string key((const char*)&entry_id, sizeof(entry_id));
   for (auto& p : parts) if (p.first) key.append((const char*)p.first, p.second); else key.append(p.second, '\0');
   const uint64_t h = fnv1a(key);
@@ -250,16 +254,18 @@ static inline bool strip_mode(const TraseRastSettings* s) { return s->tile_row_b
 // sub-tile counts in that order.  `keys` = where the preprocess kernel left the keys (strip mode: the sort's SECOND buffer)
 static int depth_order(const LaunchCtx& c, const TraseRastSettings* s, const GeomBuf& g, const PreBuf& t, int P, const int32_t* radii,
                        int pack_bits) {
+  // the input sits in buffer DEPTH_START (odd pass counts start from buffer 1), so that the sorted ids land in vals[0], where
+  // stage 2 reads them
   int rc, idx = 0;
   if (strip_mode(s)) {
-    rc = launch_compact_live(c, g, P, t, t.sort.keys[1], t.sort.keys[0], t.sort.vals[0]);
+    rc = launch_compact_live(c, g, P, t, t.sort.keys[1 - DEPTH_START], t.sort.keys[DEPTH_START], t.sort.vals[DEPTH_START]);
     if (rc) return rc;
-    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, 32, false, &idx);
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, DEPTH_KEY_BITS, false, &idx, DEPTH_DIGIT_BITS, DEPTH_START);
   } else {
-    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, 32, true, &idx);   // ids generated on the fly
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, DEPTH_KEY_BITS, true, &idx, DEPTH_DIGIT_BITS, DEPTH_START);   // ids generated on the fly
   }
   if (rc) return rc;
-  if (idx != 0) {   // 4 passes: the sorted ids are back in vals[0], where stage 2 reads them
+  if (idx != 0) {
     set_error("internal: depth sort ended in buffer %d", idx);
     return TRASE_ERR_INVALID;
   }
@@ -327,7 +333,7 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   GeomBuf g = carve_geom(ws->geom, in->P);
   PreBuf t = carve_pre(ws->pre, in->P);
   if (in->P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
-  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
+  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - DEPTH_START : DEPTH_START]);
   if (rc) return rc;
   return depth_order(c, s, g, t, in->P, out->radii, list_pack_bits(s, in->P));
 }
@@ -394,7 +400,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
 int trase_rast_forward(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
                        const TraseRastWorkspace* ws, trase_stream_t stream) {
   if (!s || !in || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(1, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream,
+  return run_maybe_graphed(1, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream, in->P,
                            [&](hipStream_t st) {
                              int rc = trase_rast_preprocess(s, in, out, ws, st);
                              if (rc) return rc;
@@ -424,7 +430,7 @@ int trase_rast_backward(const TraseRastSettings* s, const TraseRastInputs* in, c
                         const TraseRastWorkspace* ws, const TraseRastGrads* gr, trase_stream_t stream_) {
   if (!s || !in || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
   return run_maybe_graphed(2, {{s, sizeof(*s)}, {in, sizeof(*in)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug, s->device,
-                           (hipStream_t)stream_, [&](hipStream_t st) { return backward_impl(s, in, out, ws, gr, st); });
+                           (hipStream_t)stream_, in->P, [&](hipStream_t st) { return backward_impl(s, in, out, ws, gr, st); });
 }
 
 static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, const TraseRastOutputs* out,
@@ -509,7 +515,7 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   GeomBuf g = carve_geom(ws->geom, in.P);
   PreBuf t = carve_pre(ws->pre, in.P);
   if (in.P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
-  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 : 0]);
+  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - DEPTH_START : DEPTH_START]);
   if (rc) return rc;
   return depth_order(c, s, g, t, in.P, out->radii, list_pack_bits(s, in.P));
 }
@@ -596,13 +602,13 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
                             const TraseRastWorkspace* ws, const TraseRastRawGrads* gr, trase_stream_t stream) {
   if (!s || !raw || !out || !ws || !gr) { set_error("null argument"); return TRASE_ERR_INVALID; }
   return run_maybe_graphed(4, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}, {gr, sizeof(*gr)}}, s->debug, s->device,
-                           (hipStream_t)stream, [&](hipStream_t st) { return backward_raw_phases(s, raw, out, ws, gr, st, 3, -1, -1); });
+                           (hipStream_t)stream, raw->P, [&](hipStream_t st) { return backward_raw_phases(s, raw, out, ws, gr, st, 3, -1, -1); });
 }
 
 int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                            const TraseRastWorkspace* ws, trase_stream_t stream) {
   if (!s || !raw || !out || !ws) { set_error("null argument"); return TRASE_ERR_INVALID; }
-  return run_maybe_graphed(3, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream,
+  return run_maybe_graphed(3, {{s, sizeof(*s)}, {raw, sizeof(*raw)}, {out, sizeof(*out)}, {ws, sizeof(*ws)}}, s->debug, s->device, (hipStream_t)stream, raw->P,
                            [&](hipStream_t st) {
                              int rc = trase_rast_preprocess_raw(s, raw, out, ws, st);
                              if (rc) return rc;

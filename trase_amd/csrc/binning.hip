@@ -32,15 +32,19 @@ __device__ __forceinline__ uint32_t dev_n(const uint32_t* n_ptr, uint32_t cap) {
 }
 
 // ---- pass kernel 1: per-workgroup digit histograms --------------------------------------------
+// DB = digit bits of a pass: 8 (the pair sort, KNN) or 11 (the depth sort: 32 key bits in 3 passes instead of 4)
+template <int DB>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t* __restrict__ digit_total, int nb_max) {
+  constexpr int ND = 1 << DB;
   const uint32_t n = dev_n(n_ptr, cap);
   const uint32_t base = blockIdx.x * RS_TILE;
   if (base >= n) return;
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  __shared__ uint32_t h[ND];
+#pragma unroll
+  for (int d = threadIdx.x; d < ND; d += RS_THREADS) h[d] = 0;
   __syncthreads();
   // Keys arrive in runs (consecutive pairs of one Gaussian share the high bits of the sub-tile id):
   // aggregate runs inside the wave so that a 64-lane run costs one LDS atomic instead of 64 serialized ones.
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
     }
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nb_max + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+  for (int d = threadIdx.x; d < ND; d += RS_THREADS) hist[(size_t)d * nb_max + blockIdx.x] = h[d];
 }
 
 // inclusive scan over the 256 threads of a workgroup: a DPP scan inside every wave, then the three lower waves'
@@ -139,29 +144,37 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
 
 // ---- pass kernel 3: stable scatter -------------------------------------------------------------
 // Each wave owns a contiguous 512-item segment and ranks it 64 items at a time with ballots:
-// lanes holding the same digit find each other through 8 bit-plane ballots; the rank inside the
+// lanes holding the same digit find each other through DB bit-plane ballots; the rank inside the
 // round is the number of lower lanes in the peer set, the rank across rounds comes from a
 // per-wave running counter in LDS.
-template <bool IOTA>
+template <bool IOTA, int DB>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total, int nb_max) {
+  constexpr int ND = 1 << DB;
+  constexpr int DPT = ND / RS_THREADS;          // digits per thread in the per-digit steps: thread t owns [t DPT, (t + 1) DPT)
   const uint32_t n = dev_n(n_ptr, cap);
   const uint32_t base = blockIdx.x * RS_TILE;
   if (base >= n) return;
-  __shared__ uint32_t wcount[RS_WAVES][256];
-  __shared__ uint32_t wbase[RS_WAVES][256];
+  __shared__ uint32_t wcount[RS_WAVES][ND];     // per-wave digit counts, then (in place) the counts of the earlier waves
   const int wave = threadIdx.x >> 6;
   const unsigned lane = threadIdx.x & 63;
-  for (int w = 0; w < RS_WAVES; ++w) wcount[w][threadIdx.x] = 0;
+#pragma unroll
+  for (int w = 0; w < RS_WAVES; ++w)
+#pragma unroll
+    for (int d = threadIdx.x; d < ND; d += RS_THREADS) wcount[w][d] = 0;
   __syncthreads();
   uint32_t k[RS_ITEMS], v[RS_ITEMS], rk[RS_ITEMS];
   const unsigned long long lt = lanemask_lt();
   volatile uint32_t* cnt = wcount[wave];
-  // (thread d: the global total of digit d and this workgroup's offset inside it -- requested now, used after the ranking)
-  const uint32_t my_digit_total = digit_total[threadIdx.x];
-  const uint32_t my_hist = hist[(size_t)threadIdx.x * nb_max + blockIdx.x];
+  // (thread t: the global totals of its digits and this workgroup's offsets inside them -- requested now, used after the ranking)
+  uint32_t my_digit_total[DPT], my_hist[DPT];
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    my_digit_total[j] = digit_total[threadIdx.x * DPT + j];
+    my_hist[j] = hist[(size_t)(threadIdx.x * DPT + j) * nb_max + blockIdx.x];
+  }
   // every key and value of the thread is requested up front: inside the ranking loop (volatile LDS counters, wave barriers)
   // the compiler waited for each round's pair of loads before ranking it -- eight dependent round trips per workgroup
 #pragma unroll
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t dg0 = __builtin_amdgcn_readfirstlane(dg);
     if (!__all(!valid || dg == dg0)) {      // fast path: every valid lane of the round holds the same digit
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
+      for (int bit = 0; bit < DB; ++bit) {
         const bool set = (dg >> bit) & 1u;
         const unsigned long long bal = __ballot(set);
         peers &= set ? bal : ~bal;
@@ -200,29 +213,36 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   // Block-local layout: items are first placed in LDS in their sorted order inside the block (digit-major, then
   // wave, then rank), then written out by consecutive threads -- a digit's run inside the block is contiguous in
   // the output too, so the stores are coalesced runs instead of 4-byte writes scattered over the whole array.
-  __shared__ uint32_t gbase[256], lstart[256], scan_tmp[256], scan_dig[256];
+  __shared__ uint32_t gbase[ND], lstart[ND];
   __shared__ uint32_t st_k[RS_TILE], st_v[RS_TILE];
-  {
-    const int d = threadIdx.x;
-    uint32_t tot = 0;
-#pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) {
-      wbase[w][d] = tot;                           // items of digit d in earlier waves of this block
-      tot += wcount[w][d];
-    }
-    scan_tmp[d] = tot;
-    scan_dig[d] = my_digit_total;
-  }
-  __syncthreads();
+  __shared__ uint32_t part_a[4], part_b[4];
   {   // two exclusive scans over the digits: this block's counts -> LDS layout, the global digit totals -> number of
-      // items with a smaller digit
-    const int d = threadIdx.x;
-    const uint32_t mine = scan_tmp[d], mine_g = scan_dig[d];
-    __shared__ uint32_t part_a[4], part_b[4];
-    const uint32_t ia = block256_incl_scan(mine, part_a);
-    const uint32_t ig = block256_incl_scan(mine_g, part_b);
-    lstart[d] = ia - mine;
-    gbase[d] = (ig - mine_g) + my_hist;
+      // items with a smaller digit.  A thread's DPT digits are consecutive: serial inside the thread, one block scan across.
+    uint32_t cnt_d[DPT], sum_l = 0, sum_g = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      const int d = threadIdx.x * DPT + j;
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) {
+        const uint32_t c = wcount[w][d];
+        wcount[w][d] = tot;                          // items of digit d in earlier waves of this block
+        tot += c;
+      }
+      cnt_d[j] = tot;
+      sum_l += tot;
+      sum_g += my_digit_total[j];
+    }
+    uint32_t run_l = block256_incl_scan(sum_l, part_a) - sum_l;
+    uint32_t run_g = block256_incl_scan(sum_g, part_b) - sum_g;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      const int d = threadIdx.x * DPT + j;
+      lstart[d] = run_l;
+      gbase[d] = run_g + my_hist[j];
+      run_l += cnt_d[j];
+      run_g += my_digit_total[j];
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -230,7 +250,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t idx = base + wave * RS_SEG + i * WAVE + lane;
     if (idx < n) {
       const uint32_t dg = (k[i] >> shift) & mask;
-      const uint32_t lp = lstart[dg] + wbase[wave][dg] + rk[i];
+      const uint32_t lp = lstart[dg] + wcount[wave][dg] + rk[i];
       st_k[lp] = k[i];
       st_v[lp] = v[i];
     }
@@ -246,39 +266,43 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   }
 }
 
-int radix_passes(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
+int radix_passes(int bit_lo, int bit_hi, int digit_bits) { return (bit_hi - bit_lo + digit_bits - 1) / digit_bits; }
 
-int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
-                     bool vals_are_iota, int* out_idx) {
-  int cur = 0;
+// digit_bits 8 or 11 (SortBufs::hist / digit_total must be sized for it: (1 << digit_bits) * nb_max and (1 << digit_bits) * passes);
+// `start`: which of the ping-pong buffers holds the input
+template <int DB>
+static int radix_sort_pairs_t(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
+                              bool vals_are_iota, int start, int* out_idx) {
+  constexpr int ND = 1 << DB;
+  int cur = start;
   const int nb = (int)((n_cap + RS_TILE - 1) / RS_TILE);
   if (nb > t.nb_max) { set_error("radix_sort_pairs: nb %d > nb_max %d", nb, t.nb_max); return TRASE_ERR_WORKSPACE; }
-  const int passes = radix_passes(bit_lo, bit_hi);
+  const int passes = radix_passes(bit_lo, bit_hi, DB);
   if (passes > 8) return TRASE_ERR_INVALID;
   for (int p = 0; p < passes; ++p) {
-    const int shift = bit_lo + 8 * p;
-    const int nbits = (bit_hi - shift) < 8 ? (bit_hi - shift) : 8;
+    const int shift = bit_lo + DB * p;
+    const int nbits = (bit_hi - shift) < DB ? (bit_hi - shift) : DB;
     const uint32_t mask = (1u << nbits) - 1u;
-    uint32_t* dt = t.digit_total + 256 * p;
+    uint32_t* dt = t.digit_total + ND * p;
     uint32_t* vout = t.vals[cur ^ 1];
     {
       ProfScope ps("radix_hist", c.stream);
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], n_ptr, n_cap, shift,
+      hipLaunchKernelGGL(radix_hist_kernel<DB>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], n_ptr, n_cap, shift,
                          mask, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
     {
       ProfScope ps("radix_scan", c.stream);
-      hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(ND), dim3(256), 0, c.stream, n_ptr, n_cap, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_scan", c.stream, c.debug);
     {
       ProfScope ps("radix_scatter", c.stream);
       if (vals_are_iota && p == 0)
-        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
+        hipLaunchKernelGGL((radix_scatter_kernel<true, DB>), dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
                            t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, dt, t.nb_max);
       else
-        hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
+        hipLaunchKernelGGL((radix_scatter_kernel<false, DB>), dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur],
                            t.vals[cur], t.keys[cur ^ 1], vout, n_ptr, n_cap, shift, mask, t.hist, dt, t.nb_max);
     }
     TRASE_POST_LAUNCH("radix_scatter", c.stream, c.debug);
@@ -286,6 +310,14 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
   }
   *out_idx = cur;
   return TRASE_OK;
+}
+
+int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
+                     bool vals_are_iota, int* out_idx, int digit_bits, int start) {
+  if (digit_bits == 9) return radix_sort_pairs_t<9>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx);   // (instantiated for the A/B build of the depth sort)
+  if (digit_bits == 8) return radix_sort_pairs_t<8>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx);
+  set_error("radix_sort_pairs: digit_bits %d", digit_bits);
+  return TRASE_ERR_INVALID;
 }
 
 // ---- inclusive scan of tiles touched, taken in depth-rank order --------------------------------

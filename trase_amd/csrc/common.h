@@ -302,8 +302,8 @@ struct ImgBuf {            // saved between forward and backward
 struct SortBufs {          // ping-pong storage of one radix sort
   uint32_t* keys[2];
   uint32_t* vals[2];
-  uint32_t* hist;          // (256 * nb_max)
-  uint32_t* digit_total;   // (256 * 8) one row per radix pass
+  uint32_t* hist;          // (digits * nb_max), digits = 256 (2048 for the depth sort)
+  uint32_t* digit_total;   // (digits * passes) one row per radix pass
   int nb_max;
 };
 struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
@@ -390,8 +390,24 @@ int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pr
 // stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
 int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
-                     bool vals_are_iota, int* out_idx);
-int radix_passes(int bit_lo, int bit_hi);
+                     bool vals_are_iota, int* out_idx, int digit_bits = 8, int start = 0);
+int radix_passes(int bit_lo, int bit_hi, int digit_bits = 8);
+// The depth sort.  Default: the float32 depth bits in four 8-bit passes (12 launches).  -DTRASE_DEPTH_DIGITS=9 (measured, see
+// profiles/r5_ab_experiments.txt): an order-preserving 27-bit key -- float bits above those of the 0.2 near-cull plane (z > 0.2
+// for every live Gaussian), saturated: exact order for z < ~13 107 -- in three 9-bit passes (9 launches).
+#ifndef TRASE_DEPTH_DIGITS
+#define TRASE_DEPTH_DIGITS 8
+#endif
+constexpr int DEPTH_DIGIT_BITS = TRASE_DEPTH_DIGITS;
+constexpr int DEPTH_KEY_BITS = DEPTH_DIGIT_BITS == 9 ? 27 : 32;
+constexpr int DEPTH_PASSES = (DEPTH_KEY_BITS + DEPTH_DIGIT_BITS - 1) / DEPTH_DIGIT_BITS;
+constexpr int DEPTH_START = DEPTH_PASSES & 1;      // buffer the sort starts from, so that the sorted ids land in vals[0]
+__host__ __device__ inline uint32_t depth_sort_key(float z, bool live) {
+  const uint32_t bits = __builtin_bit_cast(uint32_t, z);
+  if (DEPTH_KEY_BITS == 32) return live ? bits : 0xffffffffu;
+  const uint32_t b = bits - 0x3e4ccccdu;
+  return live ? (b < 0x07fffffeu ? b : 0x07fffffeu) : 0x07ffffffu;
+}
 
 // pack_bits: 0 = never pack; jb = pack list values as (id << jb | j) when every Gaussian has fewer than 2^jb pairs
 // strip mode: (depth key, id) of the Gaussians with a pair, ascending ids, then the ids without one; hdr[HDR_WORDS - 1] = live count

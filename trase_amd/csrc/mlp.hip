@@ -860,6 +860,12 @@ struct WgradJob {
   float* bias_partial; // [G][M] or null
 };
 constexpr int WG_MAX_JOBS = 8;
+#ifndef WG_PE_SA
+#define WG_PE_SA true     // the dZ images of the encoding jobs are read once: non-temporal (0.086 -> 0.069 ms); the encoding image is shared by both jobs
+#endif
+#ifndef WG_HEAD_SB
+#define WG_HEAD_SB false
+#endif
 // distance between the partial planes of consecutive row groups, in floats: NOT the bare M * NK -- the reduction reads the
 // same offset of every plane, and planes a power of two apart put all of those reads on the same memory channels
 #ifndef WG_PLANE_PAD
@@ -1007,7 +1013,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // Schedule of K-step s: wait for MY loads of K-step s + 1, barrier (everybody's have landed; everybody holds K-step s in
 // registers, so slot s is free), request K-step s + NST into slot s, read K-step s + 1 from LDS into the second register set,
 // multiply K-step s -- the LDS latency of the next fragments hides under this step's MFMAs (one wave per SIMD: nobody else would).
-template <int MT, int NT, int WM, int WN, int NST, bool STREAM>
+template <int MT, int NT, int WM, int WN, int NST, bool STREAM_A, bool STREAM_B>
 __global__ __launch_bounds__(256) void mlp_wgrad_lds_kernel(WgradJobs jobs, const int* __restrict__ live_list,
                                                             const int* __restrict__ n_live_ptr, int G) {
   static_assert(WM * WN == 4 && MT % WM == 0 && NT % WN == 0, "four waves");
@@ -1043,10 +1049,12 @@ __global__ __launch_bounds__(256) void mlp_wgrad_lds_kernel(WgradJobs jobs, cons
   // loader role: wave w brings fragments w LPW .. w LPW + LPW - 1 of the K-step's F (A image first, then B)
   const __bf16* lsrc[LPW];
   size_t ltile[LPW], lhalf[LPW];
+  bool l_is_a[LPW];
 #pragma unroll
   for (int b = 0; b < LPW; ++b) {
     const int fid = min(wave * LPW + b, F - 1);
     const bool isA = fid < MT;
+    l_is_a[b] = isA;
     lsrc[b] = (isA ? job.A + (size_t)fid * 512 : job.B + (size_t)(fid - MT) * 512) + (size_t)i * 16 + 8 * h;
     ltile[b] = isA ? (size_t)M * 32 : (size_t)NK * 32;
     lhalf[b] = isA ? (size_t)M * 16 : (size_t)NK * 16;
@@ -1057,7 +1065,12 @@ __global__ __launch_bounds__(256) void mlp_wgrad_lds_kernel(WgradJobs jobs, cons
     const size_t tile = (size_t)tile_id;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * (unsigned)SLOT + my_slot_off);
 #pragma unroll
-    for (int b = 0; b < LPW; ++b) glds16<STREAM>(lsrc[b] + tile * ltile[b] + (size_t)(step & 1) * lhalf[b], dst + b * 1024u);
+    for (int b = 0; b < LPW; ++b) {
+      const void* src = lsrc[b] + tile * ltile[b] + (size_t)(step & 1) * lhalf[b];
+      if constexpr (STREAM_A == STREAM_B) glds16<STREAM_A>(src, dst + b * 1024u);
+      else if (l_is_a[b] ? STREAM_A : STREAM_B) glds16<true>(src, dst + b * 1024u);      // (wave-uniform)
+      else glds16<false>(src, dst + b * 1024u);
+    }
   };
   if (s_begin < s_end) {
     // (steps past the end re-request the last one: the count of loads in flight is then the same in every K-step)
@@ -1246,7 +1259,9 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   // one workgroup per CU for the big GEMMs (252 = 7 x 36), more and shorter ones for the narrow jobs
   static const int gh_env = [] { const char* e = getenv("TRASE_MLP_GH"); return e ? atoi(e) : 0; }();
   const int gh_max = gh_env > 0 ? gh_env : 36;
-  p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128); p.Gd = p.Gp;
+  p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128);
+  static const int gd_env = [] { const char* e = getenv("TRASE_MLP_GD"); return e ? atoi(e) : 0; }();
+  p.Gd = (int)(tiles < (size_t)(gd_env > 0 ? gd_env : 128) ? tiles : (gd_env > 0 ? gd_env : 128));
   if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
   p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * wg_plane(MW, MW));
   p.bias_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW);
@@ -1466,7 +1481,7 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
     ProfScope ps("mlp_wgrad_hidden", stream);
     static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
     if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 8, 2, 2, 9, true>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 8, 2, 2, 9, true, true>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
                          (const int*)bp.n_live, bp.Gh);
     else
       hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
@@ -1487,7 +1502,7 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
     ProfScope ps("mlp_wgrad_pe", stream);
     static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
     if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 3, 4, 1, 12, false>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 3, 4, 1, 12, WG_PE_SA, false>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
                          (const int*)bp.n_live, bp.Gp);
     else
       hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
@@ -1505,7 +1520,7 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
     ProfScope ps("mlp_wgrad_head", stream);
     static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
     if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<1, 8, 1, 4, 12, false>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<1, 8, 1, 4, 12, false, WG_HEAD_SB>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
                          (const int*)bp.n_live, bp.Gd);
     else
       hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   }
   if (active) {
     tiles[i] = live;
-    depth_keys[i] = (vis && live) ? __float_as_uint(o.depth) : 0xffffffffu;
+    depth_keys[i] = depth_sort_key(o.depth, vis && live);
   }
   if (vis) {
     xy[i] = make_float2(o.px, o.py);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
   }
   if (active) {
     tiles[i] = live;
-    depth_keys[i] = (vis && live) ? __float_as_uint(o.depth) : 0xffffffffu;
+    depth_keys[i] = depth_sort_key(o.depth, vis && live);
   }
   const bool want = vis && (live != 0 || !strip);             // gets a colour and a record
   if (!strip) {

@@ -75,14 +75,17 @@ def set_sync(flag: bool, capacity: int = 0):
     _Policy.rollbacks = {}
 
 
-def set_graph(flag: bool = True):
+def set_graph(flag="auto"):
     """Launch-graph replay (include/trase_rast.h ``trase_rast_graph_mode``): with the sync-free policy, a forward or backward
     whose argument record (sizes, every pointer) repeats is replayed as ONE hipGraph launch instead of ~45 kernel launches.
     Pays on small workloads, where the launches cost more host time than the kernels run (BASELINE configs 1 and 2: 1 k and
-    150 k Gaussians); at the 1080p headline the step is GPU-bound either way.  Needs ``set_sync(False)``; records repeat
-    when the allocator hands out the same blocks every iteration (a steady training loop); if they do not, the library
-    switches the mode off by itself."""
-    _lib.check(_lib.load().trase_rast_graph_mode(1 if flag else 0), "trase_rast_graph_mode")
+    150 k Gaussians); at the 1080p headline the step is GPU-bound either way.  ``"auto"`` -- the LIBRARY DEFAULT (round 5:
+    a drop-in user of render() gets the small-scene numbers without asking) -- replays calls of at most 200 000 Gaussians
+    (``TRASE_GRAPH_AUTO_P``); True: every call; False: never.  Only the sync-free entry points (``set_sync(False)``) are
+    replayed; records repeat when the allocator hands out the same blocks every iteration (a steady training loop); if they
+    do not, the library switches the mode off by itself.  Environment: ``TRASE_GRAPH=0|1|auto``."""
+    mode = 2 if flag == "auto" else (1 if flag else 0)
+    _lib.check(_lib.load().trase_rast_graph_mode(mode), "trase_rast_graph_mode")
 
 
 def graph_stats() -> dict:
