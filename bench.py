@@ -145,7 +145,10 @@ def main():
                          "after the backward; 0 (default) = chosen from the exchange model (trase_amd.dp.recommended_chunks: "
                          "ranges whenever the modelled exchange is longer than they cost -- every extra range costs ~0.027 ms "
                          "of kernel ramp/tail at S4, measured at N=1)")
-    ap.add_argument("--exchange", choices=["allreduce", "rs_ag", "direct"], default="allreduce",
+    ap.add_argument("--active-sh-degree", type=int, default=3,
+                    help="--exchange phased: the active SH degree handed to the phased exchange (train.py:160 ramps it 0 -> 3): only the "
+                         "active f_rest coefficient rows are exchanged")
+    ap.add_argument("--exchange", choices=["allreduce", "rs_ag", "direct", "phased"], default="allreduce",
                     help="algorithm of the gradient exchange (trase_amd.dp.FlatGradBucket): one RCCL all-reduce (default; RCCL "
                          "picks ring / tree), reduce-scatter + all-gather on the padded flat bucket, or the same two phases as "
                          "grouped point-to-point transfers to every peer at once (all seven xGMI links of a GPU busy)")
@@ -236,7 +239,13 @@ def main():
     # one flat gradient bucket; .grad of every parameter is a view into it (single all-reduce)
     # (only needed when there is an exchange step; at N=1 autograd just assigns .grad)
     from trase_amd.dp import FlatGradBucket
-    bucket = FlatGradBucket(params, exchange=args.exchange) if (world > 1 or args.bucket != "auto" or args.force_collectives) else None
+    # "phased": FlatGradBucket.allreduce_phased (xyz first, the rest on a side stream until the next step's render) with the
+    # "direct" algorithm; one exchange per step, no Gaussian-range overlap
+    phased = args.exchange == "phased"
+    if phased:
+        args.exchange_chunks = 1
+    bucket = FlatGradBucket(params, exchange="direct" if phased else args.exchange) if (world > 1 or args.bucket != "auto" or args.force_collectives) else None
+    phase = {"ex": None, "bytes": None}
     if bucket is not None:
         bucket._force = bool(args.force_collectives)      # one-rank RCCL group: issue the collectives anyway
         bucket.time_exchange = True                       # HIP events around the collective(s): `exchange_ms` of the bench line
@@ -275,6 +284,9 @@ def main():
         else:
             for p_ in params:
                 p_.grad = None            # autograd adopts the gradients (N > 1: views into the bucket, see above)
+        if phase["ex"] is not None:        # phase B of the previous step's exchange: needed before this step's preprocess
+            phase["ex"].wait_rest()
+            phase["ex"] = None
         if not args.unfused:
             # render() drop-in: the A1 prep (activations, SH concat, feature normalisation) is fused into the
             # per-Gaussian HIP kernels
@@ -290,7 +302,11 @@ def main():
                 means3D=pc.get_xyz, means2D=means2D, shs=pc.get_features, sh_objs=sh_objs, colors_precomp=None,
                 opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
         torch.autograd.backward([img, feats], [g_img, g_feat])
-        if bucket is not None:
+        if bucket is not None and phased:
+            ex = bucket.allreduce_phased(first=[pc._xyz], sh_rest=(pc._features_rest, args.active_sh_degree))
+            ex.wait_first()                # (Adam(xyz, MLP) and the next iteration's MLP forward would run here)
+            phase["ex"], phase["bytes"] = ex, (ex.bytes_first, ex.bytes_rest)
+        elif bucket is not None:
             bucket.allreduce()
         return radii
 
@@ -427,6 +443,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if phase["ex"] is not None:
+        phase["ex"].wait_rest()
+        phase["ex"] = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -541,6 +560,7 @@ def main():
                        # ranges the window opens at the first range's hand-off, i.e. it includes the backward tail underneath
                        "exchange_ms": (None if exchange_ms is None else round(exchange_ms, 4)),
                        "exchange_algo": (None if bucket is None else args.exchange),
+                       "phased_bytes_first_rest": phase["bytes"],
                        "exchange": (None if bucket is None else
                                     f"flat bucket {bucket.bytes_per_step} B/step, "
                                     + ("zero + accumulate" if not use_sink else

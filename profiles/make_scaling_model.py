@@ -6,7 +6,7 @@ GPU at once) gradient exchange.  Inputs: single-GPU measurements of this round (
 multi-GPU hardware; the point of the table is to say what each axis costs once the exchange is counted and which axis
 BASELINE config 5 should use.
 
-    python profiles/make_scaling_model.py > profiles/r4_scaling_model.json"""
+    python profiles/make_scaling_model.py > profiles/r5_scaling_model.json"""
 import json
 import os
 import sys
@@ -60,6 +60,47 @@ for state, bpg in B_PER_GAUSSIAN.items():
                          "speedup_vs_one_gpu": round(SIZES["S5"]["view_ms"] / step, 3)}
         per_w[str(w)] = rec
     out["axis_2_tile_rows_of_one_view"][state] = {"bucket_bytes": nbytes, "one_gpu_view_ms": SIZES["S5"]["view_ms"], "world": per_w}
+# ---- round 5: the phased exchange (trase_amd.dp.FlatGradBucket.allreduce_phased) against WHOLE iterations ---------------------
+# GAUSSIAN state: phase A = xyz (12 B / Gaussian) + the MLP's 2.03 MB, waited on before Adam(xyz, MLP); phase B = the rest
+# (f_dc 12, opacity 4, scaling 12, rotation 16 + 12 B per ACTIVE f_rest coefficient row, 15 at full degree) runs underneath the
+# next iteration's MLP training forward + the optimizer step of phase A.  FEATURE state: the 128 B / Gaussian feature bucket
+# underneath the no_grad MLP forward.  Single-GPU figures of this round: profiles/r5_iteration_breakdown.json.
+ITER = {"gaussian_iteration_ms": float(os.environ.get("S4_GAUSSIAN_ITER_MS", "2.05")), "mlp_train_forward_ms": 0.41, "adam_first_ms": 0.02,
+        "feature_iteration_ms": float(os.environ.get("S4_FEATURE_ITER_MS", "2.31")), "mlp_inference_forward_ms": 0.31}
+MLP_BYTES = 506_378 * 4
+n4 = SIZES["S4"]["n"]
+ph = {"inputs": ITER, "note": "exposed = phase A + what of phase B outlasts its hiding window; step = iteration + exposed; the un-phased row "
+      "is one exchange of the whole state bucket after the backward (round 4's schedule).  MODEL: nothing here ran on two GPUs.", "gaussian_state": {},
+      "feature_state": {}}
+for deg in (0, 1, 2, 3):
+    k = (deg + 1) ** 2 - 1
+    a_bytes = n4 * 12 + MLP_BYTES
+    b_bytes = n4 * (12 + 4 + 12 + 16 + 12 * k)
+    full = n4 * 236 + MLP_BYTES
+    rows = {}
+    for w in (2, 4, 8):
+        rec = {}
+        for algo in ("ring", "direct"):
+            ta, tb, tf = exchange_model_ms(a_bytes, w, algo), exchange_model_ms(b_bytes, w, algo), exchange_model_ms(full, w, algo)
+            window = ITER["mlp_train_forward_ms"] + ITER["adam_first_ms"]
+            exposed = ta + max(0.0, tb - window)
+            it = ITER["gaussian_iteration_ms"]
+            rec[algo] = {"phase_a_ms": round(ta, 3), "phase_b_ms": round(tb, 3), "hidden_ms": round(min(tb, window), 3), "exposed_ms": round(exposed, 3),
+                         "efficiency_phased": round(it / (it + exposed), 3), "efficiency_unphased_full_bucket": round(it / (it + tf), 3)}
+        rows[str(w)] = rec
+    ph["gaussian_state"][f"active_sh_degree_{deg}"] = {"phase_a_bytes": a_bytes, "phase_b_bytes": b_bytes, "unphased_bytes": full, "world": rows}
+rows = {}
+for w in (2, 4, 8):
+    rec = {}
+    for algo in ("ring", "direct"):
+        tb = exchange_model_ms(n4 * 128, w, algo)
+        window = ITER["mlp_inference_forward_ms"]
+        it = ITER["feature_iteration_ms"]
+        rec[algo] = {"phase_b_ms": round(tb, 3), "hidden_ms": round(min(tb, window), 3), "exposed_ms": round(max(0.0, tb - window), 3),
+                     "efficiency_phased": round(it / (it + max(0.0, tb - window)), 3), "efficiency_unphased": round(it / (it + tb), 3)}
+    rows[str(w)] = rec
+ph["feature_state"] = {"bucket_bytes": n4 * 128, "world": rows}
+out["axis_1_phased_exchange_S4_whole_iterations"] = ph
 v8 = out["axis_1_view_parallel"]["S5"]["buckets"]["all parameters"]["world"]["8"]["direct"]
 t8 = dict(out["axis_2_tile_rows_of_one_view"]["all parameters"]["world"]["8"]["direct"],
           slowest_strip_ms_measured_one_gpu=out["axis_2_tile_rows_of_one_view"]["all parameters"]["world"]["8"]["slowest_strip_ms_measured_one_gpu"])

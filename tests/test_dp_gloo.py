@@ -351,3 +351,83 @@ def test_guard_header_is_reduced_for_every_forward_with_a_recycled_pin():
     out = mgr.dict()
     mp.spawn(_guard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _phased_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket
+    P = 41                                            # ragged against world = 3 and against 64-float shards
+
+    def make():
+        torch.manual_seed(0)                          # identical replicas
+        xyz = torch.randn(P, 3, requires_grad=True)
+        f_dc = torch.randn(P, 1, 3, requires_grad=True)
+        f_rest = torch.randn(P, 15, 3, requires_grad=True)
+        opac = torch.randn(P, 1, requires_grad=True)
+        mlp = [torch.randn(6, 5, requires_grad=True), torch.randn(6, requires_grad=True)]
+        return xyz, f_dc, f_rest, opac, mlp
+
+    def loss_of(params, it, degree):
+        # a different "view" per rank and iteration; the SH coefficients above the active degree do not enter (their gradient is
+        # identically zero on every rank, as in the rasterizer: train.py:160, scene/gaussian_model.py:219-221)
+        xyz, f_dc, f_rest, opac, mlp = params
+        k = (degree + 1) ** 2 - 1
+        w = 0.37 * (rank + 1) + 0.11 * it
+        d = torch.tanh(xyz @ mlp[0][:3, :3] + mlp[1][:3])                   # "the deformation network"
+        return (torch.sin(w * (xyz + d)).sum() + torch.cos(w * f_dc).sum() + (torch.sin(w * f_rest[:, :k, :]) * 1.3).sum()
+                + torch.sigmoid(opac * w).sum())
+
+    results = {}
+    for mode in ("plain", "phased"):
+        params = make()
+        xyz, f_dc, f_rest, opac, mlp = params
+        flat_params = [xyz, f_dc, f_rest, opac] + mlp
+        first = [xyz] + mlp
+        rest = [f_dc, f_rest, opac]
+        bucket = FlatGradBucket(flat_params, exchange="direct")
+        opt_first = torch.optim.Adam(first, lr=1e-2, eps=1e-15)
+        opt_rest = torch.optim.Adam(rest, lr=1e-2, eps=1e-15)
+        sizes = []
+        for it in range(3):
+            degree = min(it, 3)                       # the ramp: degree 0, 1, 2
+            bucket.zero()
+            loss_of(params, it, degree).backward()
+            if mode == "plain":
+                bucket.allreduce(average=True)
+                opt_first.step()
+                opt_rest.step()
+            else:
+                ex = bucket.allreduce_phased(first=first, sh_rest=(f_rest, degree), average=True)
+                ex.wait_first()
+                opt_first.step()
+                # (the next iteration's MLP forward would run here, on the updated xyz / MLP parameters)
+                _ = torch.tanh(xyz.detach() @ mlp[0].detach()[:3, :3])
+                ex.wait_rest()
+                opt_rest.step()
+                sizes.append((ex.bytes_first, ex.bytes_rest))
+        results[mode] = [p.detach().clone() for p in flat_params]
+        if mode == "phased":
+            # phase A = xyz + MLP; phase B shrinks with the active SH degree: (3 + 1 + 3 k) floats per Gaussian
+            ok_sizes = all(a == 4 * (P * 3 + 36) for a, _ in sizes)
+            ok_sizes = ok_sizes and [b for _, b in sizes] == [4 * P * (3 + 1 + 3 * k) for k in (0, 3, 8)]
+    ok = all(torch.equal(a, b) for a, b in zip(results["plain"], results["phased"]))
+    # replicas stay bit-identical
+    mine = torch.cat([t.reshape(-1) for t in results["phased"]])
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    ok = ok and all(torch.equal(o, mine) for o in other)
+    out[rank] = bool(ok and ok_sizes)
+    dist.destroy_process_group()
+
+
+def test_phased_exchange_is_bit_identical_to_the_plain_exchange_over_three_iterations():
+    """the exchange in two phases -- (xyz, MLP) first, the rest (with only the ACTIVE f_rest coefficients
+    during the SH ramp) behind the next iteration's first kernels.  World size 3, ragged sizes, the "direct" algorithm: the
+    parameters after three Adam iterations must equal, bit for bit, those of the un-overlapped exchange, on every replica."""
+    world = 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_phased_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True, 2: True}

@@ -79,3 +79,31 @@ def test_graph_mode_is_ignored_by_the_synchronising_policy():
         R.set_graph("auto")
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_graph_replay_clears_its_scratch_on_every_hit(monkeypatch):
+    """Round 5 regression: the backward clears the pair flags of its gradient-row scratch at its start.  As a hipMemsetAsync
+    captured into the launch graph that clear worked for the capture and the first replay only (ROCm 7.0.2): from the second
+    hit on, rows of stale flags were summed into a quarter of the Gaussians' gradients.  It is a kernel now
+    (launch_zero_bytes).  Poisoned workspaces (0xFF = every flag set, NaN rows) make any missing clear visible."""
+    from trase_amd import rasterizer as R
+    from tests import test_gpu_overlap as T
+    monkeypatch.setattr(R, "_POISON", True)
+    pc, pipe, cam, dev = T._scene()
+    params = pc.parameters()
+    try:
+        R.set_graph(False)
+        for p in params:
+            p.grad = None
+        T._backward(pc, pipe, cam, dev)
+        base = [p.grad.clone() for p in params]
+        R.set_graph("auto")
+        for it in range(6):
+            for p in params:
+                p.grad = None
+            T._backward(pc, pipe, cam, dev)
+            for k, (p, b) in enumerate(zip(params, base)):
+                assert torch.equal(p.grad, b), f"iteration {it}, parameter {k}: graph replay differs from the eager backward"
+        assert R.graph_stats()["hits"] >= 4
+    finally:
+        R.set_graph("auto")

@@ -392,7 +392,7 @@ int trase_rast_render(const TraseRastSettings* s, const TraseRastInputs* in, con
     if (rc) return rc;
     return launch_render_fwd(c, *s, *in, *out, g, b, im, t.pair_gauss, (uint32_t)cap);
   } else {
-    TRASE_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * ((size_t)T + 1), stream));
+    launch_zero_bytes(b.ranges, sizeof(uint2) * ((size_t)T + 1), stream);
   }
   return launch_render_fwd(c, *s, *in, *out, g, b, im);
 }
@@ -463,14 +463,14 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
     zero_feats = g2.dL_dsh_objs != nullptr && in->F > 0;
     g2.dL_dsh_objs = nullptr;
   }
-  if (zero_feats) TRASE_CHECK(hipMemsetAsync(gr->dL_dsh_objs, 0, sizeof(float) * (size_t)in->F * in->P, stream));
+  if (zero_feats) launch_zero_bytes(gr->dL_dsh_objs, sizeof(float) * (size_t)in->F * in->P, stream);
   // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
   // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
   // F == 0 here also means "no feature cotangent" (GAUSSIAN-state iterations): the MFMA kernel's image-only scope
   if ((in2.F == 32 || in2.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
     rc = launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
   } else {
-    TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+    launch_zero_bytes(row_flags, (size_t)ws->capacity, stream);
     rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags, out->depth);
   }
   if (rc) return rc;
@@ -575,11 +575,11 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
   const bool sparse = strip_mode(s) && !ranged && (s->variant & TRASE_VARIANT_SPARSE_STRIP_GRADS) != 0;
   if (phase & 1) {
     if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0 && !sparse)
-      TRASE_CHECK(hipMemsetAsync(gr->dL_dgaussian_features, 0, sizeof(float) * (size_t)raw->F * raw->P, stream));
+      launch_zero_bytes(gr->dL_dgaussian_features, sizeof(float) * (size_t)raw->F * raw->P, stream);
     if ((in.F == 32 || in.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
       rc = launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
     } else {
-      TRASE_CHECK(hipMemsetAsync(row_flags, 0, (size_t)ws->capacity, stream));
+      launch_zero_bytes(row_flags, (size_t)ws->capacity, stream);
       rc = launch_render_bwd_gs(c, *s, in, g, b, im, g2, rows, row_flags, out->depth);
     }
     if (rc) return rc;

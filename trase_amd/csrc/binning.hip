@@ -266,6 +266,25 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint8_t* __restrict__ p, size_t bytes) {
+  // 16-byte stores over the aligned middle, single bytes at the ragged ends
+  const size_t head = ((size_t)(-(intptr_t)p) & 15u) < bytes ? ((size_t)(-(intptr_t)p) & 15u) : bytes;
+  const size_t n16 = (bytes - head) >> 4;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  const size_t tail0 = head + (n16 << 4);
+  if (t < head) p[t] = 0;
+  if (t < bytes - tail0) p[tail0 + t] = 0;
+}
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
+  if (!p || bytes == 0) return TRASE_OK;
+  const size_t n16 = bytes >> 4;
+  const unsigned blocks = (unsigned)(n16 / 256 / 4 + 1 < 4096 ? n16 / 256 / 4 + 1 : 4096);
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(blocks), dim3(256), 0, stream, (uint8_t*)p, bytes);
+  return TRASE_OK;
+}
+
 int radix_passes(int bit_lo, int bit_hi, int digit_bits) { return (bit_hi - bit_lo + digit_bits - 1) / digit_bits; }
 
 // digit_bits 8 or 11 (SortBufs::hist / digit_total must be sized for it: (1 << digit_bits) * nb_max and (1 << digit_bits) * passes);
@@ -918,7 +937,7 @@ __global__ __launch_bounds__(256) void tile_ranges4_kernel(const uint32_t* __res
 
 int launch_tile_ranges(const LaunchCtx& c, const uint32_t* keys, const uint32_t* n_ptr, uint32_t cap, uint2* ranges, int T,
                        uint32_t* dbg, bool clear) {
-  if (clear) TRASE_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, c.stream));
+  if (clear) launch_zero_bytes(ranges, sizeof(uint2) * (size_t)T, c.stream);
   int blocks = (int)((cap + 1023) / 1024);
   if (blocks < 1) blocks = 1;
   {

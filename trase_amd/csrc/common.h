@@ -391,6 +391,9 @@ int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pr
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
 int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
                      bool vals_are_iota, int* out_idx, int digit_bits = 8, int start = 0);
+// zero-fill as a KERNEL: a hipMemsetAsync captured into a launch graph did not clear its buffer from the second replay on
+// (round 5: gradient rows of stale pair flags -- NaN under TRASE_POISON -- on every graph hit after the first; ROCm 7.0.2)
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t stream);
 int radix_passes(int bit_lo, int bit_hi, int digit_bits = 8);
 // The depth sort.  Default: the float32 depth bits in four 8-bit passes (12 launches).  -DTRASE_DEPTH_DIGITS=9 (measured, see
 // profiles/r5_ab_experiments.txt): an order-preserving 27-bit key -- float bits above those of the 0.2 near-cull plane (z > 0.2

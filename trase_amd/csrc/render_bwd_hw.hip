@@ -570,7 +570,7 @@ int launch_render_bwd_hw(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.W = s.image_width; a.H = s.image_height;
   a.gx8 = (a.W + SUB - 1) / SUB;
   { int lo, hi; strip_subtile_rows(s, lo, hi); a.tile0 = lo * a.gx8; a.ntiles = (hi - lo) * a.gx8; }
-  TRASE_CHECK(hipMemsetAsync(row_flags, 0, flag_bytes, c.stream));
+  launch_zero_bytes(row_flags, flag_bytes, c.stream);   // (a kernel, not a memset node: common.h)
   if (a.ntiles <= 0) return TRASE_OK;                    // an empty strip: no rows (the flags are cleared)
   {
     ProfScope ps("render_bwd", c.stream);

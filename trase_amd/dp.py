@@ -289,7 +289,12 @@ class FlatGradBucket:
         shard = (self.numel + world - 1) // world
         shard = (shard + 63) // 64 * 64
         assert shard * world <= self._store.numel()
-        buf = self._store[:shard * world]
+        self._exchange_padded(self._store[:shard * world], shard)
+
+    def _exchange_padded(self, buf: torch.Tensor, shard: int):
+        """The "rs_ag" / "direct" exchange of a buffer of exactly world * shard elements (see _exchange_flat)."""
+        import torch.distributed as dist
+        world = dist.get_world_size()
         rank = dist.get_rank()
         mine = buf[rank * shard:(rank + 1) * shard]
         if self.exchange == "rs_ag" and dist.get_backend() != "gloo":
@@ -299,8 +304,9 @@ class FlatGradBucket:
             return
         # phase 1: every rank receives its shard from every peer and sums in rank order
         tmp = getattr(self, "_tmp", None)
-        if tmp is None or tmp.numel() != shard * world:
+        if tmp is None or tmp.numel() < shard * world or tmp.device != buf.device:
             self._tmp = tmp = torch.empty(shard * world, device=buf.device, dtype=buf.dtype)
+        tmp = tmp[:shard * world]
         ops = []
         for peer in range(world):
             if peer == rank:
@@ -320,6 +326,140 @@ class FlatGradBucket:
             ops.append(dist.P2POp(dist.irecv, buf[peer * shard:(peer + 1) * shard], peer))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+    def _exchange_run(self, t: torch.Tensor):
+        """SUM of one contiguous 1-D tensor (a run of the flat buffer, or a packed copy) by the configured algorithm.  The
+        shard algorithms work on a padded staging copy: a run's length is not a multiple of world x 64."""
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        if self.exchange == "allreduce" or world == 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        n = t.numel()
+        shard = ((n + world - 1) // world + 63) // 64 * 64
+        st = getattr(self, "_stage", None)
+        if st is None or st.numel() < shard * world or st.device != t.device:
+            self._stage = st = torch.empty(shard * world, device=t.device, dtype=t.dtype)
+        buf = st[:shard * world]
+        buf[:n].copy_(t)
+        buf[n:].zero_()
+        self._exchange_padded(buf, shard)
+        t.copy_(buf[:n])
+
+    # ---- phased exchange: hidden behind the NEXT iteration --------------------------------------------------------------
+    def allreduce_phased(self, first: Iterable[torch.Tensor], sh_rest=None, average: bool = False) -> "PhasedExchange":
+        """The exchange in two phases, for a loop that hides most of it behind the next iteration's first kernels.
+
+        The reference's next iteration starts with the deformation MLP on ``xyz.detach()`` and ``t`` (train.py:202-204): of
+        everything this exchange produces, only the gradients of ``_xyz`` and of the MLP's own parameters are needed before
+        that forward may run (through their optimizer steps).  So:
+
+        * phase A = the slices of ``first`` (GAUSSIAN state: ``_xyz`` 12 B / Gaussian + the MLP's 2.0 MB), exchanged first;
+          ``wait_first()`` before ``Adam(first)``;
+        * phase B = everything else (f_dc, f_rest, opacity, scaling, rotation: 224 B / Gaussian), exchanged behind phase A on
+          the same side stream; ``wait_rest()`` only before the next ``render()``'s preprocess -- i.e. phase B runs underneath
+          the next iteration's MLP training forward (0.4 ms at 300k Gaussians) and the optimizer step of ``first``.
+          FEATURE state (``first=[]``): the whole feature bucket is phase B, behind the ``no_grad`` MLP forward.
+        * ``sh_rest=(f_rest_parameter, active_sh_degree)``: during the SH ramp (train.py:160, one degree per 1000 iterations;
+          scene/gaussian_model.py:219-221) the coefficients above the active degree receive an identically zero gradient on
+          every rank -- 76 % of the GAUSSIAN bucket at degree 0.  Only the active ``(d + 1)^2 - 1`` of the 15 coefficient rows
+          are exchanged (packed, reduced, scattered back); degree 0 exchanges nothing of f_rest.
+
+        On a GPU the collectives and their staging copies run on a side stream (the current stream is free to run the next
+        iteration); the handle's waits are stream waits, not host waits.  gloo (CPU tests): synchronous.  With the "direct"
+        algorithm every element is summed in rank order wherever it sits, so the result is bit-identical to allreduce()."""
+        import torch.distributed as dist
+        if getattr(self, "_pending", None):
+            raise RuntimeError("FlatGradBucket.allreduce_phased: ranges of an overlapped exchange are pending; use allreduce()")
+        self.gather_grads()
+        ex = PhasedExchange(self, average)
+        if not self._collectives_on():
+            return ex
+        first_ids = {id(p) for p in first}
+        unknown = first_ids - {id(p) for p in self.params}
+        if unknown:
+            raise ValueError("allreduce_phased: a tensor of `first` is not a parameter of this bucket")
+        sh_param, sh_k = None, None
+        if sh_rest is not None:
+            sh_param, deg = sh_rest
+            if id(sh_param) not in {id(p) for p in self.params} or sh_param.dim() != 3:
+                raise ValueError("allreduce_phased: sh_rest must name the (P, 15, 3) f_rest parameter of this bucket")
+            sh_k = min((int(deg) + 1) ** 2 - 1, sh_param.shape[1])
+            if sh_k >= sh_param.shape[1]:
+                sh_param = None                                     # full degree: an ordinary slice
+        runs_a, runs_b, off = [], [], 0
+        for p in self.params:                                       # maximal contiguous runs of the flat buffer per phase
+            n = p.numel()
+            if sh_param is not None and p is sh_param:
+                off += n
+                continue
+            dst = runs_a if id(p) in first_ids else runs_b
+            if dst and dst[-1][1] == off:
+                dst[-1][1] = off + n
+            else:
+                dst.append([off, off + n])
+            off += n
+        cuda = self.flat.is_cuda
+        if cuda:
+            side = getattr(self, "_side", None)
+            if side is None:
+                self._side = side = torch.cuda.Stream(device=self.flat.device)
+            side.wait_stream(torch.cuda.current_stream(self.flat.device))      # the gradients are final in current-stream order
+            ctx = torch.cuda.stream(side)
+        else:
+            import contextlib
+            side, ctx = None, contextlib.nullcontext()
+        world = dist.get_world_size()
+        with ctx:
+            for a, b in runs_a:
+                self._exchange_run(self.flat[a:b])
+                if average:
+                    self.flat[a:b].div_(world)
+            if cuda:
+                ex._ev_first = torch.cuda.Event()
+                ex._ev_first.record(side)
+            for a, b in runs_b:
+                self._exchange_run(self.flat[a:b])
+                if average:
+                    self.flat[a:b].div_(world)
+            if sh_param is not None and sh_k > 0:
+                view = self._views[[id(p) for p in self.params].index(id(sh_param))]
+                packed = view[:, :sh_k, :].contiguous()
+                self._exchange_run(packed.view(-1))
+                if average:
+                    packed.div_(world)
+                view[:, :sh_k, :].copy_(packed)
+                ex._keep = packed                                   # alive until the side stream is done with it
+            if cuda:
+                ex._ev_rest = torch.cuda.Event()
+                ex._ev_rest.record(side)
+        ex.bytes_first = sum(b - a for a, b in runs_a) * self.flat.element_size()
+        ex.bytes_rest = (sum(b - a for a, b in runs_b) + (0 if sh_param is None else sh_param.shape[0] * sh_k * sh_param.shape[2])) * self.flat.element_size()
+        return ex
+
+
+class PhasedExchange:
+    """Handle of FlatGradBucket.allreduce_phased(): ``wait_first()`` before the optimizer step of the `first` parameters,
+    ``wait_rest()`` before anything reads the other gradients (their optimizer step, i.e. before the next render()).  On a GPU
+    both make the CURRENT stream wait for the side stream's event; on the CPU the exchange has already happened."""
+
+    def __init__(self, bucket: "FlatGradBucket", average: bool):
+        self.bucket, self.average = bucket, average
+        self._ev_first = self._ev_rest = None
+        self._keep = None
+        self.bytes_first = self.bytes_rest = 0
+
+    def wait_first(self):
+        if self._ev_first is not None:
+            torch.cuda.current_stream(self.bucket.flat.device).wait_event(self._ev_first)
+            self._ev_first = None
+
+    def wait_rest(self):
+        self.wait_first()
+        if self._ev_rest is not None:
+            torch.cuda.current_stream(self.bucket.flat.device).wait_event(self._ev_rest)
+            self._ev_rest = None
+        self._keep = None
 
 
 def allreduce_densify_stats(xyz_gradient_accum, denom, max_radii2D):

@@ -23,8 +23,11 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     @torch.no_grad()
-    def step(self, closure=None, guard="auto"):
-        """guard="auto": under the rasterizer's sync-free policy the step is issued behind a device-side guard on the most
+    def step(self, closure=None, guard="auto", only=None):
+        """only: restrict this call to the given parameters (by identity) -- the two halves of a phased gradient exchange
+        (trase_amd.dp.FlatGradBucket.allreduce_phased) step ``only=first`` as soon as phase A has landed and the rest before the
+        next render(); every parameter keeps its own moments and step counter, so two partial steps equal one whole step.
+        guard="auto": under the rasterizer's sync-free policy the step is issued behind a device-side guard on the most
         recent forward's overflow flag (``trase_amd.rasterizer.current_guard``): if that forward overflowed its pair
         buffer, parameters and moments stay bit-identical and the step counters are rolled back when the overflow is
         reported.  guard=None: unconditional."""
@@ -39,9 +42,10 @@ class FusedAdam(torch.optim.Optimizer):
         # one launch per (betas, eps, device) combination: the reference uses a single one
         batches = {}
         stepped = []                             # (group index, parameter index) of what this step touches
+        only_ids = None if only is None else {id(p) for p in only}
         for gi, group in enumerate(self.param_groups):
             for pi, p in enumerate(group["params"]):
-                if p.grad is None:
+                if p.grad is None or (only_ids is not None and id(p) not in only_ids):
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam: parameters must be contiguous float32 CUDA tensors (there is no CPU path)")
