@@ -144,7 +144,7 @@ def test_binning_count_and_emit_agree_at_s3_size(monkeypatch):
 
 
 def test_mfma_backward_matches_fp32_valu_backward_full_size(monkeypatch):
-    """The default F = 32 backward runs the channel contractions as bf16-split MFMA GEMMs (render_bwd_mf.hip, three
+    """The default F = 32 backward runs the channel contractions as bf16-split MFMA GEMMs (render_bwd_hw.hip, three
     products per term).  At the headline size (300k Gaussians, 1080p) every gradient must agree with the packed-FP32
     formulation of the same algorithm (render_bwd_gs.hip, `variant` bit 0x40) to 5e-5 of the gradient's scale -- the
     split is exact to ~2^-17 per operand -- and stay bit-reproducible."""

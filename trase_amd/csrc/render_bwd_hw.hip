@@ -1,9 +1,10 @@
 // render_bwd_hw.hip -- backward of the compositing stage, half-wave formulation (default for F = 32).
 //
-// Same mathematics as render_bwd_mf.hip (lane = Gaussian, DPP scans along the list, both channel contractions as
-// bf16-split MFMA GEMMs, one gradient row per (sub-tile, Gaussian) pair, no atomics) with a different shape:
+// The mathematics of render_bwd_gs.hip (lane = Gaussian, DPP scans along the list, one gradient row per (sub-tile, Gaussian)
+// pair, no atomics) with both channel contractions as bf16-split MFMA GEMMs, in this shape (the 64-entry-chunk MFMA kernel of
+// round 1, render_bwd_mf.hip, was removed in round 4):
 //
-//   * a chunk is 32 list entries, not 64: lane l = (g = l & 31, h = l >> 5).  Both lane halves hold the SAME 32
+//   * a chunk is 32 list entries: lane l = (g = l & 31, h = l >> 5).  Both lane halves hold the SAME 32
 //     Gaussians; half h visits the pixels of columns 4h..4h+3 of the 8x8 sub-tile.  One instruction still handles 64
 //     (pixel, Gaussian) pairs, but
 //       - a scan along the list is 5 DPP steps (row_shr 1,2,4,8 + row_bcast:15) instead of 6,
