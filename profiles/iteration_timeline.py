@@ -18,7 +18,7 @@ def main():
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if "mlp_pack_kernel" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "mlp_pack_kernel" in r[0]]          # first launch of an iteration (either state)
     if len(marks) < 3:
         print("not enough iterations in the trace", cols); return
     # iteration_breakdown.py runs 8 sizing + 4 warm-up + 16 timed + 8 event-profiled iterations: take one from the middle of the
@@ -41,7 +41,7 @@ def main():
     tail_gap = max(0.0, (t_next - prev_end) / 1e3)
     span = (t_next - it[0][1]) / 1e3
     with open(out, "w") as f:
-        f.write("# One GAUSSIAN-state iteration, kernel by kernel (rocprofv3 --kernel-trace of profiles/iteration_breakdown.py)\n\n")
+        f.write("# One training iteration, kernel by kernel (rocprofv3 --kernel-trace of profiles/iteration_breakdown.py)\n\n")
         f.write(f"span (first dispatch -> first dispatch of the next iteration) {span:.1f} us; {len(it)} dispatches; library kernels "
                 f"{t_lib:.1f} us; torch kernels {t_other:.1f} us ({sum(1 for r in it if not lib(r[0]))} dispatches); idle gaps between "
                 f"dispatches {gaps:.1f} us + {tail_gap:.1f} us before the next iteration\n\n| kernel | whose | gap before us | duration us |\n|---|---|---:|---:|\n")

@@ -10,7 +10,7 @@ R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_$TAG
 cd /tmp
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-iteration-window"
+CMD="${PMC_CMD:-python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-iteration-window}"     # PMC_CMD: another workload (e.g. profiles/bench_mlp.py)
 declare -A G
 G[sq]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"
 G[sq2]="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
