@@ -22,11 +22,18 @@ __device__ __forceinline__ float tile_load(const float* __restrict__ p, int H, i
   return (x >= 0 && x < W && y >= 0 && y < H) ? p[(size_t)y * W + x] : 0.f;    // conv2d zero padding
 }
 
+// LDS traffic is what bounds both kernels (every tap of the separable window is an LDS read: 127 per pixel in the forward as one
+// output per loop trip).  Round 5: a thread owns FOUR consecutive outputs along the filtered direction and slides the window over
+// the 14 inputs they share -- 28 + 70 reads per four pixels instead of 88 + 220 -- with every output's eleven fused multiply-adds
+// in the same order as before (k ascending), so the maps are bit-identical.  Pitch 40 of the intermediate rows: the two row groups
+// of a wave (4 rows apart) land 32 banks apart.
+constexpr int HP = 40;
+
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
                                                        LossWin win, float* __restrict__ dmaps /* [3][C][H][W] */,
                                                        float* __restrict__ partial /* [blocks][2] */) {
   __shared__ float sx[LH][LH + 1], sy[LH][LH + 1];
-  __shared__ float hb[5][LH][LT + 1];
+  __shared__ float hb[5][LH][HP];
   __shared__ float red[2][4];
   const int c = blockIdx.z;
   const size_t plane = (size_t)H * W;
@@ -52,41 +59,63 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LH * LT; i += 256) {       // horizontal pass: 42 rows x 32 columns
-    const int r = i / LT, q = i % LT;
-    float a = 0.f, b = 0.f, p = 0.f, qq = 0.f, rr = 0.f;
+  for (int i = threadIdx.x; i < LH * (LT / 4); i += 256) {   // horizontal pass: 42 rows x 8 groups of four columns
+    const int r = i >> 3, q0 = (i & 7) * 4;
+    float xs[LW + 3], ys[LW + 3];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k], x = sx[r][q + k], y = sy[r][q + k];
-      a = fmaf(w, x, a); b = fmaf(w, y, b); p = fmaf(w, x * x, p); qq = fmaf(w, y * y, qq); rr = fmaf(w, x * y, rr);
+    for (int t = 0; t < LW + 3; ++t) { xs[t] = sx[r][q0 + t]; ys[t] = sy[r][q0 + t]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f, b = 0.f, p = 0.f, qq = 0.f, rr = 0.f;
+#pragma unroll
+      for (int k = 0; k < LW; ++k) {
+        const float w = win.g[k], x = xs[j + k], y = ys[j + k];
+        a = fmaf(w, x, a); b = fmaf(w, y, b); p = fmaf(w, x * x, p); qq = fmaf(w, y * y, qq); rr = fmaf(w, x * y, rr);
+      }
+      hb[0][r][q0 + j] = a; hb[1][r][q0 + j] = b; hb[2][r][q0 + j] = p; hb[3][r][q0 + j] = qq; hb[4][r][q0 + j] = rr;
     }
-    hb[0][r][q] = a; hb[1][r][q] = b; hb[2][r][q] = p; hb[3][r][q] = qq; hb[4][r][q] = rr;
   }
   __syncthreads();
   float s_l1 = 0.f, s_ss = 0.f;
   const size_t cp = (size_t)gridDim.z * plane;
-  for (int i = threadIdx.x; i < LT * LT; i += 256) {        // vertical pass + SSIM
-    const int r = i / LT, q = i % LT;
-    const int y = y0 + r, x = x0 + q;
-    if (y >= H || x >= W) continue;
-    float a = 0.f, b = 0.f, p = 0.f, qq = 0.f, rr = 0.f;
+  {                                                           // vertical pass + SSIM: column q, rows r0 .. r0 + 3
+    const int q = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
+    float acc[4][5];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      a = fmaf(w, hb[0][r + k][q], a); b = fmaf(w, hb[1][r + k][q], b); p = fmaf(w, hb[2][r + k][q], p);
-      qq = fmaf(w, hb[3][r + k][q], qq); rr = fmaf(w, hb[4][r + k][q], rr);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 5; ++m) acc[j][m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < LW + 3; ++t) {
+      float v[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) v[m] = hb[m][r0 + t][q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = t - j;
+        if (k >= 0 && k < LW) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) acc[j][m] = fmaf(win.g[k], v[m], acc[j][m]);
+        }
+      }
     }
-    constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float A1 = 2.f * a * b + C1, A2 = 2.f * (rr - a * b) + C2;
-    const float B1 = a * a + b * b + C1, B2 = (p - a * a) + (qq - b * b) + C2;
-    const float iB1 = 1.f / B1, iB2 = 1.f / B2;
-    const float S = A1 * A2 * iB1 * iB2;
-    const size_t o = c * plane + (size_t)y * W + x;
-    dmaps[o] = 2.f * b * (A2 - A1) * iB1 * iB2 - 2.f * a * S * (iB1 - iB2);   // dS/dmu1
-    dmaps[cp + o] = -S * iB2;                                                   // dS/dE[x^2]
-    dmaps[2 * cp + o] = 2.f * A1 * iB1 * iB2;                                   // dS/dE[xy]
-    s_ss += S;
-    s_l1 += fabsf(sx[r + LR][q + LR] - sy[r + LR][q + LR]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + j, y = y0 + r, x = x0 + q;
+      if (y >= H || x >= W) continue;
+      const float a = acc[j][0], b = acc[j][1], p = acc[j][2], qq = acc[j][3], rr = acc[j][4];
+      constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float A1 = 2.f * a * b + C1, A2 = 2.f * (rr - a * b) + C2;
+      const float B1 = a * a + b * b + C1, B2 = (p - a * a) + (qq - b * b) + C2;
+      const float iB1 = 1.f / B1, iB2 = 1.f / B2;
+      const float S = A1 * A2 * iB1 * iB2;
+      const size_t o = c * plane + (size_t)y * W + x;
+      dmaps[o] = 2.f * b * (A2 - A1) * iB1 * iB2 - 2.f * a * S * (iB1 - iB2);   // dS/dmu1
+      dmaps[cp + o] = -S * iB2;                                                   // dS/dE[x^2]
+      dmaps[2 * cp + o] = 2.f * A1 * iB1 * iB2;                                   // dS/dE[xy]
+      s_ss += S;
+      s_l1 += fabsf(sx[r + LR][q + LR] - sy[r + LR][q + LR]);
+    }
   }
   // block reduction in a fixed order
   s_l1 = wave_sum_all(s_l1); s_ss = wave_sum_all(s_ss);
@@ -127,7 +156,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ g2 /* dL/dl1, dL/dssim */, float inv_count,
                                                        float* __restrict__ d_img) {
   __shared__ float sd[3][LH][LH + 1];
-  __shared__ float hb[3][LH][LT + 1];
+  __shared__ float hb[3][LH][HP];
   const int c = blockIdx.z;
   const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -151,33 +180,57 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LH * LT; i += 256) {
-    const int r = i / LT, q = i % LT;
-    float a = 0.f, p = 0.f, rr = 0.f;
+  for (int i = threadIdx.x; i < LH * (LT / 4); i += 256) {   // horizontal pass, four columns per thread (see ssim_fwd_kernel)
+    const int r = i >> 3, q0 = (i & 7) * 4;
+    float v[3][LW + 3];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      a = fmaf(w, sd[0][r][q + k], a); p = fmaf(w, sd[1][r][q + k], p); rr = fmaf(w, sd[2][r][q + k], rr);
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int t = 0; t < LW + 3; ++t) v[m][t] = sd[m][r][q0 + t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f, p = 0.f, rr = 0.f;
+#pragma unroll
+      for (int k = 0; k < LW; ++k) {
+        const float w = win.g[k];
+        a = fmaf(w, v[0][j + k], a); p = fmaf(w, v[1][j + k], p); rr = fmaf(w, v[2][j + k], rr);
+      }
+      hb[0][r][q0 + j] = a; hb[1][r][q0 + j] = p; hb[2][r][q0 + j] = rr;
     }
-    hb[0][r][q] = a; hb[1][r][q] = p; hb[2][r][q] = rr;
   }
   __syncthreads();
   const float wl = g2[0] * inv_count, ws = g2[1] * inv_count;
-  for (int i = threadIdx.x; i < LT * LT; i += 256) {
-    const int r = i / LT, q = i % LT;
-    const int y = y0 + r, x = x0 + q;
-    if (y >= H || x >= W) continue;
-    float a = 0.f, p = 0.f, rr = 0.f;
+  {
+    const int q = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
+    float acc[4][3];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      a = fmaf(w, hb[0][r + k][q], a); p = fmaf(w, hb[1][r + k][q], p); rr = fmaf(w, hb[2][r + k][q], rr);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) acc[j][m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < LW + 3; ++t) {
+      float v[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) v[m] = hb[m][r0 + t][q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = t - j;
+        if (k >= 0 && k < LW) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) acc[j][m] = fmaf(win.g[k], v[m], acc[j][m]);
+        }
+      }
     }
-    const size_t o = c * plane + (size_t)y * W + x;
-    const float xv = img[o], yv = gt[o];
-    const float d = xv - yv;
-    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-    d_img[o] = ws * (a + 2.f * xv * p + yv * rr) + wl * sgn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + r0 + j, x = x0 + q;
+      if (y >= H || x >= W) continue;
+      const size_t o = c * plane + (size_t)y * W + x;
+      const float xv = img[o], yv = gt[o];
+      const float d = xv - yv;
+      const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+      d_img[o] = ws * (acc[j][0] + 2.f * xv * acc[j][1] + yv * acc[j][2]) + wl * sgn;
+    }
   }
 }
 
