@@ -22,11 +22,11 @@ __device__ __forceinline__ float tile_load(const float* __restrict__ p, int H, i
   return (x >= 0 && x < W && y >= 0 && y < H) ? p[(size_t)y * W + x] : 0.f;    // conv2d zero padding
 }
 
-// LDS traffic is what bounds both kernels (every tap of the separable window is an LDS read: 127 per pixel in the forward as one
-// output per loop trip).  Round 5: a thread owns FOUR consecutive outputs along the filtered direction and slides the window over
-// the 14 inputs they share -- 28 + 70 reads per four pixels instead of 88 + 220 -- with every output's eleven fused multiply-adds
-// in the same order as before (k ascending), so the maps are bit-identical.  Pitch 40 of the intermediate rows: the two row groups
-// of a wave (4 rows apart) land 32 banks apart.
+// Round 5: a thread owns FOUR consecutive outputs along the filtered direction and slides the window over the 14 inputs they
+// share -- 28 + 70 LDS reads per four pixels instead of 88 + 220 -- with every output's eleven fused multiply-adds in the same
+// order as before (k ascending).  Measured (profiles/r5_ab_experiments.txt): forward 0.075 -> 0.072 ms, backward unchanged at
+// 0.062 -- the tap reads were NOT what bounds these kernels (the halo loads and their bounds checks are next).  Pitch 40 of the
+// intermediate rows: the two row groups of a wave (4 rows apart) land 32 banks apart.
 constexpr int HP = 40;
 
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
