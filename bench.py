@@ -481,6 +481,48 @@ def main():
                     "all_kernels": round(sum(per_scope.values()), 2)}
         R.profile_enable(0)
 
+    # ---- extra key: two views per launch sequence (trase_amd.renderer.render_views: ONE depth sort for both views) ---------------
+    # not the headline (the reference renders one view per iteration, train.py:180): what a loop that accumulates two views per
+    # optimizer step, or an evaluation sweep, gets; same views, same cotangents, forward + backward of both
+    batched = None
+    if world == 1 and not tiles_mode and not args.unfused and args.policy == "free" and bucket is None and not args.forward_only:
+        try:
+            from trase_amd.renderer import render_views
+
+            def step2(i):
+                for p_ in params:
+                    p_.grad = None
+                outs = render_views([cams_dev[(2 * i) % n_views], cams_dev[(2 * i + 1) % n_views]], pc, pipe, bg, 0.0, 0.0, 0.0)
+                for o_ in outs:
+                    torch.autograd.backward([o_["render"], o_["render_gaussian_features"]], [g_img, g_feat])
+            def step1x2(i):            # the same two views, gradients accumulated over both, through two render() calls: the
+                for p_ in params:      # comparison of the same phase of the run
+                    p_.grad = None
+                for j_ in (2 * i, 2 * i + 1):
+                    o_ = render(cams_dev[j_ % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
+                    torch.autograd.backward([o_["render"], o_["render_gaussian_features"]], [g_img, g_feat])
+
+            def timed_pairs(fn, n):
+                for i in range(2):
+                    fn(i)
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for i in range(n):
+                    fn(i)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / (2 * n) * 1e3
+            n2 = max(args.steps // 2, 4)
+            ser, par = [], []
+            for _ in range(2):           # alternating: clocks and allocator state drift over a run
+                ser.append(timed_pairs(step1x2, n2))
+                par.append(timed_pairs(step2, n2))
+            batched = {"views_per_s": round(1e3 / min(par), 3), "ms_per_view": round(min(par), 4), "pairs_timed": n2,
+                       "serial_ms_per_view_same_phase": round(min(ser), 4), "all_ms_per_view": {"serial": [round(x, 4) for x in ser], "pair": [round(x, 4) for x in par]}}
+            for p_ in params:
+                p_.grad = None
+        except Exception as e:
+            batched = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- secondary window: whole training iterations, iter_start -> iter_end of train.py:157-303 -------
     iteration_ms = None
     if world == 1 and not tiles_mode and not args.no_iteration_window and not args.unfused and (N, W, H, F) == (300_000, 1920, 1080, 32):
@@ -576,6 +618,8 @@ def main():
             "kernels_ms_per_view": breakdown,
             "launches_per_view": launches,
             "iteration_ms": iteration_ms,
+            "batched_2_views_per_s": (None if batched is None else batched.get("views_per_s")),
+            "batched_2_views": batched,
         }
         # the forward compositing kernel beside the dominant one, and the VALU-issue fraction of the two together: both kernels
         # sit at ~0.65-0.70 of the VALU issue rate at their register-limited residency, i.e. the roofline that binds them is NOT

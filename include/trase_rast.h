@@ -240,6 +240,18 @@ int trase_rast_backward_raw(const TraseRastSettings* s, const TraseRastRawInputs
  * sync-free policy): one boundary crossing per direction. */
 int trase_rast_forward_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                            const TraseRastWorkspace* ws, trase_stream_t stream);
+/* Two views of the SAME Gaussians in one launch sequence (round 5; no counterpart in the reference, whose loop renders one view
+ * per iteration, train.py:180).  Identical results to two trase_rast_forward_raw calls -- each view keeps its own settings,
+ * per-view deformation (d_*), outputs and workspaces, and its backward is the ordinary trase_rast_backward_raw on those -- but the
+ * two depth sorts, the latency-bound part of a view (twelve launches over 1.2 MB of keys at 300k Gaussians), are ONE sort of 2 P
+ * keys with the view index in the sign bit of the float32 depth key.  `pair_ws`: scratch of trase_rast_pair_sizes(P) bytes, free
+ * again when the call's work has run.  Whole-image views only (no tile-row strips); the sync-free capacity policy (both
+ * workspaces sized by the caller beforehand). */
+int trase_rast_pair_sizes(int32_t P, size_t* bytes);
+int trase_rast_forward_raw_pair(const TraseRastSettings* s0, const TraseRastRawInputs* raw0, const TraseRastOutputs* out0,
+                                const TraseRastWorkspace* ws0, const TraseRastSettings* s1, const TraseRastRawInputs* raw1,
+                                const TraseRastOutputs* out1, const TraseRastWorkspace* ws1, void* pair_ws, size_t pair_bytes,
+                                trase_stream_t stream);
 
 /* Launch-graph replay (hipGraph) for small workloads, where the ~45 kernel launches of a direction cost more host time
  * than the kernels run (BASELINE configs 1 and 2).  With mode != 0, trase_rast_forward / _forward_raw / _backward /

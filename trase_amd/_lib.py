@@ -123,6 +123,10 @@ SYMBOLS = [
                                             C.POINTER(RastWorkspace), C.c_void_p]),
     ("trase_rast_forward_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
                                          C.POINTER(RastWorkspace), C.c_void_p]),
+    ("trase_rast_pair_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    ("trase_rast_forward_raw_pair", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),
+                                              C.POINTER(RastWorkspace), C.POINTER(RastSettings), C.POINTER(RastRawInputs),
+                                              C.POINTER(RastOutputs), C.POINTER(RastWorkspace), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("trase_rast_graph_mode", C.c_int, [C.c_int]),
     ("trase_rast_graph_stats", C.c_int, [C.POINTER(C.c_int64 * 4)]),
     ("trase_rast_render_raw", C.c_int, [C.POINTER(RastSettings), C.POINTER(RastRawInputs), C.POINTER(RastOutputs),

@@ -520,6 +520,95 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   return depth_order(c, s, g, t, in.P, out->radii, list_pack_bits(s, in.P));
 }
 
+// ---- two views per launch sequence (reduced to what is latency-bound) ---------------------------------
+// The depth sort of one view is twelve launches of ~5 us over 1.2 MB of keys: the chip idles between them.  Two views' keys in ONE
+// sort cost the same twelve launches: a live Gaussian's key is a positive float (z > 0.2), so its sign bit is free to carry the view
+// index -- view 0's keys sort in front of view 1's, each in its own depth order, ties by ascending id as before.  Everything after
+// the sort (scan, emit, sub-tile sort, compositing) and the whole backward run per view, unchanged, on the per-view workspaces; the
+// forward results are bit-identical to two single-view calls.
+static size_t pair_ws_bytes(int P) {
+  const size_t n = 2 * (size_t)(P > 0 ? P : 1);
+  return align_up(sizeof(uint32_t) * n) * 4 + sort_bytes_common(n) + align_up(sizeof(uint32_t) * 4);
+}
+int trase_rast_pair_sizes(int32_t P, size_t* bytes) {
+  if (!bytes || P < 0) { set_error("trase_rast_pair_sizes: bad arguments"); return TRASE_ERR_INVALID; }
+  *bytes = pair_ws_bytes(P);
+  return TRASE_OK;
+}
+
+static int forward_raw_pair_impl(const TraseRastSettings* const s[2], const TraseRastRawInputs* const raw[2], const TraseRastOutputs* const out[2],
+                                 const TraseRastWorkspace* const ws[2], void* pair_ws, hipStream_t stream) {
+  const int P = raw[0]->P;
+  TRASE_CHECK(hipSetDevice(s[0]->device));
+  char* cp = (char*)pair_ws;
+  const size_t n = 2 * (size_t)P;
+  SortBufs cs;
+  for (int i = 0; i < 2; ++i) { cs.keys[i] = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * n); }
+  for (int i = 0; i < 2; ++i) { cs.vals[i] = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * n); }
+  cs.hist = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n));
+  cs.digit_total = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * 256 * 8);
+  cs.nb_max = rs_blocks(n);
+  uint32_t* n_word = (uint32_t*)cp;
+  launch_fill_u32(n_word, (uint32_t)n, stream);
+  GeomBuf g[2];
+  PreBuf t[2];
+  for (int v = 0; v < 2; ++v) {
+    LaunchCtx c{stream, s[v]->debug, s[v]->variant};
+    g[v] = carve_geom(ws[v]->geom, P);
+    t[v] = carve_pre(ws[v]->pre, P);
+    const int rc = launch_preprocess_fwd_raw(c, *s[v], *raw[v], out[v]->radii, g[v], cs.keys[0] + (size_t)v * P,
+                                             v ? 0x80000000u : 0u, v ? 0xffffffffu : 0x7fffffffu);
+    if (rc) return rc;
+  }
+  LaunchCtx c0{stream, s[0]->debug, s[0]->variant};
+  int idx = 0;
+  int rc = radix_sort_pairs(c0, cs, n_word, (uint32_t)n, 0, 32, true, &idx, 8, 0);      // ids generated on the fly: 0 .. 2 P - 1
+  if (rc) return rc;
+  if (idx != 0) { set_error("internal: pair depth sort ended in buffer %d", idx); return TRASE_ERR_INVALID; }
+  launch_split_pair_ids(c0, cs.vals[0], P, t[0].sort.vals[0], t[1].sort.vals[0]);
+  for (int v = 0; v < 2; ++v) {
+    LaunchCtx c{stream, s[v]->debug, s[v]->variant};
+    rc = launch_scan_tiles(c, g[v], t[v].sort.vals[0], P, t[v], 0xffffffffu, out[v]->radii, (s[v]->image_width + TILE - 1) / TILE,
+                           (s[v]->image_height + TILE - 1) / TILE, list_pack_bits(s[v], P));
+    if (rc) return rc;
+    rc = trase_rast_render_raw(s[v], raw[v], out[v], ws[v], (trase_stream_t)stream);
+    if (rc) return rc;
+  }
+  return TRASE_OK;
+}
+
+int trase_rast_forward_raw_pair(const TraseRastSettings* s0, const TraseRastRawInputs* raw0, const TraseRastOutputs* out0,
+                                const TraseRastWorkspace* ws0, const TraseRastSettings* s1, const TraseRastRawInputs* raw1,
+                                const TraseRastOutputs* out1, const TraseRastWorkspace* ws1, void* pair_ws, size_t pair_bytes,
+                                trase_stream_t stream) {
+  if (!s0 || !raw0 || !out0 || !ws0 || !s1 || !raw1 || !out1 || !ws1) { set_error("null argument"); return TRASE_ERR_INVALID; }
+  const TraseRastSettings* s[2] = {s0, s1};
+  const TraseRastRawInputs* raw[2] = {raw0, raw1};
+  const TraseRastOutputs* out[2] = {out0, out1};
+  const TraseRastWorkspace* ws[2] = {ws0, ws1};
+  for (int v = 0; v < 2; ++v) {
+    int rc = validate_raw(s[v], raw[v]);
+    if (rc) return rc;
+    if (raw[v]->P > 0 && !out[v]->radii) { set_error("radii output required"); return TRASE_ERR_INVALID; }
+    const TraseRastInputs in = raw_as_inputs(raw[v]);
+    rc = check_ws(&in, s[v], ws[v], WS_GEOM | WS_PRE);
+    if (rc) return rc;
+    if (strip_mode(s[v])) { set_error("trase_rast_forward_raw_pair: tile-row strips are rendered one view at a time"); return TRASE_ERR_UNSUPPORTED; }
+  }
+  if (raw0->P != raw1->P || s0->device != s1->device) { set_error("trase_rast_forward_raw_pair: both views render the same P Gaussians on one device"); return TRASE_ERR_INVALID; }
+  if (DEPTH_KEY_BITS != 32) { set_error("trase_rast_forward_raw_pair: needs the float32 depth keys (sign bit = view)"); return TRASE_ERR_UNSUPPORTED; }
+  if (raw0->P == 0) {      // nothing to sort: the single-view path handles the empty scene
+    int rc = trase_rast_forward_raw(s0, raw0, out0, ws0, stream);
+    return rc ? rc : trase_rast_forward_raw(s1, raw1, out1, ws1, stream);
+  }
+  if (!pair_ws || pair_bytes < pair_ws_bytes(raw0->P)) { set_error("trase_rast_forward_raw_pair: pair workspace too small"); return TRASE_ERR_WORKSPACE; }
+  struct { const void* p; size_t b; } extra = {pair_ws, pair_bytes};
+  return run_maybe_graphed(5, {{s0, sizeof(*s0)}, {raw0, sizeof(*raw0)}, {out0, sizeof(*out0)}, {ws0, sizeof(*ws0)}, {s1, sizeof(*s1)},
+                               {raw1, sizeof(*raw1)}, {out1, sizeof(*out1)}, {ws1, sizeof(*ws1)}, {&extra, sizeof(extra)}},
+                           s0->debug | s1->debug, s0->device, (hipStream_t)stream, raw0->P,
+                           [&](hipStream_t st) { return forward_raw_pair_impl(s, raw, out, ws, pair_ws, st); });
+}
+
 int trase_rast_render_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,
                           const TraseRastWorkspace* ws, trase_stream_t stream) {
   int rc = validate_raw(s, raw);

@@ -285,6 +285,27 @@ int launch_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
   return TRASE_OK;
 }
 
+// ---- two views in one depth sort (trase_rast_forward_raw_pair) -----------------------------------------------------------
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+int launch_fill_u32(uint32_t* p, uint32_t v, hipStream_t stream) {
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, stream, p, v);
+  return TRASE_OK;
+}
+// the sorted (view, depth) order of 2 P keys back into the two views' own id lists: entries [0, P) are view 0's Gaussians in
+// depth order, entries [P, 2 P) view 1's with P added to their ids
+__global__ __launch_bounds__(256) void split_pair_ids_kernel(const uint32_t* __restrict__ sorted, int P, uint32_t* __restrict__ ids0,
+                                                             uint32_t* __restrict__ ids1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * P) return;
+  const uint32_t v = sorted[i];
+  if (i < P) ids0[i] = v; else ids1[i - P] = v - (uint32_t)P;
+}
+int launch_split_pair_ids(const LaunchCtx& c, const uint32_t* sorted, int P, uint32_t* ids0, uint32_t* ids1) {
+  ProfScope ps("split_pair_ids", c.stream);
+  hipLaunchKernelGGL(split_pair_ids_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, c.stream, sorted, P, ids0, ids1);
+  return TRASE_OK;
+}
+
 int radix_passes(int bit_lo, int bit_hi, int digit_bits) { return (bit_hi - bit_lo + digit_bits - 1) / digit_bits; }
 
 // digit_bits 8 or 11 (SortBufs::hist / digit_total must be sized for it: (1 << digit_bits) * nb_max and (1 << digit_bits) * passes);

@@ -379,8 +379,7 @@ int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const 
 int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
                           const GeomBuf& g, const float* acc, const TraseRastGrads& gr);
 
-int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
-                              const GeomBuf& g, uint32_t* depth_keys);
+
 // Gaussians [p_begin, p_end) only (p_begin a multiple of 64; p_end = P or a multiple of 64)
 int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw,
                               const int32_t* radii, const GeomBuf& g, const float* acc, const TraseRastRawGrads& gr,
@@ -394,6 +393,8 @@ int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_pt
 // zero-fill as a KERNEL: a hipMemsetAsync captured into a launch graph did not clear its buffer from the second replay on
 // (round 5: gradient rows of stale pair flags -- NaN under TRASE_POISON -- on every graph hit after the first; ROCm 7.0.2)
 int launch_zero_bytes(void* p, size_t bytes, hipStream_t stream);
+int launch_fill_u32(uint32_t* p, uint32_t v, hipStream_t stream);
+int launch_split_pair_ids(const LaunchCtx& c, const uint32_t* sorted, int P, uint32_t* ids0, uint32_t* ids1);
 int radix_passes(int bit_lo, int bit_hi, int digit_bits = 8);
 // The depth sort.  Default: the float32 depth bits in four 8-bit passes (12 launches).  -DTRASE_DEPTH_DIGITS=9 (measured, see
 // profiles/r5_ab_experiments.txt): an order-preserving 27-bit key -- float bits above those of the 0.2 near-cull plane (z > 0.2
@@ -411,6 +412,10 @@ __host__ __device__ inline uint32_t depth_sort_key(float z, bool live) {
   const uint32_t b = bits - 0x3e4ccccdu;
   return live ? (b < 0x07fffffeu ? b : 0x07fffffeu) : 0x07ffffffu;
 }
+// key_or / key_dead: see RawFwdArgs (the two-view forward puts the view index into the key's sign bit)
+int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
+                              const GeomBuf& g, uint32_t* depth_keys, uint32_t key_or = 0u,
+                              uint32_t key_dead = depth_sort_key(0.f, false));
 
 // pack_bits: 0 = never pack; jb = pack list values as (id << jb | j) when every Gaussian has fewer than 2^jb pairs
 // strip mode: (depth key, id) of the Gaussians with a pair, ascending ids, then the ids without one; hdr[HDR_WORDS - 1] = live count

@@ -165,13 +165,23 @@ class _RenderRaw(torch.autograd.Function):
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
         ws.tmp, ws.tmp_bytes = _lib.ptr(tmp), tmp.numel()
         ws.capacity = capacity
-        if one_call:
+        if _PAIR is not None:
+            # render_views(): the launch sequence of this view is issued together with the next view's (one depth sort for both);
+            # the record keeps every buffer the argument structs point at alive until then
+            if not one_call or s.tile_row_begin or s.tile_row_end:
+                raise RuntimeError("trase_amd.renderer.render_views needs the sync-free capacity policy with a known capacity "
+                                   "(rasterizer.set_sync(False, capacity=...)) and whole-image views")
+            _PAIR.append(dict(s=s, raw=raw, out=out, ws=ws, P=P, device=device, stream=stream, after=(geom, capacity, binb, (H, W)),
+                              keep=(keep, xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat, featn,
+                                    image, feats, depth, radii, geom, pre, img, binb, tmp)))
+        elif one_call:
             _lib.check(lib.trase_rast_forward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                        "trase_rast_forward_raw")
         else:
             _lib.check(lib.trase_rast_render_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                        "trase_rast_render_raw")
-        _after_render(geom, capacity, binb, (H, W))
+        if _PAIR is None:
+            _after_render(geom, capacity, binb, (H, W))
         ctx.raster_settings, ctx.capacity, ctx.dims = raster_settings, capacity, (P, F, H, W)
         ctx.variant, ctx.tile_rows, ctx.feat_bg = s.variant, (s.tile_row_begin, s.tile_row_end), s.feat_bg
         if (s.variant & _r_VARIANT_SPARSE) and (s.tile_row_begin != 0 or s.tile_row_end != 0):
@@ -322,6 +332,59 @@ class _RenderRaw(torch.autograd.Function):
                     t.zero_()
         return (g_xyz if need[0] else None, g_dxyz, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat,
                 g_m2d if need[10] else None, None, None)
+
+
+# ---- two views per launch sequence ---------------------------------------------------------------------------------------
+_PAIR = None        # render_views(): list of deferred forward records
+
+
+def _flush_pair(recs):
+    lib = _lib.load()
+    if len(recs) == 2 and recs[0]["P"] == recs[1]["P"] and recs[0]["device"] == recs[1]["device"] and recs[0]["P"] > 0:
+        a, b = recs
+        nbytes = C.c_size_t()
+        _lib.check(lib.trase_rast_pair_sizes(a["P"], C.byref(nbytes)), "trase_rast_pair_sizes")
+        pair_ws = _bytes(nbytes.value, a["device"])
+        _lib.check(lib.trase_rast_forward_raw_pair(C.byref(a["s"]), C.byref(a["raw"]), C.byref(a["out"]), C.byref(a["ws"]),
+                                                   C.byref(b["s"]), C.byref(b["raw"]), C.byref(b["out"]), C.byref(b["ws"]),
+                                                   _lib.ptr(pair_ws), pair_ws.numel(), a["stream"]), "trase_rast_forward_raw_pair")
+    else:
+        for r in recs:
+            _lib.check(lib.trase_rast_forward_raw(C.byref(r["s"]), C.byref(r["raw"]), C.byref(r["out"]), C.byref(r["ws"]), r["stream"]),
+                       "trase_rast_forward_raw")
+    for r in recs:
+        _after_render(*r["after"])
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color, d_xyz, d_rotation, d_scaling, **kwargs):
+    """``[render(cam, pc, pipe, bg, d_xyz, d_rotation, d_scaling, **kwargs) for cam in viewpoint_cameras]`` with the views taken two
+    at a time through ONE launch sequence (``trase_rast_forward_raw_pair``: the two views' depth sorts -- the latency-bound
+    part of a view -- are one sort).  No counterpart in the reference (train.py:180 renders one view per iteration); a loop
+    that accumulates the losses of two views per optimizer step (or an evaluation sweep) can call this instead of two
+    ``render()``s.  Every entry of the returned list is an ordinary ``render()`` dict with its own autograd history: outputs
+    and gradients are bit-identical to the serial calls (``tests/test_gpu_pair.py``).  ``d_xyz`` / ``d_rotation`` /
+    ``d_scaling``: one value for all views, or a list with one entry per view (each view's deformation at its own time).
+    Needs ``rasterizer.set_sync(False, capacity=...)`` (the workspaces of both views are sized before anything runs); views
+    that cannot take the fused path, and an odd last view, go through ``render()`` as they are."""
+    global _PAIR
+    cams = list(viewpoint_cameras)
+    per = lambda d, i: d[i] if isinstance(d, (list, tuple)) else d
+    outs = []
+    for i in range(0, len(cams), 2):
+        if i + 1 >= len(cams):
+            outs.append(render(cams[i], pc, pipe, bg_color, per(d_xyz, i), per(d_rotation, i), per(d_scaling, i), **kwargs))
+            break
+        if _PAIR is not None:
+            raise RuntimeError("render_views is not re-entrant")
+        _PAIR = []
+        try:
+            pair = [render(cams[j], pc, pipe, bg_color, per(d_xyz, j), per(d_rotation, j), per(d_scaling, j), **kwargs) for j in (i, i + 1)]
+            recs, _PAIR = _PAIR, None
+            _flush_pair(recs)
+        finally:
+            _PAIR = None
+        outs.extend(pair)
+    return outs
 
 
 _ZERO_CACHE: dict = {}
