@@ -17,8 +17,8 @@ bash profiles/run_iter_trace.sh ${T} image > /dev/null 2>&1
 bash profiles/run_iter_trace.sh ${T}f feature > /dev/null 2>&1
 PMC_CMD="python $R/profiles/bench_mlp.py" PMC_TIMEOUT=200 bash profiles/run_pmc.sh ${T}_mlp fetch write sq2 > /dev/null 2>&1
 rm -f gpurun_out/${T}_bench_configs.jsonl
-python bench.py --gaussians 1000 --width 128 --height 128 --feat 0 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
-python bench.py --gaussians 150000 --width 480 --height 270 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
+python bench.py --gaussians 1000 --width 128 --height 128 --feat 0 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
+python bench.py --gaussians 150000 --width 480 --height 270 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
 python bench.py --gaussians 1000000 --width 1352 --height 1014 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
 python bench.py --gaussians 2500000 --width 1280 --height 960 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/${T}_bench_configs.jsonl
 TRASE_SWEEP_COUNT=${SWEEP:-200} TRASE_SWEEP_SEED=50505 TRASE_FAMILY_COUNT=${FAM:-30} TRASE_FAMILY_SEED=5151 timeout 1500 python -m pytest tests/test_gpu_sweep.py -m gpu -q -s -k "random_parity_sweep or camera_and_scene_families" > gpurun_out/${T}_parity_extended.txt 2>&1
