@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=16.0, help="wall-time budget of the CPU preprocess baseline")
     ap.add_argument("--cpu-oracle-budget-s", type=float, default=1.0, help="forward wall-time budget of the oracle sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core (os.cpu_count())")
-    ap.add_argument("--kernel-breakdown", action="store_true", help="extra untimed pass timing every kernel")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="(kept for old command lines: the per-kernel pass always runs)")
     ap.add_argument("--policy", choices=["free", "sync"], default="free",
                     help="capacity policy of the timed steps: free = set_sync(False) with a measured capacity (default, what the "
                          "metric is quoted on); sync = the drop-in default (pair count read back every forward, exact allocation)")
@@ -465,21 +465,21 @@ def main():
     log(f"timed: {ms_per_step:.3f} ms/step, {views_per_s:.1f} views/s")
 
     breakdown, launches = None, None
-    if True:   # (the per-kernel table is part of the line: roofline.forward, backward_frac and launches_per_view are built from it)
-        R.profile_enable(1)
-        nb = min(4, n_views)
-        for i in range(nb):
-            step(i)
-        torch.cuda.synchronize()
-        rep_ = R.profile_report()
-        breakdown = {k: round(v["ms"] * v["n"] / nb, 4) for k, v in rep_.items()}
-        # kernel launches per view of the library's own launch sequences (one profiling scope = one launch, except scan_tiles
-        # = 2); memsets and the torch-side kernels of the wrapper are not counted
-        per_scope = {k: (2 if k == "scan_tiles" else 1) * v["n"] / nb for k, v in rep_.items()}
-        chain = ("radix_hist", "radix_scan", "radix_scatter", "depth_sort", "emit_pairs", "scan_tiles", "tile_ranges")
-        launches = {"binning_chain": round(sum(v for k, v in per_scope.items() if k in chain), 2),
-                    "all_kernels": round(sum(per_scope.values()), 2)}
-        R.profile_enable(0)
+    # the per-kernel table is part of the line: roofline.forward, backward_frac and launches_per_view are built from it
+    R.profile_enable(1)
+    nb = min(4, n_views)
+    for i in range(nb):
+        step(i)
+    torch.cuda.synchronize()
+    rep_ = R.profile_report()
+    breakdown = {k: round(v["ms"] * v["n"] / nb, 4) for k, v in rep_.items()}
+    # kernel launches per view of the library's own launch sequences (one profiling scope = one launch, except scan_tiles
+    # = 2); memsets and the torch-side kernels of the wrapper are not counted
+    per_scope = {k: (2 if k == "scan_tiles" else 1) * v["n"] / nb for k, v in rep_.items()}
+    chain = ("radix_hist", "radix_scan", "radix_scatter", "depth_sort", "emit_pairs", "scan_tiles", "tile_ranges")
+    launches = {"binning_chain": round(sum(v for k, v in per_scope.items() if k in chain), 2),
+                "all_kernels": round(sum(per_scope.values()), 2)}
+    R.profile_enable(0)
 
     # ---- extra key: two views per launch sequence (trase_amd.renderer.render_views: ONE depth sort for both views) ---------------
     # not the headline (the reference renders one view per iteration, train.py:180): what a loop that accumulates two views per
