@@ -102,6 +102,71 @@ def test_overlapped_exchange_through_a_one_rank_rccl_group():
         dist.destroy_process_group()
 
 
+def test_phased_exchange_through_a_one_rank_rccl_group_with_the_mlp_underneath():
+    """VERDICT r4 item 4 on the GPU box: FlatGradBucket.allreduce_phased through a one-rank RCCL group -- phase A (xyz + the
+    deformation network), FusedAdam.step(only=...), the NEXT iteration's MLP training forward issued while phase B (the rest,
+    only the active f_rest rows) is still on the side stream, wait_rest, the second optimizer half.  Summing over one rank
+    must leave every gradient untouched, so parameters and MLP outputs after two iterations must equal, bit for bit, those of
+    the plain loop (one allreduce, one whole optimizer step) -- with RCCL kernels and staging copies running beside
+    mlp_fwd_train_kernel_blk (profiles/r5_two_streams.md is what allows that schedule)."""
+    import torch.distributed as dist
+    from trase_amd.deform import DeformNetworkHIP
+    from trase_amd.dp import FlatGradBucket
+    from trase_amd.optim import FusedAdam
+    from trase_amd.synthetic import SynthDeformNetwork
+    from gaussian_renderer import render
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    results = {}
+    try:
+        for mode in ("plain", "phased"):
+            pc, pipe, cam, _ = _scene(n=30000, seed=5)
+            torch.manual_seed(11)
+            net = SynthDeformNetwork().to(dev)
+            with torch.no_grad():
+                for m in (net.gaussian_warp, net.gaussian_rotation, net.gaussian_scaling):
+                    m.weight.mul_(0.01)
+            hip_net = DeformNetworkHIP(net)
+            gauss = [pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation]
+            mlp = list(net.parameters())
+            bucket = FlatGradBucket(gauss + mlp, exchange="direct")
+            bucket._force = True
+            opt = FusedAdam([{"params": [p], "lr": 1e-3} for p in gauss] + [{"params": mlp, "lr": 1e-3}], lr=0.0, eps=1e-15)
+            first = [pc._xyz] + mlp
+            rest = [p for p in gauss if p is not pc._xyz]
+            N = pc._xyz.shape[0]
+            t = cam.fid.reshape(1, 1).expand(N, -1)
+            g = torch.Generator(device="cpu").manual_seed(3)
+            d = hip_net(pc.get_xyz.detach(), t)
+            for it in range(2):
+                bucket.zero()
+                out = render(cam, pc, pipe, torch.zeros(3, device=dev), *d)
+                gi = torch.randn(out["render"].shape, generator=g).to(dev)
+                out["render"].backward(gi)
+                if mode == "plain":
+                    bucket.allreduce()
+                    opt.step(guard=None)
+                    d = hip_net(pc.get_xyz.detach(), t)
+                else:
+                    ex = bucket.allreduce_phased(first=first, sh_rest=(pc._features_rest, 1))
+                    ex.wait_first()
+                    opt.step(guard=None, only=first)
+                    d = hip_net(pc.get_xyz.detach(), t)            # the next iteration's MLP forward, underneath phase B
+                    ex.wait_rest()
+                    opt.step(guard=None, only=rest)
+                    assert ex.bytes_first == 4 * (N * 3 + sum(p.numel() for p in mlp))
+                    assert ex.bytes_rest == 4 * N * (3 + 9 + 1 + 3 + 4)     # f_dc, 3 active f_rest rows, opacity, scaling, rotation
+            torch.cuda.synchronize()
+            results[mode] = [p.detach().clone() for p in gauss + mlp] + [x.detach().clone() for x in d]
+    finally:
+        dist.destroy_process_group()
+    for i, (a, b) in enumerate(zip(results["plain"], results["phased"])):
+        assert torch.equal(a, b), f"tensor {i}: the phased loop differs from the plain one"
+
+
 @pytest.mark.parametrize("n", [777, 4096 + 13])
 def test_unaligned_parameter_storage_gives_identical_results(n):
     """The wave-cooperative row moves of the per-Gaussian kernels use 16-byte accesses when the base pointers allow it and
