@@ -84,23 +84,6 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(MlpPackArgs a) {
 // column order of cat(PE(x), PE(t)) as built by Embedder.embed (utils/time_utils.py:26-57):
 //   x(3), then per frequency 2^f: sin(x 2^f)(3), cos(x 2^f)(3);  t, then per frequency: sin(t 2^f), cos(t 2^f)
 //   is_blender: the time block is the timenet output instead (30 columns, the same for every row)
-__device__ __forceinline__ float pe_value(int c, float x0, float x1, float x2, float t, const float* __restrict__ temb) {
-  if (c < 3) return c == 0 ? x0 : (c == 1 ? x1 : x2);
-  if (c < 63) {
-    const int q = c - 3, f = q / 6, r = q % 6, d = r % 3;
-    const float v = (d == 0 ? x0 : (d == 1 ? x1 : x2)) * (float)(1 << f);
-    return r < 3 ? __sinf(v) : __cosf(v);
-  }
-  if (temb) return c < EMB_B ? temb[c - 63] : 0.f;
-  if (c == 63) return t;
-  if (c < EMB_T) {
-    const int q = c - 64, f = q >> 1;
-    const float v = t * (float)(1 << f);
-    return (q & 1) ? __cosf(v) : __sinf(v);
-  }
-  return 0.f;
-}
-
 // LDS activation tile of one wave: 32 rows x 256 bf16, 16-byte chunks XOR-swizzled by the row
 __device__ __forceinline__ int act_off(int m, int k) {   // element offset of (row m, column k)
   const int chunk = (k >> 3) ^ (m & 15);
@@ -578,54 +561,6 @@ __global__ __launch_bounds__(256) void mlp_pack_t_kernel(MlpPackTArgs a) {
   }
 }
 
-// transposed image of the bf16 positional encoding, [tile][2][96][16] (columns 84..95 and padding rows zero):
-// the GEMM input of layers 0 and 5
-__global__ __launch_bounds__(256) void mlp_pe_kernel(const float* __restrict__ x, const float* __restrict__ t, int t_stride,
-                                                     const float* __restrict__ temb, int N, __bf16* __restrict__ peT,
-                                                     const int* __restrict__ ro) {
-  // A workgroup owns 128 batch rows (four image tiles): their inputs (x, y, z, t -- gathered through the row order) are read
-  // ONCE into LDS, then every thread produces (half-tile, column) pieces: 16 rows of one column = 32 contiguous image bytes,
-  // from sixteen broadcast LDS reads.  (One thread per piece reading its inputs from memory re-read every row 96 times and,
-  // with a row order, through a dependent index load each time.)
-  __shared__ float4 rows[128];
-  const int row_base = blockIdx.x * 128;
-  if (threadIdx.x < 128) {
-    const int row = row_base + threadIdx.x;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < N) {
-      const size_t gr = ro ? ro[row] : row;
-      v = make_float4(x[3 * gr], x[3 * gr + 1], x[3 * gr + 2], temb ? 0.f : t[gr * (size_t)t_stride]);
-    }
-    rows[threadIdx.x] = v;
-  }
-  __syncthreads();
-  const int tiles = (N + 31) >> 5;
-  for (int piece = threadIdx.x; piece < 8 * EMBP; piece += 256) {      // 8 half-tiles x 96 columns
-    const int hf = piece / EMBP, c = piece % EMBP;
-    const int tile = blockIdx.x * 4 + (hf >> 1);
-    if (tile >= tiles) break;
-    // which input the column depends on: 0..2 = coordinate, 3 = t, -1 = none (padding / timenet columns)
-    int src = -1;
-    if (c < 3) src = c;
-    else if (c < 63) src = ((c - 3) % 6) % 3;
-    else if (!temb && c < EMB_T) src = 3;
-    bf16x8 o[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = hf * 16 + r;
-      float v = 0.f;
-      if (row_base + lr < N) {
-        const float4 q = rows[lr];
-        const float in = src < 0 ? 0.f : (src == 0 ? q.x : (src == 1 ? q.y : (src == 2 ? q.z : q.w)));
-        v = pe_value(c, in, in, in, in, temb);               // the column picks the one argument it uses
-      }
-      o[r >> 3][r & 7] = (__bf16)v;
-    }
-    bf16x8* dst = reinterpret_cast<bf16x8*>(peT + ((size_t)tile * 2 + (hf & 1)) * (EMBP * 16) + (size_t)c * 16);
-    dst[0] = o[0]; dst[1] = o[1];
-  }
-}
-
 // Dead rows.  A Gaussian that the view culled (radii == 0: a quarter of them on the S4 orbit, more with a camera inside the cloud)
 // hands the network an exactly-zero cotangent: its dZ rows are zero in every layer and it adds nothing to any parameter gradient.
 // The backward therefore works on the LIVE 32-row tiles only: mlp_tile_flags / mlp_tile_list compact the ids of the tiles that
@@ -860,12 +795,6 @@ struct WgradJob {
   float* bias_partial; // [G][M] or null
 };
 constexpr int WG_MAX_JOBS = 8;
-#ifndef WG_PE_SA
-#define WG_PE_SA true     // the dZ images of the encoding jobs are read once: non-temporal (0.086 -> 0.069 ms); the encoding image is shared by both jobs
-#endif
-#ifndef WG_HEAD_SB
-#define WG_HEAD_SB false
-#endif
 // distance between the partial planes of consecutive row groups, in floats: NOT the bare M * NK -- the reduction reads the
 // same offset of every plane, and planes a power of two apart put all of those reads on the same memory channels
 #ifndef WG_PLANE_PAD
@@ -874,129 +803,19 @@ constexpr int WG_MAX_JOBS = 8;
 __host__ __device__ constexpr size_t wg_plane(int M, int NK) { return (size_t)M * NK + WG_PLANE_PAD; }
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
-#ifndef WGRAD_NBUF
-#define WGRAD_NBUF 4
-#endif
-// WM x WN waves, each owning MB x NB blocks of 32 x 32; M = WM*MB*32, NK = WN*NB*32
-template <int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(WM* WN * 64) void mlp_wgrad_kernel(WgradJobs jobs, const int* __restrict__ live_list,
-                                                                const int* __restrict__ n_live_ptr, int G) {
-  constexpr int M = WM * MB * 32, NK = WN * NB * 32;
-  const WgradJob job = jobs.j[blockIdx.y];
-  const int g = blockIdx.x;
-  const int tiles = *n_live_ptr;                           // the reduction runs over the LIVE row tiles (see "dead rows")
-  const int t_begin = (int)((long long)tiles * g / G), t_end = (int)((long long)tiles * (g + 1) / G);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  const bool do_bias = job.bias_partial != nullptr && wn == 0;
-  f32x16 acc[MB][NB], accb[MB];
-#pragma unroll
-  for (int a = 0; a < MB; ++a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[a][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  }
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  // fragment (tile, K-step s): 8 consecutive rows 16s + 8h .. of column f; the lanes of one load are 1 KB contiguous
-  const __bf16* pa = job.A + (size_t)(wm * MB * 32 + i) * 16 + 8 * h;
-  const __bf16* pb = job.B + (size_t)(wn * NB * 32 + i) * 16 + 8 * h;
-  // fragment ring: NBUF - 1 K-steps are requested ahead of the one being multiplied.  One wave per SIMD is all the
-  // accumulators leave room for, so the only latency cover is this wave's own queue: with one step ahead a K-step took
-  // ~3000 cycles for 512 cycles of MFMA work.
-  constexpr int NBUF = WGRAD_NBUF;
-  bf16x8 fa[NBUF][MB], fb[NBUF][NB];
-  auto load = [&](int buf, int step) {      // step = (position in the live list) * 2 + s
-    const size_t tile = (size_t)live_list[step >> 1];      // wave-uniform index: a scalar load
-    const size_t ta = tile * (M * 32) + (size_t)(step & 1) * (M * 16);
-    const size_t tb = tile * (NK * 32) + (size_t)(step & 1) * (NK * 16);
-#pragma unroll
-    for (int a = 0; a < MB; ++a) fa[buf][a] = *reinterpret_cast<const bf16x8*>(pa + ta + (size_t)a * 32 * 16);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) fb[buf][b] = *reinterpret_cast<const bf16x8*>(pb + tb + (size_t)b * 32 * 16);
-  };
-  auto mma = [&](int buf) {
-#pragma unroll
-    for (int a = 0; a < MB; ++a)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][a], fb[buf][b], acc[a][b], 0, 0, 0);
-    if (do_bias)
-#pragma unroll
-      for (int a = 0; a < MB; ++a) accb[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][a], ones, accb[a], 0, 0, 0);
-  };
-  const int s_begin = 2 * t_begin, s_end = 2 * t_end;     // always an even number of steps
-  if (s_begin >= s_end) {                                  // (an empty group still writes its zero partials below)
-  } else {
-#pragma unroll
-    for (int k = 0; k < NBUF - 1; ++k) {                   // every buffer of the ring holds something finite
-      const bool real = s_begin + k < s_end;
-      load(k, real ? s_begin + k : s_end - 2 + (k & 1));
-      if (!real) {
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fa[k][a][e] = (__bf16)0.0f;
-      }
-    }
-  }
-  // (s_end - s_begin is even and NBUF is even: the parity of step s + j is that of j, so every fragment address of the
-  // unrolled body is base + tile * stride + a compile-time constant.  The last group may run past the end: those steps
-  // re-read the last tile and multiply a ZERO A fragment -- the MFMAs stay unconditional, which keeps the accumulators
-  // out of control-flow merges: guarded MFMA blocks made the allocator spill.)
-  for (int s = s_begin; s < s_end; s += NBUF) {
-    // keep the waves of the workgroup on the same tiles: two of them read every A fragment and two every B fragment; once
-    // they drift apart the second reader misses L1 and often L2 (measured: 3.2 GB fetched from HBM for 2.15 GB of operands)
-    if (WM * WN > 1 && MB * NB >= 16) __builtin_amdgcn_s_barrier();   // (the narrow jobs lose more at the barrier than they gain)
-#pragma unroll
-    for (int j = 0; j < NBUF; ++j) {
-      const int nx = s + j + NBUF - 1, nb_ = (j + NBUF - 1) % NBUF;
-      const bool real = nx < s_end;
-      load(nb_, real ? nx : s_end - 2 + (nb_ & 1));
-      if (!real) {
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fa[nb_][a][e] = (__bf16)0.0f;
-      }
-      mma(j);
-    }
-  }
-  // D[f_local][k_local]: lane = k_local (+32 for the odd f quads), register r = f_local%4 + 4*(f_local/8)
-  float* out = job.partial + (size_t)g * wg_plane(M, NK);
-#pragma unroll
-  for (int a = 0; a < MB; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = (wm * MB + a) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        out[(size_t)f * NK + (wn * NB + b) * 32 + i] = acc[a][b][r];
-      }
-  if (do_bias && i == 0) {
-#pragma unroll
-    for (int a = 0; a < MB; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        job.bias_partial[(size_t)g * M + (wm * MB + a) * 32 + 8 * (r >> 2) + 4 * h + (r & 3)] = accb[a][r];
-  }
-}
-
 // ---- the hidden-layer weight-gradient GEMM with its operand stream parked in LDS ----------------------------------
-// mlp_wgrad_kernel<2, 2, 4, 4> is bound by the HBM stream of its two images (128 flop per byte against the chip's ~400), and
-// what limits the stream is the bytes it can keep in flight: 480 accumulator + fragment registers leave a ring of three
-// K-steps (48 KB unique per CU, every fragment requested twice -- by the two waves that share it).  Here the fragments go
+// The GEMM is bound by the HBM stream of its two images (128 flop per byte against the chip's ~400), and what limits the stream
+// is the bytes it can keep in flight.  The round-2..4 kernel kept its operand fragments in registers: 480 accumulator + fragment
+// registers left a ring of three K-steps (48 KB unique per CU, every fragment requested twice -- by the two waves that share
+// it), 0.469 ms for the hidden layers (profiles/r5_ab_experiments.txt; removed in round 5).  Here the fragments go
 // global -> LDS directly (global_load_lds_dwordx4: no registers; a fragment load of the transposed image is ONE contiguous
 // kilobyte, and the LDS-DMA writes lane L's 16 bytes at base + 16 L -- exactly the 16 bytes lane L wants back), each fragment
-// is requested ONCE per workgroup (wave w loads fragments 4 w .. 4 w + 3 of the K-step's sixteen), and the ring is WL_NST
-// K-steps deep (16 KB each): 128 KB in flight per CU.  One workgroup barrier per K-step; LDS-DMA completion is counted by hand
-// (hipcc does not see the asm loads): s_waitcnt vmcnt(4 (WL_NST - 2)) = "my four loads of this K-step have landed".
-// STREAM: non-temporal policy -- for images that this launch reads exactly once (the hidden layers' jobs: 0.404 -> 0.354 ms,
-// 6.07 TB/s); the narrow jobs share an operand between jobs (the encoding image) or are short, and lose with it
+// is requested ONCE per workgroup (wave w loads fragments 4 w .. 4 w + 3 of the K-step's sixteen), and the ring is NST
+// K-steps deep (16 KB each): 144 KB in flight per CU.  One workgroup barrier per K-step; LDS-DMA completion is counted by hand
+// (hipcc does not see the asm loads): s_waitcnt vmcnt(4 (NST - 2)) = "my four loads of the next K-step have landed".
+// STREAM: non-temporal policy -- per operand, for an image that the launch reads exactly once: both images of the hidden layers'
+// jobs (0.404 -> 0.354 ms, 6.07 TB/s) and the dZ image of the encoding jobs (0.086 -> 0.069); the encoding image (shared by both
+// encoding jobs) and the short head job lose with it
 template <bool STREAM>
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -1029,7 +848,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_lds_kernel(WgradJobs jobs, cons
   const int wm = wave / WN, wn = wave % WN;
   const bool do_bias = job.bias_partial != nullptr && wn == 0;
   // MB x NB blocks of 32 x 32 (the hidden layers: 16 blocks = all 256 accumulation registers).  The bias sums (db_l = column
-  // sums of dZ_l) do NOT take another MFMA block per row of blocks as in mlp_wgrad_kernel (64 more accumulators: the allocator
+  // sums of dZ_l) do NOT take another MFMA block per row of blocks as in the register-fragment kernel of rounds 2-4 (64 more accumulators: the allocator
   // then rotates ~100 registers between the two register files in every K-step): a lane holds 8 rows of one column per
   // fragment -- four packed bf16 dot products against (1, 1) add them up in fp32; the two row halves meet in the epilogue.
   f32x16 acc[MB][NB];
@@ -1260,8 +1079,7 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   static const int gh_env = [] { const char* e = getenv("TRASE_MLP_GH"); return e ? atoi(e) : 0; }();
   const int gh_max = gh_env > 0 ? gh_env : 36;
   p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128);
-  static const int gd_env = [] { const char* e = getenv("TRASE_MLP_GD"); return e ? atoi(e) : 0; }();
-  p.Gd = (int)(tiles < (size_t)(gd_env > 0 ? gd_env : 128) ? tiles : (gd_env > 0 ? gd_env : 128));
+  p.Gd = p.Gp;
   if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
   p.part_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * wg_plane(MW, MW));
   p.bias_hidden = (float*)c; c += align_up(sizeof(float) * 7 * (size_t)p.Gh * MW);
@@ -1384,13 +1202,6 @@ int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const
     if (t_stride != 0) { set_error("trase_mlp_forward_train: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
     net.temb = t;
   }
-  static const bool pe_kernel = [] { const char* e = getenv("TRASE_MLP_PE_KERNEL"); return e && atoi(e) != 0; }();   // (A/B only)
-  if (pe_kernel) {
-    ProfScope ps("mlp_pe", stream);
-    hipLaunchKernelGGL(mlp_pe_kernel, dim3((unsigned)((N + 127) / 128)), dim3(256), 0, stream, x, t, t_stride, net.temb, N, sv.peT,
-                       (const int*)row_order);
-  }
-  TRASE_POST_LAUNCH("mlp_pe", stream, 0);
   {
     ProfScope ps("mlp_fwd_train", stream);
     const dim3 block(MWAVES * WAVE);
@@ -1479,13 +1290,8 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
       reduce_job(j.partial, j.bias_partial, grads->weight[l], grads->bias[l], MW, MW, kin, l == SKIP ? EMB : 0, MW, MW, bp.Gh);
     }
     ProfScope ps("mlp_wgrad_hidden", stream);
-    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
-    if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 8, 2, 2, 9, true, true>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gh);
-    else
-      hipLaunchKernelGGL((mlp_wgrad_kernel<2, 2, 4, 4>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gh);
+    hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 8, 2, 2, 9, true, true>), dim3(bp.Gh, MD - 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gh);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_hidden", stream, 0);
   {   // encoding inputs: layer 0 and the first 84 columns of the skip layer
@@ -1500,13 +1306,8 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
                  k == 0 ? EMB : EMB + MW, 0, EMB, MW, bp.Gp);
     }
     ProfScope ps("mlp_wgrad_pe", stream);
-    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
-    if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 3, 4, 1, 12, WG_PE_SA, false>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gp);
-    else
-      hipLaunchKernelGGL((mlp_wgrad_kernel<4, 1, 2, 3>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gp);
+    hipLaunchKernelGGL((mlp_wgrad_lds_kernel<8, 3, 4, 1, 12, true, false>), dim3(bp.Gp, 2), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gp);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_pe", stream, 0);
   {   // heads: cotangent image (32 padded columns) x activations of the last layer
@@ -1518,13 +1319,8 @@ int trase_mlp_backward_rows(const TraseMlpWeights* w, int32_t N, const int32_t* 
     r.head_w[0] = grads->w_warp; r.head_w[1] = grads->w_rotation; r.head_w[2] = grads->w_scaling;
     r.head_b[0] = grads->b_warp; r.head_b[1] = grads->b_rotation; r.head_b[2] = grads->b_scaling;
     ProfScope ps("mlp_wgrad_head", stream);
-    static const bool use_lds = [] { const char* e = getenv("TRASE_MLP_WGRAD_LDS"); return !e || atoi(e) != 0; }();
-    if (use_lds)
-      hipLaunchKernelGGL((mlp_wgrad_lds_kernel<1, 8, 1, 4, 12, false, WG_HEAD_SB>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gd);
-    else
-      hipLaunchKernelGGL((mlp_wgrad_kernel<1, 4, 1, 2>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
-                         (const int*)bp.n_live, bp.Gd);
+    hipLaunchKernelGGL((mlp_wgrad_lds_kernel<1, 8, 1, 4, 12, false, false>), dim3(bp.Gd, 1), dim3(256), 0, stream, jobs, (const int*)bp.live_list,
+                       (const int*)bp.n_live, bp.Gd);
   }
   TRASE_POST_LAUNCH("mlp_wgrad_head", stream, 0);
   {
