@@ -1211,6 +1211,13 @@ def test_mask_stats_and_sampler_match_reference_golden():
     big = torch.rand(37, 271, 483, device="cuda", generator=g) < 0.07          # H*W odd: the scalar tail path
     cover, size = mask_stats(big)
     assert torch.equal(cover.long(), big.sum(dim=0)) and torch.equal(size.long(), big.sum(-1).sum(-1))
+    # H*W a multiple of 16: the 16-pixels-per-thread kernel; 300 masks of which a pixel can be covered by more than 255 (the
+    # packed byte counters are flushed every 255 masks), incl. a fully covered corner
+    wide = torch.rand(300, 64, 112, device="cuda", generator=g) < 0.6
+    wide[:, :3, :5] = True
+    cover, size = mask_stats(wide)
+    assert int(cover.max()) == 300
+    assert torch.equal(cover.long(), wide.sum(dim=0)) and torch.equal(size.long(), wide.sum(-1).sum(-1))
 
 
 @pytest.mark.parametrize("mode,use_w", [("soft", True), ("all", True), ("hard", True), ("soft", False)])

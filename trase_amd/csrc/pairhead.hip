@@ -109,6 +109,65 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restri
   for (int n = threadIdx.x; n < N; n += 256) if (lsize[n]) atomicAdd(&size[n], lsize[n]);
 }
 
+// 16 pixels per thread (one 16-byte load per mask; HW a multiple of 16): round 5 -- with four bytes per lane a wave moved 256 bytes
+// per load instruction and the kernel ran at 2.6 TB/s (0.080 ms for 100 masks at 1080p).  Cover counts accumulate as packed
+// bytes (flushed every 255 masks); a mask's size is the wave total of the lanes' 0..16 set flags, gathered with five ballots.
+__global__ __launch_bounds__(256) void mask_stats16_kernel(const uint8_t* __restrict__ masks, int N, long long HW,
+                                                           int32_t* __restrict__ cover, uint32_t* __restrict__ size) {
+  extern __shared__ uint32_t lsize[];
+  for (int n = threadIdx.x; n < N; n += 256) lsize[n] = 0u;
+  __syncthreads();
+  const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+  const bool in = p0 < HW;                                   // (HW % 16 == 0: a thread is inside with all sixteen pixels or not at all)
+  uint32_t cnt32[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cnt32[e] = 0u;
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+  int since_flush = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) cnt32[4 * j + b] += (acc[j] >> (8 * b)) & 0xffu;
+      acc[j] = 0u;
+    }
+    since_flush = 0;
+  };
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    uint4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      wv[u] = (in && n0 + u < N) ? *reinterpret_cast<const uint4*>(masks + (size_t)(n0 + u) * HW + p0) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = n0 + u;
+      if (n >= N) break;
+      uint32_t w[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t v = w[j];
+        v = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;       // any non-zero byte -> 1 (five operations)
+        acc[j] += v;
+        c += (uint32_t)__popc(v);
+      }
+      uint32_t tot = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) tot += (uint32_t)__popcll(__ballot((c >> b) & 1u)) << b;
+      if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&lsize[n], tot);
+      if (++since_flush == 255) flush();
+    }
+  }
+  flush();
+  if (in) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 4)
+      *reinterpret_cast<int4*>(cover + p0 + e) = make_int4((int)cnt32[e], (int)cnt32[e + 1], (int)cnt32[e + 2], (int)cnt32[e + 3]);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) if (lsize[n]) atomicAdd(&size[n], lsize[n]);
+}
+
 // ---- per sampled pixel ---------------------------------------------------------------------------------------------------
 // bit position of every sampled mask = its rank among the sampled ones (the row order of sam_masks[sampled_mask])
 __global__ __launch_bounds__(256) void ph_rank_kernel(const uint8_t* __restrict__ sampled_mask, int N, int* __restrict__ rank,
@@ -499,8 +558,12 @@ int trase_mask_stats(const uint8_t* sam_masks, int32_t N, int64_t HW, int32_t* c
   TRASE_CHECK(hipMemsetAsync(mask_size, 0, sizeof(uint32_t) * (size_t)N, stream));
   {
     ProfScope ps("mask_stats", stream);
-    hipLaunchKernelGGL(mask_stats_kernel, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), sizeof(uint32_t) * (size_t)N, stream,
-                       sam_masks, N, (long long)HW, cover_count, mask_size);
+    if ((HW & 15) == 0 && (((size_t)sam_masks | (size_t)cover_count) & 15) == 0)
+      hipLaunchKernelGGL(mask_stats16_kernel, dim3((unsigned)((HW + 4095) / 4096)), dim3(256), sizeof(uint32_t) * (size_t)N, stream,
+                         sam_masks, N, (long long)HW, cover_count, mask_size);
+    else
+      hipLaunchKernelGGL(mask_stats_kernel, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), sizeof(uint32_t) * (size_t)N, stream,
+                         sam_masks, N, (long long)HW, cover_count, mask_size);
   }
   TRASE_POST_LAUNCH("mask_stats", stream, 0);
   return TRASE_OK;
