@@ -521,6 +521,22 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
 int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S, int32_t mode, float positive_th,
                             float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
                             size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream);
+/* The same head WITHOUT the host knowing the number of sampled pixels (round 5: the reference synchronises at every boolean index of
+ * train.py:262-296; the round-4 head still did once, for S).  trase_compact_pixels turns the (H W) byte mask `sampled_pixel` into the
+ * ascending pixel indices `pix[0 .. count[0])` -- the order of a boolean index -- entirely on the device: count[0] = min(number of set
+ * bytes, cap), count[1] = the number itself (ws: trase_compact_pixels_sizes(HW) bytes).  The _n entry points take S = the CAPACITY the
+ * workspace and the launch grids are sized for and S_dev = &count[0] (NULL: S is the count, as in the entry points above); rows at or
+ * behind the device count do not exist for any kernel; S_dev == 0 gives zero losses, NaN similarities and a zero gradient. */
+int trase_compact_pixels_sizes(int64_t HW, size_t* ws_bytes);
+int trase_compact_pixels(const uint8_t* flags, int64_t HW, int32_t* pix, int32_t cap, int32_t* count2, void* ws, size_t ws_bytes,
+                         int32_t device, trase_stream_t stream);
+int trase_pairhead_forward_n(const float* feats, int32_t F, int64_t HW, const uint8_t* sam_masks, int32_t N,
+                             const uint8_t* sampled_mask, int32_t n_sampled_masks, const uint32_t* mask_size, const int32_t* pix,
+                             int32_t S, const int32_t* S_dev, int32_t mode, float positive_th, float negative_th, int32_t use_weights,
+                             float* out8, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_pairhead_backward_n(int32_t F, int64_t HW, const int32_t* pix, int32_t S, const int32_t* S_dev, int32_t mode, float positive_th,
+                              float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
+                              size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream);
 int trase_featnorm_sizes(int64_t HW, size_t* ws_bytes);
 int trase_featnorm_forward(const float* feats, int32_t F, int64_t HW, float* out2, void* ws, size_t ws_bytes, int32_t device,
                            trase_stream_t stream);

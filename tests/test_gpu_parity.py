@@ -1220,6 +1220,42 @@ def test_mask_stats_and_sampler_match_reference_golden():
     assert torch.equal(cover.long(), wide.sum(dim=0)) and torch.equal(size.long(), wide.sum(-1).sum(-1))
 
 
+@pytest.mark.parametrize("mode", ["soft", "all", "hard"])
+def test_contrastive_head_without_the_count_read_back_equals_the_synchronising_head(mode):
+    """Round 5: when the sampled-pixel mask carries the draw's target count (get_sample_pixel_and_mask tags it), the head
+    compacts the pixel indices on the device (trase_compact_pixels) and every kernel takes the count from device memory --
+    buffers and grids are sized for a capacity, nothing is read back.  Losses, similarities and the feature gradient must
+    equal those of the synchronising path (the golden-checked one) -- the gradient bit for bit, the scalars to 1e-6 relative (the
+    per-workgroup partial sums are laid out for a larger grid) -- and an empty draw must give zero losses, NaN similarities and
+    a zero gradient."""
+    import os
+    from trase_amd.feature_head import contrastive_head
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_head.npz"))
+    sam = torch.from_numpy(d["sam_masks"]).cuda()
+    sp, sm = torch.from_numpy(d["sampled_pixel"]).cuda(), torch.from_numpy(d["sampled_mask"]).cuda()
+    res = []
+    for tagged in (False, True):
+        f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
+        spx = sp.clone()
+        if tagged:
+            spx._trase_expected_count = int(sp.sum())              # what the sampler aims at
+        lp, ln, ps, ns, reg = contrastive_head(f, sam, spx, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True,
+                                               with_norm_reg=True)
+        (lp + ln + reg).backward()
+        res.append((lp.detach(), ln.detach(), ps, ns, reg.detach(), f.grad.clone()))
+    a, b = res
+    for x, y in zip(a[:5], b[:5]):
+        assert abs(float(x) - float(y)) <= 1e-6 * max(abs(float(x)), 1e-6), (float(x), float(y))
+    assert torch.equal(a[5], b[5])
+    empty = torch.zeros_like(sp)
+    empty._trase_expected_count = 50
+    f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
+    lp, ln, ps, ns = contrastive_head(f, sam, empty, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True)
+    (lp + ln).backward()
+    assert float(lp) == 0.0 and float(ln) == 0.0 and bool(torch.isnan(ps)) and bool(torch.isnan(ns))
+    assert float(f.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("mode,use_w", [("soft", True), ("all", True), ("hard", True), ("soft", False)])
 def test_contrastive_head_matches_reference_golden(mode, use_w):
     """trase_pairhead_forward / _backward against the reference's own composition (tests/golden/feature_head.npz:

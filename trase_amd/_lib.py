@@ -191,6 +191,15 @@ SYMBOLS = [
                                          C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_pairhead_backward", C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("trase_compact_pixels_sizes", C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
+    ("trase_compact_pixels", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
+                                       C.c_void_p]),
+    ("trase_pairhead_forward_n", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    ("trase_pairhead_backward_n", C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_void_p]),
     ("trase_featnorm_sizes", C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
     ("trase_featnorm_forward", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_featnorm_backward", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -168,6 +168,53 @@ __global__ __launch_bounds__(256) void mask_stats16_kernel(const uint8_t* __rest
   for (int n = threadIdx.x; n < N; n += 256) if (lsize[n]) atomicAdd(&size[n], lsize[n]);
 }
 
+// ---- sampled pixels -> ascending index list, on the device ------------------------------------------------------------------
+constexpr int CP_TILE = 4096;             // bytes of the mask per workgroup (16 per thread)
+__global__ __launch_bounds__(256) void cp_count_kernel(const uint8_t* __restrict__ flags, long long HW, uint32_t* __restrict__ block_cnt) {
+  const long long p0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * 16;
+  uint32_t c = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c += (p0 + e < HW && flags[p0 + e]) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+  __shared__ uint32_t part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void cp_scatter_kernel(const uint8_t* __restrict__ flags, long long HW, const uint32_t* __restrict__ block_cnt,
+                                                         int nblocks, int32_t* __restrict__ pix, int cap, int32_t* __restrict__ count2) {
+  __shared__ uint32_t sh[4], sh2[4], part[4];
+  uint32_t before = 0, total = 0;                            // set bytes in the blocks in front of this one / in all blocks
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const uint32_t v = block_cnt[b];
+    total += v;
+    before += (b < (int)blockIdx.x) ? v : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { before += (uint32_t)__shfl_xor((int)before, o); total += (uint32_t)__shfl_xor((int)total, o); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = before; sh2[threadIdx.x >> 6] = total; }
+  __syncthreads();
+  before = sh[0] + sh[1] + sh[2] + sh[3];
+  total = sh2[0] + sh2[1] + sh2[2] + sh2[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { count2[0] = (int32_t)min(total, (uint32_t)cap); count2[1] = (int32_t)total; }
+  const long long p0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * 16;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bits |= (p0 + e < HW && flags[p0 + e]) ? (1u << e) : 0u;
+  const uint32_t mine = (uint32_t)__popc(bits);
+  uint32_t x = mine;                                         // inclusive scan over the workgroup
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o); if ((int)(threadIdx.x & 63) >= o) x += y; }
+  if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t at = before + x - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) at += part[w];
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if (bits & (1u << e)) { if (at < (uint32_t)cap) pix[at] = (int32_t)(p0 + e); ++at; }
+}
+
 // ---- per sampled pixel ---------------------------------------------------------------------------------------------------
 // bit position of every sampled mask = its rank among the sampled ones (the row order of sam_masks[sampled_mask])
 __global__ __launch_bounds__(256) void ph_rank_kernel(const uint8_t* __restrict__ sampled_mask, int N, int* __restrict__ rank,
@@ -199,8 +246,10 @@ __global__ __launch_bounds__(256) void ph_rank_kernel(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void ph_gather_kernel(const float* __restrict__ feats, long long HW,
                                                         const uint8_t* __restrict__ masks, int N, const int* __restrict__ rank,
                                                         const uint32_t* __restrict__ mask_size, const int32_t* __restrict__ pix,
-                                                        int S, float* __restrict__ fn, float* __restrict__ rinv,
-                                                        float* __restrict__ a, uint32_t* __restrict__ bits) {
+                                                        int S_cap, const int* __restrict__ S_ptr, float* __restrict__ fn,
+                                                        float* __restrict__ rinv, float* __restrict__ a, uint32_t* __restrict__ bits) {
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
+  if (S <= 0) return;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int s = gid >> 3, l = gid & 7;
   const long long p = pix[min(s, S - 1)];
@@ -251,7 +300,9 @@ __global__ __launch_bounds__(256) void ph_gather_kernel(const float* __restrict_
 
 // ptp_max = (max a)^2; w_max = max(1, ptp_max / (min non-zero a)^2); the matrix minimum of the clamped ratio is exactly 1
 // (the entry of the two largest a, ptp_max / ptp_max, or any zero product replaced by 1e10)
-__global__ __launch_bounds__(256) void ph_consts_kernel(const float* __restrict__ a, int S, float* __restrict__ consts) {
+__global__ __launch_bounds__(256) void ph_consts_kernel(const float* __restrict__ a, int S_cap, const int* __restrict__ S_ptr,
+                                                        float* __restrict__ consts) {
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
   __shared__ float smax[256], smin[256];
   float mx = 0.f, mn = INFINITY;
   for (int s = threadIdx.x; s < S; s += 256) { const float v = a[s]; mx = fmaxf(mx, v); if (v > 0.f) mn = fminf(mn, v); }
@@ -299,10 +350,15 @@ __device__ __forceinline__ float dot32(const f32x2* fj, const float* fi_) {
 }
 
 // kind: bit 1-2 = mode (0 soft, 1 all, 2 hard)
-__global__ __launch_bounds__(256) void ph_flags_kernel(const float* __restrict__ fn, const uint32_t* __restrict__ bits, int S,
-                                                       float pth, float nth, int mode, int* __restrict__ colP,
-                                                       int* __restrict__ colN, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void ph_flags_kernel(const float* __restrict__ fn, const uint32_t* __restrict__ bits, int S_cap,
+                                                       const int* __restrict__ S_ptr, float pth, float nth, int mode,
+                                                       int* __restrict__ colP, int* __restrict__ colN, double* __restrict__ partial) {
   __shared__ double red[4][4];
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
+  if ((int)(blockIdx.y * PH_ROWS) >= S || (int)(blockIdx.x * 256) >= S) {     // nothing of this tile exists (grids are sized for S_cap)
+    if (threadIdx.x < 4) partial[8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 4 + threadIdx.x] = 0.0;
+    return;
+  }
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * PH_ROWS, i1 = min(i0 + PH_ROWS, S);
   f32x2 fj[PH_F / 2]; uint32_t bj[PH_MAXW];
@@ -336,10 +392,12 @@ __global__ __launch_bounds__(256) void ph_flags_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void ph_sum_kernel(const float* __restrict__ fn, const uint32_t* __restrict__ bits,
-                                                     const float* __restrict__ a, const float* __restrict__ consts, int S,
-                                                     float pth, float nth, int mode, int use_w, const int* __restrict__ colP,
-                                                     const int* __restrict__ colN, double* __restrict__ partial) {
+                                                     const float* __restrict__ a, const float* __restrict__ consts, int S_cap,
+                                                     const int* __restrict__ S_ptr, float pth, float nth, int mode, int use_w,
+                                                     const int* __restrict__ colP, const int* __restrict__ colN,
+                                                     double* __restrict__ partial) {
   __shared__ double red[4][4];
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * PH_ROWS, i1 = min(i0 + PH_ROWS, S);
   if (i0 >= min(S, (int)(blockIdx.x * 256 + 256))) {        // the whole tile is on or below the diagonal: nothing to add
@@ -380,9 +438,11 @@ __global__ __launch_bounds__(256) void ph_sum_kernel(const float* __restrict__ f
 
 // out8 = {loss_pos, N_pos, loss_neg, N_neg, pos_similarity, neg_similarity, S, sampled masks}
 __global__ __launch_bounds__(256) void ph_final_kernel(const double* __restrict__ partial, int nblk, const int* __restrict__ colP,
-                                                       const int* __restrict__ colN, int S, int mode,
-                                                       const float* __restrict__ consts, float* __restrict__ out8) {
+                                                       const int* __restrict__ colN, int S_cap, const int* __restrict__ S_ptr,
+                                                       int mode, const float* __restrict__ consts, float* __restrict__ out8) {
   __shared__ double sh[10][256];
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
+
   double v[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) v[k] = 0.0;
@@ -413,10 +473,13 @@ __global__ __launch_bounds__(256) void ph_final_kernel(const double* __restrict_
 
 // d f_t += coeff(min(t,u), max(t,u)) * f_u over one chunk of u; coeff = dL/dC_F of the pair
 __global__ __launch_bounds__(256) void ph_bwd_kernel(const float* __restrict__ fn, const uint32_t* __restrict__ bits,
-                                                     const float* __restrict__ a, const float* __restrict__ consts, int S,
-                                                     float pth, float nth, int mode, int use_w, const int* __restrict__ colP,
-                                                     const int* __restrict__ colN, const float* __restrict__ out8,
-                                                     const float* __restrict__ g2, float* __restrict__ dpart) {
+                                                     const float* __restrict__ a, const float* __restrict__ consts, int S_cap,
+                                                     const int* __restrict__ S_ptr, float pth, float nth, int mode, int use_w,
+                                                     const int* __restrict__ colP, const int* __restrict__ colN,
+                                                     const float* __restrict__ out8, const float* __restrict__ g2,
+                                                     float* __restrict__ dpart) {
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
+  if ((int)(blockIdx.x * 256) >= S) return;
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int per = (S + PH_CHUNKS - 1) / PH_CHUNKS;
   const int u0 = blockIdx.y * per, u1 = min(u0 + per, S);
@@ -459,8 +522,11 @@ __global__ __launch_bounds__(256) void ph_bwd_kernel(const float* __restrict__ f
 // reduce the chunks in order, back through x -> x / max(|x|, eps), scatter into the gradient image.
 // One thread per (sampled pixel, channel): a 32-lane half wave owns a pixel and reduces <fn, d> with shuffles.
 __global__ __launch_bounds__(256) void ph_scatter_kernel(const float* __restrict__ dpart, const float* __restrict__ fn,
-                                                         const float* __restrict__ rinv, const int32_t* __restrict__ pix, int S,
-                                                         long long HW, int accumulate, float* __restrict__ dfeats) {
+                                                         const float* __restrict__ rinv, const int32_t* __restrict__ pix, int S_cap,
+                                                         const int* __restrict__ S_ptr, long long HW, int accumulate,
+                                                         float* __restrict__ dfeats) {
+  const int S = S_ptr ? min(*S_ptr, S_cap) : S_cap;            // device-side count (sync-free head) or the host's
+  if ((int)((blockIdx.x * 256) >> 5) >= S) return;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int s = gid >> 5, c = gid & 31;
   const int ss = min(s, S - 1);
@@ -569,6 +635,29 @@ int trase_mask_stats(const uint8_t* sam_masks, int32_t N, int64_t HW, int32_t* c
   return TRASE_OK;
 }
 
+int trase_compact_pixels_sizes(int64_t HW, size_t* ws_bytes) {
+  if (!ws_bytes || HW < 1) { set_error("trase_compact_pixels_sizes: bad arguments"); return TRASE_ERR_INVALID; }
+  *ws_bytes = align_up(sizeof(uint32_t) * (size_t)((HW + CP_TILE - 1) / CP_TILE));
+  return TRASE_OK;
+}
+
+int trase_compact_pixels(const uint8_t* flags, int64_t HW, int32_t* pix, int32_t cap, int32_t* count2, void* ws, size_t ws_bytes,
+                         int32_t device, trase_stream_t stream_) {
+  if (!flags || !pix || !count2 || HW < 1 || cap < 1) { set_error("trase_compact_pixels: bad arguments"); return TRASE_ERR_INVALID; }
+  const int nblocks = (int)((HW + CP_TILE - 1) / CP_TILE);
+  if (!ws || ws_bytes < align_up(sizeof(uint32_t) * (size_t)nblocks)) { set_error("trase_compact_pixels: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  TRASE_CHECK(hipSetDevice(device));
+  {
+    ProfScope ps("compact_pixels", stream);
+    hipLaunchKernelGGL(cp_count_kernel, dim3(nblocks), dim3(256), 0, stream, flags, (long long)HW, (uint32_t*)ws);
+    hipLaunchKernelGGL(cp_scatter_kernel, dim3(nblocks), dim3(256), 0, stream, flags, (long long)HW, (const uint32_t*)ws, nblocks, pix, cap,
+                       count2);
+  }
+  TRASE_POST_LAUNCH("compact_pixels", stream, 0);
+  return TRASE_OK;
+}
+
 int trase_pairhead_sizes(int32_t S, size_t* ws_bytes) {
   if (!ws_bytes || S < 1) { set_error("trase_pairhead_sizes: bad arguments"); return TRASE_ERR_INVALID; }
   *ws_bytes = pair_ws_carve(S, nullptr, nullptr);
@@ -579,6 +668,14 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
                            const uint8_t* sampled_mask, int32_t n_sampled_masks, const uint32_t* mask_size, const int32_t* pix,
                            int32_t S, int32_t mode, float positive_th, float negative_th, int32_t use_weights, float* out8,
                            void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  return trase_pairhead_forward_n(feats, F, HW, sam_masks, N, sampled_mask, n_sampled_masks, mask_size, pix, S, nullptr, mode, positive_th,
+                                  negative_th, use_weights, out8, ws, ws_bytes, device, stream_);
+}
+
+int trase_pairhead_forward_n(const float* feats, int32_t F, int64_t HW, const uint8_t* sam_masks, int32_t N,
+                             const uint8_t* sampled_mask, int32_t n_sampled_masks, const uint32_t* mask_size, const int32_t* pix,
+                             int32_t S, const int32_t* S_dev, int32_t mode, float positive_th, float negative_th, int32_t use_weights,
+                             float* out8, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
   if (!feats || !sam_masks || !sampled_mask || !mask_size || !pix || !out8 || S < 1 || N < 1 || N > PH_MAXN || HW < 1 || mode < 0 || mode > 2) {
     set_error("trase_pairhead_forward: bad arguments"); return TRASE_ERR_INVALID;
   }
@@ -597,13 +694,14 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
     ProfScope ps("pairhead_fwd", stream);
     hipLaunchKernelGGL(ph_rank_kernel, dim3(1), dim3(256), 0, stream, sampled_mask, N, w.rank, w.consts);
     hipLaunchKernelGGL(ph_gather_kernel, dim3((S * 8 + 255) / 256), dim3(256), 0, stream, feats, (long long)HW, sam_masks, N, w.rank,
-                       mask_size, pix, S, w.fn, w.rinv, w.a, w.bits);
-    hipLaunchKernelGGL(ph_consts_kernel, dim3(1), dim3(256), 0, stream, w.a, S, w.consts);
-    hipLaunchKernelGGL(ph_flags_kernel, grid, dim3(256), 0, stream, w.fn, w.bits, S, positive_th, negative_th, mode, w.colP, w.colN,
-                       w.partial);
-    hipLaunchKernelGGL(ph_sum_kernel, grid, dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, positive_th, negative_th, mode,
-                       use_weights, w.colP, w.colN, w.partial);
-    hipLaunchKernelGGL(ph_final_kernel, dim3(1), dim3(256), 0, stream, w.partial, w.nblk, w.colP, w.colN, S, mode, w.consts, out8);
+                       mask_size, pix, S, (const int*)S_dev, w.fn, w.rinv, w.a, w.bits);
+    hipLaunchKernelGGL(ph_consts_kernel, dim3(1), dim3(256), 0, stream, w.a, S, (const int*)S_dev, w.consts);
+    hipLaunchKernelGGL(ph_flags_kernel, grid, dim3(256), 0, stream, w.fn, w.bits, S, (const int*)S_dev, positive_th, negative_th, mode, w.colP,
+                       w.colN, w.partial);
+    hipLaunchKernelGGL(ph_sum_kernel, grid, dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, (const int*)S_dev, positive_th, negative_th,
+                       mode, use_weights, w.colP, w.colN, w.partial);
+    hipLaunchKernelGGL(ph_final_kernel, dim3(1), dim3(256), 0, stream, w.partial, w.nblk, w.colP, w.colN, S, (const int*)S_dev, mode, w.consts,
+                       out8);
   }
   TRASE_POST_LAUNCH("pairhead_fwd", stream, 0);
   return TRASE_OK;
@@ -612,6 +710,13 @@ int trase_pairhead_forward(const float* feats, int32_t F, int64_t HW, const uint
 int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S, int32_t mode, float positive_th,
                             float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
                             size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream_) {
+  return trase_pairhead_backward_n(F, HW, pix, S, nullptr, mode, positive_th, negative_th, use_weights, out8, g2, ws, ws_bytes, accumulate,
+                                   dL_dfeats, device, stream_);
+}
+
+int trase_pairhead_backward_n(int32_t F, int64_t HW, const int32_t* pix, int32_t S, const int32_t* S_dev, int32_t mode, float positive_th,
+                              float negative_th, int32_t use_weights, const float* out8, const float* g2, const void* ws,
+                              size_t ws_bytes, int32_t accumulate, float* dL_dfeats, int32_t device, trase_stream_t stream_) {
   if (!pix || !out8 || !g2 || !dL_dfeats || S < 1 || HW < 1 || mode < 0 || mode > 2 || F != PH_F) {
     set_error("trase_pairhead_backward: bad arguments"); return TRASE_ERR_INVALID;
   }
@@ -622,10 +727,10 @@ int trase_pairhead_backward(int32_t F, int64_t HW, const int32_t* pix, int32_t S
   if (!accumulate) TRASE_CHECK(hipMemsetAsync(dL_dfeats, 0, sizeof(float) * (size_t)F * (size_t)HW, stream));
   {
     ProfScope ps("pairhead_bwd", stream);
-    hipLaunchKernelGGL(ph_bwd_kernel, dim3((S + 255) / 256, PH_CHUNKS), dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, positive_th,
-                       negative_th, mode, use_weights, w.colP, w.colN, out8, g2, w.dpart);
-    hipLaunchKernelGGL(ph_scatter_kernel, dim3((S * PH_F + 255) / 256), dim3(256), 0, stream, w.dpart, w.fn, w.rinv, pix, S, (long long)HW,
-                       accumulate, dL_dfeats);
+    hipLaunchKernelGGL(ph_bwd_kernel, dim3((S + 255) / 256, PH_CHUNKS), dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, (const int*)S_dev,
+                       positive_th, negative_th, mode, use_weights, w.colP, w.colN, out8, g2, w.dpart);
+    hipLaunchKernelGGL(ph_scatter_kernel, dim3((S * PH_F + 255) / 256), dim3(256), 0, stream, w.dpart, w.fn, w.rinv, pix, S, (const int*)S_dev,
+                       (long long)HW, accumulate, dL_dfeats);
   }
   TRASE_POST_LAUNCH("pairhead_bwd", stream, 0);
   return TRASE_OK;

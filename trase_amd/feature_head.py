@@ -73,12 +73,15 @@ def get_sample_pixel_and_mask(sam_masks, num_sampled_pixels, num_sampled_masks, 
     pixel_sample_rate = num_sampled_pixels / (sam_masks.shape[-1] * sam_masks.shape[-2])
     sampled_pixel = torch.rand(sam_masks.shape[-2], sam_masks.shape[-1], device=where).to(dev) < pixel_sample_rate
     sampled_pixel = torch.logical_and(sampled_pixel, cover_count != 0)
+    # (how many pixels the draw aims at: lets contrastive_head size its buffers without reading the count back from the device)
+    sampled_pixel._trase_expected_count = int(num_sampled_pixels)
     return sampled_pixel, sampled_mask
 
 
 class _PairHead(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, masks_u8, sampled_mask_u8, n_sampled, mask_size, pix, mode, pth, nth, use_w, with_reg):
+    def forward(ctx, feats, masks_u8, sampled_mask_u8, n_sampled, mask_size, pix, mode, pth, nth, use_w, with_reg, s_dev=None):
+        # s_dev: int32[2] on the device, s_dev[0] = number of valid entries of `pix` (trase_compact_pixels); None: all of them
         lib = _lib.load()
         dev = feats.device
         F, H, W = feats.shape
@@ -89,10 +92,11 @@ class _PairHead(torch.autograd.Function):
         ws = _bytes(nbytes.value, dev)
         out8 = torch.empty(8, device=dev)
         d = _dev_index(dev)
-        _lib.check(lib.trase_pairhead_forward(_lib.ptr(f), F, H * W, _lib.ptr(masks_u8), masks_u8.shape[0], _lib.ptr(sampled_mask_u8),
-                                              int(n_sampled), _lib.ptr(mask_size), _lib.ptr(pix), S, int(mode), float(pth), float(nth),
-                                              int(use_w), _lib.ptr(out8), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
+        _lib.check(lib.trase_pairhead_forward_n(_lib.ptr(f), F, H * W, _lib.ptr(masks_u8), masks_u8.shape[0], _lib.ptr(sampled_mask_u8),
+                                                int(n_sampled), _lib.ptr(mask_size), _lib.ptr(pix), S, _lib.ptr(s_dev), int(mode), float(pth),
+                                                float(nth), int(use_w), _lib.ptr(out8), _lib.ptr(ws), ws.numel(), d, _stream(dev)),
                    "trase_pairhead_forward")
+        ctx.s_dev = s_dev
         sims = out8[4:6].clone()
         ctx.mark_non_differentiable(sims)
         ctx.cfg = (F, H, W, S, int(mode), float(pth), float(nth), int(use_w), bool(with_reg))
@@ -123,10 +127,10 @@ class _PairHead(torch.autograd.Function):
             gg = g_reg.reshape(1).float().contiguous()
             _lib.check(lib.trase_featnorm_backward(_lib.ptr(f), F, H * W, _lib.ptr(out2), _lib.ptr(gg), _lib.ptr(d_feats), d, st),
                        "trase_featnorm_backward")
-        _lib.check(lib.trase_pairhead_backward(F, H * W, _lib.ptr(pix), S, mode, pth, nth, use_w, _lib.ptr(out8), _lib.ptr(g2),
-                                               _lib.ptr(ws), ws.numel(), 1 if with_reg else 0, _lib.ptr(d_feats), d, st),
+        _lib.check(lib.trase_pairhead_backward_n(F, H * W, _lib.ptr(pix), S, _lib.ptr(ctx.s_dev), mode, pth, nth, use_w, _lib.ptr(out8),
+                                                 _lib.ptr(g2), _lib.ptr(ws), ws.numel(), 1 if with_reg else 0, _lib.ptr(d_feats), d, st),
                    "trase_pairhead_backward")
-        return (d_feats,) + (None,) * 10
+        return (d_feats,) + (None,) * 11
 
 
 def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, mode="soft", positive_th=0.75, negative_th=0.5,
@@ -134,8 +138,9 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
     """(loss_pos, loss_neg, pos_similarity, neg_similarity[, norm_reg]) of train.py:272-296:
     ``positive_pixel_pair_loss[mode](C, C_F, positive_th, weights)``, ``negative_pixel_pair_loss[mode](...)``,
     ``C_F[C == 1].mean()``, ``C_F[C == 0].mean()`` for the matrices the reference derives from ``sam_masks``,
-    ``sampled_pixel``, ``sampled_mask`` and the (32, H, W) features.  One synchronisation (the number of sampled pixels;
-    the reference synchronises at every boolean index).  ``with_norm_reg=True`` also returns the regulariser
+    ``sampled_pixel``, ``sampled_mask`` and the (32, H, W) features.  No synchronisation when ``sampled_pixel`` comes from
+    ``get_sample_pixel_and_mask`` (it carries the draw's target count: the indices are compacted and counted on the device); one --
+    the number of sampled pixels -- for any other boolean mask (the reference synchronises at every boolean index).  ``with_norm_reg=True`` also returns the regulariser
     ``(1 - rendered_features.norm(dim=0).mean()) ** 2`` (train.py:281-282) of the same image -- valid when the rendered
     features already have the mask resolution, so that train.py:284's ``interpolate`` is the identity -- and shares one
     dense gradient pass with the pair losses."""
@@ -152,17 +157,34 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
     dev = m.device
     if mask_size is None:
         _, mask_size = mask_stats(sam_masks)
-    pix = torch.nonzero(sampled_pixel.reshape(-1)).reshape(-1).to(torch.int32)       # ascending = boolean-index order
     sm = (sampled_mask != 0).to(dev).contiguous().view(torch.uint8)
     n_sampled = N if N <= 256 else int(sm.sum())
     if n_sampled > 256:
         raise ValueError(f"{n_sampled} sampled masks (the membership bit sets hold 256)")
-    if pix.numel() == 0:
-        z = rendered_features.sum() * 0.0
-        nan = torch.full((), float("nan"), device=dev)
-        return (z, z, nan, nan, feature_norm_reg(rendered_features)) if with_norm_reg else (z, z, nan, nan)
+    expected = getattr(sampled_pixel, "_trase_expected_count", None)
+    s_dev = None
+    if expected is not None and sampled_pixel.dtype == torch.bool:
+        # no read-back (round 5): the indices are compacted on the device into a buffer sized for the draw's target plus eight
+        # standard deviations of the binomial count; every kernel of the head takes the count from the device.  (A draw that
+        # overflowed the buffer -- probability ~ 1e-15 -- would drop its highest pixels; count[1] keeps the true number.)
+        cap = int(expected + 8.0 * expected ** 0.5 + 64)
+        lib = _lib.load()
+        flags = sampled_pixel.contiguous().view(torch.uint8)
+        pix = torch.empty(cap, dtype=torch.int32, device=dev)
+        s_dev = torch.empty(2, dtype=torch.int32, device=dev)
+        nb = C.c_size_t()
+        _lib.check(lib.trase_compact_pixels_sizes(H * W, C.byref(nb)), "trase_compact_pixels_sizes")
+        cws = _bytes(nb.value, dev)
+        _lib.check(lib.trase_compact_pixels(_lib.ptr(flags), H * W, _lib.ptr(pix), cap, _lib.ptr(s_dev), _lib.ptr(cws), cws.numel(),
+                                            _dev_index(dev), _stream(dev)), "trase_compact_pixels")
+    else:
+        pix = torch.nonzero(sampled_pixel.reshape(-1)).reshape(-1).to(torch.int32)       # ascending = boolean-index order (synchronises)
+        if pix.numel() == 0:
+            z = rendered_features.sum() * 0.0
+            nan = torch.full((), float("nan"), device=dev)
+            return (z, z, nan, nan, feature_norm_reg(rendered_features)) if with_norm_reg else (z, z, nan, nan)
     res = _PairHead.apply(rendered_features, m, sm, n_sampled, mask_size.contiguous(), pix, _MODES[mode], positive_th, negative_th,
-                          1 if use_weights else 0, bool(with_norm_reg))
+                          1 if use_weights else 0, bool(with_norm_reg), s_dev)
     lp, ln, sims = res[:3]
     return (lp, ln, sims[0], sims[1], res[3]) if with_norm_reg else (lp, ln, sims[0], sims[1])
 
