@@ -92,6 +92,9 @@ typedef enum TraseVariant {
                                               * values whenever every Gaussian has few enough pairs -- decided on the device,
                                               * results identical) */
   /* -- tile-row strips (tile_row_begin / tile_row_end set) -- */
+  TRASE_VARIANT_DEPTH32 = 0x400000,          /* depth sort on the raw float32 depth bits (four 8-bit passes) instead of the default 27-bit
+                                              * key (three 9-bit passes, exact for view depth < 13 107): selected by the caller after a
+                                              * forward has raised bit 1 of the header's overflow word (a saturated depth key) */
   TRASE_VARIANT_SPARSE_STRIP_GRADS = 0x200000, /* trase_rast_backward_raw writes ONLY the gradient rows of the Gaussians that have a
                                               * pair in the strip (~1 / world of them); the caller guarantees that every other row
                                               * of the gradient tensors is zero -- persistent tensors, zero-filled once, whose

@@ -114,7 +114,7 @@ static int list_pack_bits(const TraseRastSettings* s, int P) {
 }
 size_t pre_bytes(int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
-  return align_up(sizeof(uint32_t) * p) * 7 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p, DEPTH_DIGIT_BITS);
+  return align_up(sizeof(uint32_t) * p) * 7 + align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3) + sort_bytes_common(p, DEPTH_MAX_DIGIT_BITS);
 }
 PreBuf carve_pre(void* ptr, int P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -126,7 +126,7 @@ PreBuf carve_pre(void* ptr, int P) {
   t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.live_ids = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3);
-  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * ((size_t)1 << DEPTH_DIGIT_BITS) * (size_t)rs_blocks(p));
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * ((size_t)1 << DEPTH_MAX_DIGIT_BITS) * (size_t)rs_blocks(p));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(p);
   return t;
@@ -254,15 +254,17 @@ static inline bool strip_mode(const TraseRastSettings* s) { return s->tile_row_b
 // sub-tile counts in that order.  `keys` = where the preprocess kernel left the keys (strip mode: the sort's SECOND buffer)
 static int depth_order(const LaunchCtx& c, const TraseRastSettings* s, const GeomBuf& g, const PreBuf& t, int P, const int32_t* radii,
                        int pack_bits) {
-  // the input sits in buffer DEPTH_START (odd pass counts start from buffer 1), so that the sorted ids land in vals[0], where
-  // stage 2 reads them
+  // the input sits in buffer cfg.start (odd pass counts start from buffer 1), so that the sorted ids land in vals[0], where
+  // stage 2 reads them; the 27-bit sort watches for a saturated key in its first pass (common.h)
+  const DepthSortCfg cfg = depth_sort_cfg(s->variant);
+  uint32_t* const flag = cfg.key_bits == 27 ? g.hdr + HDR_OVERFLOW : nullptr;
   int rc, idx = 0;
   if (strip_mode(s)) {
-    rc = launch_compact_live(c, g, P, t, t.sort.keys[1 - DEPTH_START], t.sort.keys[DEPTH_START], t.sort.vals[DEPTH_START]);
+    rc = launch_compact_live(c, g, P, t, t.sort.keys[1 - cfg.start], t.sort.keys[cfg.start], t.sort.vals[cfg.start]);
     if (rc) return rc;
-    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, DEPTH_KEY_BITS, false, &idx, DEPTH_DIGIT_BITS, DEPTH_START);
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, cfg.key_bits, false, &idx, cfg.digit_bits, cfg.start, DEPTH27_SAT, flag);
   } else {
-    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, DEPTH_KEY_BITS, true, &idx, DEPTH_DIGIT_BITS, DEPTH_START);   // ids generated on the fly
+    rc = radix_sort_pairs(c, t.sort, g.hdr + (HDR_WORDS - 1), (uint32_t)P, 0, cfg.key_bits, true, &idx, cfg.digit_bits, cfg.start, DEPTH27_SAT, flag);   // ids generated on the fly
   }
   if (rc) return rc;
   if (idx != 0) {
@@ -333,7 +335,8 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   GeomBuf g = carve_geom(ws->geom, in->P);
   PreBuf t = carve_pre(ws->pre, in->P);
   if (in->P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
-  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - DEPTH_START : DEPTH_START]);
+  const DepthSortCfg cfg = depth_sort_cfg(s->variant);
+  rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - cfg.start : cfg.start], cfg.key_bits == 27);
   if (rc) return rc;
   return depth_order(c, s, g, t, in->P, out->radii, list_pack_bits(s, in->P));
 }
@@ -515,7 +518,9 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   GeomBuf g = carve_geom(ws->geom, in.P);
   PreBuf t = carve_pre(ws->pre, in.P);
   if (in.P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
-  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - DEPTH_START : DEPTH_START]);
+  const DepthSortCfg cfg = depth_sort_cfg(s->variant);
+  rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - cfg.start : cfg.start], cfg.key_bits == 27, 0u,
+                                 depth_dead_key(cfg.key_bits == 27));
   if (rc) return rc;
   return depth_order(c, s, g, t, in.P, out->radii, list_pack_bits(s, in.P));
 }
@@ -556,7 +561,7 @@ static int forward_raw_pair_impl(const TraseRastSettings* const s[2], const Tras
     LaunchCtx c{stream, s[v]->debug, s[v]->variant};
     g[v] = carve_geom(ws[v]->geom, P);
     t[v] = carve_pre(ws[v]->pre, P);
-    const int rc = launch_preprocess_fwd_raw(c, *s[v], *raw[v], out[v]->radii, g[v], cs.keys[0] + (size_t)v * P,
+    const int rc = launch_preprocess_fwd_raw(c, *s[v], *raw[v], out[v]->radii, g[v], cs.keys[0] + (size_t)v * P, false,
                                              v ? 0x80000000u : 0u, v ? 0xffffffffu : 0x7fffffffu);
     if (rc) return rc;
   }
@@ -596,7 +601,6 @@ int trase_rast_forward_raw_pair(const TraseRastSettings* s0, const TraseRastRawI
     if (strip_mode(s[v])) { set_error("trase_rast_forward_raw_pair: tile-row strips are rendered one view at a time"); return TRASE_ERR_UNSUPPORTED; }
   }
   if (raw0->P != raw1->P || s0->device != s1->device) { set_error("trase_rast_forward_raw_pair: both views render the same P Gaussians on one device"); return TRASE_ERR_INVALID; }
-  if (DEPTH_KEY_BITS != 32) { set_error("trase_rast_forward_raw_pair: needs the float32 depth keys (sign bit = view)"); return TRASE_ERR_UNSUPPORTED; }
   if (raw0->P == 0) {      // nothing to sort: the single-view path handles the empty scene
     int rc = trase_rast_forward_raw(s0, raw0, out0, ws0, stream);
     return rc ? rc : trase_rast_forward_raw(s1, raw1, out1, ws1, stream);

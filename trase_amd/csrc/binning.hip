@@ -32,12 +32,13 @@ __device__ __forceinline__ uint32_t dev_n(const uint32_t* n_ptr, uint32_t cap) {
 }
 
 // ---- pass kernel 1: per-workgroup digit histograms --------------------------------------------
-// DB = digit bits of a pass: 8 (the pair sort, KNN) or 11 (the depth sort: 32 key bits in 3 passes instead of 4)
+// DB = digit bits of a pass: 8 (the pair sort, KNN, 32-bit depth keys) or 9 (the default 27-bit depth keys in 3 passes)
 template <int DB>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ hist,
-                                                                uint32_t* __restrict__ digit_total, int nb_max) {
+                                                                uint32_t* __restrict__ digit_total, int nb_max,
+                                                                uint32_t flag_key = 0u, uint32_t* __restrict__ flag_word = nullptr) {
   constexpr int ND = 1 << DB;
   const uint32_t n = dev_n(n_ptr, cap);
   const uint32_t base = blockIdx.x * RS_TILE;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
   for (int i = 0; i < RS_ITEMS; ++i) {
     const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
     const bool valid = idx < n;
+    if (flag_word && valid && kk[i] == flag_key) atomicOr(flag_word, 2u);      // (the depth sort's saturated-key watch: first pass only)
     const uint32_t dg = valid ? ((kk[i] >> shift) & mask) : 0xffffffffu;
     const uint32_t prev = (uint32_t)__shfl_up((int)dg, 1);
     const bool start = valid && (lane == 0 || prev != dg);
@@ -308,11 +310,11 @@ int launch_split_pair_ids(const LaunchCtx& c, const uint32_t* sorted, int P, uin
 
 int radix_passes(int bit_lo, int bit_hi, int digit_bits) { return (bit_hi - bit_lo + digit_bits - 1) / digit_bits; }
 
-// digit_bits 8 or 11 (SortBufs::hist / digit_total must be sized for it: (1 << digit_bits) * nb_max and (1 << digit_bits) * passes);
+// digit_bits 8 or 9 (SortBufs::hist / digit_total must be sized for it: (1 << digit_bits) * nb_max and (1 << digit_bits) * passes);
 // `start`: which of the ping-pong buffers holds the input
 template <int DB>
 static int radix_sort_pairs_t(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
-                              bool vals_are_iota, int start, int* out_idx) {
+                              bool vals_are_iota, int start, int* out_idx, uint32_t flag_key, uint32_t* flag_word) {
   constexpr int ND = 1 << DB;
   int cur = start;
   const int nb = (int)((n_cap + RS_TILE - 1) / RS_TILE);
@@ -328,7 +330,7 @@ static int radix_sort_pairs_t(const LaunchCtx& c, const SortBufs& t, const uint3
     {
       ProfScope ps("radix_hist", c.stream);
       hipLaunchKernelGGL(radix_hist_kernel<DB>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], n_ptr, n_cap, shift,
-                         mask, t.hist, dt, t.nb_max);
+                         mask, t.hist, dt, t.nb_max, flag_key, p == 0 ? flag_word : (uint32_t*)nullptr);
     }
     TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
     {
@@ -353,9 +355,9 @@ static int radix_sort_pairs_t(const LaunchCtx& c, const SortBufs& t, const uint3
 }
 
 int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
-                     bool vals_are_iota, int* out_idx, int digit_bits, int start) {
-  if (digit_bits == 9) return radix_sort_pairs_t<9>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx);   // (instantiated for the A/B build of the depth sort)
-  if (digit_bits == 8) return radix_sort_pairs_t<8>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx);
+                     bool vals_are_iota, int* out_idx, int digit_bits, int start, uint32_t flag_key, uint32_t* flag_word) {
+  if (digit_bits == 9) return radix_sort_pairs_t<9>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx, flag_key, flag_word);
+  if (digit_bits == 8) return radix_sort_pairs_t<8>(c, t, n_ptr, n_cap, bit_lo, bit_hi, vals_are_iota, start, out_idx, flag_key, flag_word);
   set_error("radix_sort_pairs: digit_bits %d", digit_bits);
   return TRASE_ERR_INVALID;
 }
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(uint32_t* __restr
   if (threadIdx.x == 0) {
     const uint32_t R = carry;     // pairs after exact sub-tile culling (HDR_R holds the lineage count)
     hdr[HDR_R_EFF] = R;
-    hdr[HDR_OVERFLOW] = (R > cap) ? 1u : 0u;
+    hdr[HDR_OVERFLOW] = (hdr[HDR_OVERFLOW] & 2u) | ((R > cap) ? 1u : 0u);   // (bit 1: a saturated depth key, set by the depth sort)
   }
   uint32_t part = 0;
   for (int b = threadIdx.x; b < nblocks; b += SC_THREADS) part += block_R[b];
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t* __restr
   if (ranges)
     for (uint32_t i = (uint32_t)gt; i <= trash_key; i += gridDim.x * blockDim.x) ranges[i] = make_uint2(0u, 0u);
   if (gt == 0) {
-    if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] = 1u;   // pairs beyond the capacity are dropped
+    if (hdr[HDR_R_EFF] > cap) hdr[HDR_OVERFLOW] |= 1u;  // pairs beyond the capacity are dropped (bit 1 stays)
     hdr[HDR_WORDS - 2] = cap;
   }
   const bool in = r < min(P, (int)hdr[HDR_WORDS - 1]);      // depth ranks that exist (live Gaussians only when compacted)

@@ -375,7 +375,7 @@ __device__ __forceinline__ float4 split_rgbd(float r, float g, float b, float d)
 int launch_feature_table(const LaunchCtx& c, const float* feats, const uint32_t* tiles, int P, uint32_t* ftab);
 
 int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
-                          const GeomBuf& g, uint32_t* depth_keys);
+                          const GeomBuf& g, uint32_t* depth_keys, bool key27);
 int launch_preprocess_bwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, const int32_t* radii,
                           const GeomBuf& g, const float* acc, const TraseRastGrads& gr);
 
@@ -389,33 +389,37 @@ int launch_zero_live_rows(const LaunchCtx& c, const GeomBuf& g, const PreBuf& pr
 // stable LSD radix sort of (key,val) u32 pairs on bits [bit_lo, bit_hi); n is read on the device
 // from *n_ptr and clamped to n_cap.  Result ends in keys[out_idx]/vals[out_idx] (returned).
 int radix_sort_pairs(const LaunchCtx& c, const SortBufs& t, const uint32_t* n_ptr, uint32_t n_cap, int bit_lo, int bit_hi,
-                     bool vals_are_iota, int* out_idx, int digit_bits = 8, int start = 0);
+                     bool vals_are_iota, int* out_idx, int digit_bits = 8, int start = 0, uint32_t flag_key = 0u,
+                     uint32_t* flag_word = nullptr);     // flag_word: *flag_word |= 2 when the first pass meets a key == flag_key
 // zero-fill as a KERNEL: a hipMemsetAsync captured into a launch graph did not clear its buffer from the second replay on
 // (round 5: gradient rows of stale pair flags -- NaN under TRASE_POISON -- on every graph hit after the first; ROCm 7.0.2)
 int launch_zero_bytes(void* p, size_t bytes, hipStream_t stream);
 int launch_fill_u32(uint32_t* p, uint32_t v, hipStream_t stream);
 int launch_split_pair_ids(const LaunchCtx& c, const uint32_t* sorted, int P, uint32_t* ids0, uint32_t* ids1);
 int radix_passes(int bit_lo, int bit_hi, int digit_bits = 8);
-// The depth sort.  Default: the float32 depth bits in four 8-bit passes (12 launches).  -DTRASE_DEPTH_DIGITS=9 (measured, see
-// profiles/r5_ab_experiments.txt): an order-preserving 27-bit key -- float bits above those of the 0.2 near-cull plane (z > 0.2
-// for every live Gaussian), saturated: exact order for z < ~13 107 -- in three 9-bit passes (9 launches).
-#ifndef TRASE_DEPTH_DIGITS
-#define TRASE_DEPTH_DIGITS 8
-#endif
-constexpr int DEPTH_DIGIT_BITS = TRASE_DEPTH_DIGITS;
-constexpr int DEPTH_KEY_BITS = DEPTH_DIGIT_BITS == 9 ? 27 : 32;
-constexpr int DEPTH_PASSES = (DEPTH_KEY_BITS + DEPTH_DIGIT_BITS - 1) / DEPTH_DIGIT_BITS;
-constexpr int DEPTH_START = DEPTH_PASSES & 1;      // buffer the sort starts from, so that the sorted ids land in vals[0]
-__host__ __device__ inline uint32_t depth_sort_key(float z, bool live) {
-  const uint32_t bits = __builtin_bit_cast(uint32_t, z);
-  if (DEPTH_KEY_BITS == 32) return live ? bits : 0xffffffffu;
-  const uint32_t b = bits - 0x3e4ccccdu;
-  return live ? (b < 0x07fffffeu ? b : 0x07fffffeu) : 0x07ffffffu;
+// The depth sort (round 5).  Default: an order-preserving 27-bit key -- the float32 depth bits ABOVE those of the 0.2 near-cull
+// plane (z > 0.2 for every live Gaussian), saturated at 2^27 - 2 -- in THREE 9-bit passes (9 launches; measured -16 us per view
+// against four 8-bit passes over the raw float bits, point lists bit-identical).  Exact as long as no live Gaussian lies beyond
+// z = 13 107 (2^27 float steps above 0.2): the first histogram pass sees every key and raises bit 1 of the header's overflow word
+// when one is saturated, which the callers treat like a pair-buffer overflow -- the iteration is repeated (sync policy: at
+// once; sync-free: guarded consumers skip it, the report switches the process over) with TRASE_VARIANT_DEPTH32: the raw float
+// bits in four 8-bit passes, which is also what the two-view forward uses (it needs the sign bit for the view index).
+struct DepthSortCfg { int key_bits, digit_bits, passes, start; };     // start: ping-pong buffer the sort begins in (ids must END in vals[0])
+inline DepthSortCfg depth_sort_cfg(int variant) {
+  return (variant & TRASE_VARIANT_DEPTH32) ? DepthSortCfg{32, 8, 4, 0} : DepthSortCfg{27, 9, 3, 1};
 }
+constexpr int DEPTH_MAX_DIGIT_BITS = 9;                                 // histogram buffers are sized for this
+constexpr uint32_t DEPTH27_BASE = 0x3e4ccccdu, DEPTH27_SAT = 0x07fffffeu, DEPTH27_DEAD = 0x07ffffffu;
+__host__ __device__ inline uint32_t depth_sort_key(float z, bool key27) {     // key of a LIVE Gaussian
+  const uint32_t bits = __builtin_bit_cast(uint32_t, z);
+  if (!key27) return bits;
+  const uint32_t b = bits - DEPTH27_BASE;
+  return b < DEPTH27_SAT ? b : DEPTH27_SAT;
+}
+inline uint32_t depth_dead_key(bool key27) { return key27 ? DEPTH27_DEAD : 0xffffffffu; }
 // key_or / key_dead: see RawFwdArgs (the two-view forward puts the view index into the key's sign bit)
 int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
-                              const GeomBuf& g, uint32_t* depth_keys, uint32_t key_or = 0u,
-                              uint32_t key_dead = depth_sort_key(0.f, false));
+                              const GeomBuf& g, uint32_t* depth_keys, bool key27, uint32_t key_or = 0u, uint32_t key_dead = 0xffffffffu);
 
 // pack_bits: 0 = never pack; jb = pack list values as (id << jb | j) when every Gaussian has fewer than 2^jb pairs
 // strip mode: (depth key, id) of the Gaussians with a pair, ascending ids, then the ids without one; hdr[HDR_WORDS - 1] = live count

@@ -19,6 +19,7 @@ struct PreArgs {
   int P, M, deg, W, H;
   float tanx, tany, mod;
   int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
+  int key27;                 // 27-bit depth keys (common.h depth_sort_key)
 };
 
 __device__ __forceinline__ void fill_view(const PreArgs& a, View& v) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(PreArgs a, int32_t*
   }
   if (active) {
     tiles[i] = live;
-    depth_keys[i] = depth_sort_key(o.depth, vis && live);
+    depth_keys[i] = (vis && live) ? depth_sort_key(o.depth, a.key27 != 0) : (a.key27 ? DEPTH27_DEAD : 0xffffffffu);
   }
   if (vis) {
     xy[i] = make_float2(o.px, o.py);
@@ -125,9 +126,10 @@ static void fill_pre_args(PreArgs& a, const TraseRastSettings& s, const TraseRas
 }
 
 int launch_preprocess_fwd(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastInputs& in, int32_t* radii,
-                          const GeomBuf& g, uint32_t* depth_keys) {
+                          const GeomBuf& g, uint32_t* depth_keys, bool key27) {
   PreArgs a;
   fill_pre_args(a, s, in);
+  a.key27 = key27 ? 1 : 0;
   const dim3 grid((in.P + 255) / 256), block(256);
   const bool cov = in.cov3D_precomp != nullptr, sh = in.shs != nullptr;
   {

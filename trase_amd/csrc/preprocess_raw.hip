@@ -25,6 +25,7 @@ struct RawFwdArgs {
   int sy_lo, sy_hi;          // sub-tile rows of the strip being rendered
   int strip;                 // forward: a tile-row strip is rendered (most Gaussians have no pair): colour and records only for those that do
   int p_begin, p_end;        // backward only: the Gaussians [p_begin, p_end) (p_begin a multiple of 64)
+  int key27;                 // forward: 27-bit depth keys (common.h depth_sort_key)
   uint32_t key_or, key_dead; // forward: OR-ed into a live Gaussian's depth key / the key of one without a pair (the two-view forward keeps
                              // the view index in the sign bit of the float32 key: z > 0.2, so the bit is free)
 };
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
   }
   if (active) {
     tiles[i] = live;
-    depth_keys[i] = (vis && live) ? (depth_sort_key(o.depth, true) | a.key_or) : a.key_dead;
+    depth_keys[i] = (vis && live) ? (depth_sort_key(o.depth, a.key27 != 0) | a.key_or) : a.key_dead;
   }
   const bool want = vis && (live != 0 || !strip);             // gets a colour and a record
   if (!strip) {
@@ -273,9 +274,9 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
 }
 
 int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, const TraseRastRawInputs& raw, int32_t* radii,
-                              const GeomBuf& g, uint32_t* depth_keys, uint32_t key_or, uint32_t key_dead) {
+                              const GeomBuf& g, uint32_t* depth_keys, bool key27, uint32_t key_or, uint32_t key_dead) {
   RawFwdArgs a;
-  a.key_or = key_or; a.key_dead = key_dead;
+  a.key27 = key27 ? 1 : 0; a.key_or = key_or; a.key_dead = key_dead;
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;
   a.scaling = raw.scaling; a.d_scaling = raw.d_scaling; a.rotation = raw.rotation; a.d_rotation = raw.d_rotation;
   a.features = raw.gaussian_features; a.featn = raw.featn;
@@ -471,7 +472,7 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   if (p_end < 0) p_end = raw.P;
   if (p_end <= p_begin) return TRASE_OK;
   RawFwdArgs a;
-  a.key_or = 0u; a.key_dead = 0u;
+  a.key27 = 0; a.key_or = 0u; a.key_dead = 0u;
   a.write_featn = 0;
   a.p_begin = p_begin; a.p_end = p_end;
   a.xyz = raw.xyz; a.d_xyz = raw.d_xyz; a.f_dc = raw.features_dc; a.f_rest = raw.features_rest; a.opacity = raw.opacity;

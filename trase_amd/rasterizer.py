@@ -103,6 +103,18 @@ VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x200
 VARIANT_FEATURES_ONLY_BWD = 0x400                                                       # backward scope
 VARIANT_VALU_BACKWARD, VARIANT_VALU_FORWARD, VARIANT_SLOT_LISTS = 0x40, 0x2000, 0x100000  # cross-check formulations
 VARIANT_SPARSE_STRIP_GRADS = 0x200000                                                   # tile-row strips: live rows only
+VARIANT_DEPTH32 = 0x400000                # depth sort on the raw float32 depth bits (the fallback of the 27-bit keys, see set_depth_keys)
+
+
+def set_depth_keys(bits: int = 27):
+    """Depth-sort keys.  27 (default): the float32 depth bits above those of the 0.2 near-cull plane, in three 9-bit radix
+    passes -- the same order as the lineage's float keys for every view depth below 13 107 scene units, three launches and
+    16 us per view cheaper than 32: the raw float bits in four 8-bit passes.  The library watches for a saturated key and
+    switches the process to 32 by itself (sync policy: the forward is repeated at once; sync-free: that iteration is
+    reported like a pair-buffer overflow -- guarded consumers skip it -- and every later forward uses 32)."""
+    if bits not in (27, 32):
+        raise ValueError("depth keys are 27 or 32 bits")
+    _Policy.variant = (_Policy.variant & ~VARIANT_DEPTH32) | (VARIANT_DEPTH32 if bits == 32 else 0)
 
 
 def set_sparse_strip_grads(flag: bool = True):
@@ -169,6 +181,13 @@ def _header_verdict(h, cap: int, what: str):
         _Policy.capacity = max(_Policy.capacity, int(r_eff * 1.25) + 1024)
     if int(h[16]) or int(h[20]):
         raise RuntimeError(f"trase_amd rasterizer: binning guard tripped in {what} (key flag {int(h[16])}, slot flag {int(h[20])})")
+    if int(h[1]) >= 2:         # bit 1 (MAX-reduced over the ranks under data parallelism: any value >= 2): a saturated 27-bit depth key
+        _Policy.variant |= VARIANT_DEPTH32
+        raise RuntimeError(f"trase_amd rasterizer: a Gaussian of {what} lies beyond the range of the 27-bit depth keys (view depth > "
+                           f"13 107): that call's depth order was not exact beyond that distance.  This process now sorts on the raw "
+                           f"float32 depth bits (rasterizer.set_depth_keys(32)).  Guarded consumers of that iteration "
+                           f"(FusedAdam.step, add_densification_stats) skipped it on the device; unguarded ones have used its "
+                           f"gradients: re-run the iteration, or call set_depth_keys(32) / set_sync(True) up front for such scenes.")
     if int(h[1]):
         raise RuntimeError(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
                            f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
@@ -257,11 +276,16 @@ def check_overflow():
     _poll_pending(block=True)
 
 
-def _pick_capacity(lib, ws, stream) -> int:
-    """Pair capacity of the forward whose stage 1 has just been enqueued on `stream`."""
+def _pick_capacity(lib, ws, stream, rerun_stage1=None) -> int:
+    """Pair capacity of the forward whose stage 1 has just been enqueued on `stream`.  rerun_stage1(): repeats stage 1 with
+    32-bit depth keys -- called when the status read finds a saturated 27-bit key (set_depth_keys)."""
     if _Policy.sync or _Policy.capacity <= 0:
         st = (C.c_int64 * 3)()
         _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
+        if int(st[1]) & 2 and rerun_stage1 is not None:
+            _Policy.variant |= VARIANT_DEPTH32
+            rerun_stage1()
+            _lib.check(lib.trase_rast_status(C.byref(ws), C.byref(st), stream), "trase_rast_status")
         need = max(int(st[2]), 1)              # pairs after exact sub-tile culling
         if _Policy.sync:
             return need
@@ -502,7 +526,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if not one_call:
             _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream),
                        "trase_rast_preprocess")
-        capacity = _pick_capacity(lib, ws, stream)
+        def _again():              # a saturated 27-bit depth key: stage 1 once more on the raw float bits
+            s.variant |= VARIANT_DEPTH32
+            _lib.check(lib.trase_rast_preprocess(C.byref(s), C.byref(inp), C.byref(out), C.byref(ws), stream), "trase_rast_preprocess")
+        capacity = _pick_capacity(lib, ws, stream, None if one_call else _again)
         _, bin_b, _, _, tmp_b, _ = _sizes(lib, P, W, H, F, capacity)
         binb = _bytes(bin_b, device)
         tmp = _bytes(tmp_b, device)

@@ -18,6 +18,7 @@ from . import _lib
 from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
 from .rasterizer import VARIANT_SPARSE_STRIP_GRADS as _r_VARIANT_SPARSE
+from .rasterizer import VARIANT_DEPTH32 as _r_VARIANT_DEPTH32
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _release_last, _bytes, _fill_settings,
                          _output_maps, _pick_capacity, _prep, _sizes, _stream)
 
@@ -159,7 +160,11 @@ class _RenderRaw(torch.autograd.Function):
         if not one_call:
             _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
                        "trase_rast_preprocess_raw")
-        capacity = _pick_capacity(lib, ws, stream)
+        def _again():              # a saturated 27-bit depth key: stage 1 once more on the raw float bits
+            s.variant |= _r_VARIANT_DEPTH32
+            _lib.check(lib.trase_rast_preprocess_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), stream),
+                       "trase_rast_preprocess_raw")
+        capacity = _pick_capacity(lib, ws, stream, None if one_call else _again)
         _, bin_b, _, _, tmp_b, _ = _sizes(lib, P, W, H, F, capacity)
         binb, tmp = _bytes(bin_b, device), _bytes(tmp_b, device)
         ws.bin, ws.bin_bytes = _lib.ptr(binb), binb.numel()
