@@ -440,9 +440,14 @@ def main():
             pass
     if not args.graph:           # (a replayed launch graph has no per-kernel events: --graph takes the kernel times of the untimed pass below)
         R.profile_enable(2)      # HIP events around the compositing kernels only, on the launch stream
+    import gc
+    gc.collect()
+    gc.disable()                 # (a generation-2 collection inside 20 steps of ~1 ms is a quarter of the timed region)
+    host_t = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+        host_t.append(time.perf_counter())
     if phase["ex"] is not None:
         phase["ex"].wait_rest()
         phase["ex"] = None
@@ -450,6 +455,9 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    gc.enable()
+    host_gaps = [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_t[:-1], host_t)]
+    log(f"host ms per step() call: {host_gaps}; drain {(t1 - host_t[-1]) * 1e3:.3f} ms")
     prof = R.profile_report() if not args.graph else {}
     R.profile_enable(0)
     exchange_ms = bucket.exchange_ms() if bucket is not None else None      # the last timed step's collective(s)
