@@ -397,6 +397,15 @@ int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int
                                size_t ws_bytes, int32_t device, trase_stream_t stream);
 int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
                                 const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream);
+/* The combination train.py:235-238 forms with scalar tensor arithmetic, `(1 - lambda_dssim) * Ll1 + lambda_dssim * (1 - ssim(image,
+ * gt))`, inside the same two launches: out3 = {l1, ssim, loss} (device floats); the backward takes ONE cotangent g = dL/dloss (a
+ * device float) and scales it by (1 - lambda) and -lambda itself -- the ~10 scalar kernels autograd launches for the composition
+ * (and their host time) disappear.  lambda_dssim in [0, 1]. */
+int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                                   float* out3, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
+int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                                    const float* g, const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device,
+                                    trase_stream_t stream);
 
 /* ---- contrastive pixel-pair losses (second half) -------------------------------------------
  * positive_pixel_pair_loss / negative_pixel_pair_loss (utils/loss_utils.py:396-406), selected by

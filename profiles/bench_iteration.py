@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trase_amd import rasterizer as R
 from trase_amd.synthetic import make_scene, orbit_camera, SynthGaussianModel, SynthPipe, SynthDeformNetwork
 from trase_amd.deform import DeformNetworkHIP
-from trase_amd.losses import l1_ssim
+from trase_amd.losses import photometric_loss
 from trase_amd.optim import FusedAdam
 from trase_amd.densify import add_densification_stats
 from trase_amd.renderer import render
@@ -64,8 +64,7 @@ def main():
         t = cam.fid.reshape(1, 1).expand(N, -1)            # train.py:186-196: a stride-0 view of the camera's device-resident fid
         d_xyz, d_rot, d_scale = hip_net(pc.get_xyz.detach(), t)
         out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)
-        l1, ss = l1_ssim(out["render"], gts[i % 2])
-        (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+        photometric_loss(out["render"], gts[i % 2], 0.2).backward()
         return out["viewspace_points"], out["radii"]
 
     def all_hip_full(i):

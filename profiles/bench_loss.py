@@ -6,7 +6,7 @@ import sys, os, time, json, math
 import torch
 import torch.nn.functional as Fn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from trase_amd.losses import l1_ssim
+from trase_amd.losses import l1_ssim, photometric_loss
 from trase_amd import rasterizer as R
 
 
@@ -46,13 +46,18 @@ def main():
         l1, ss = l1_ssim(x, y)
         (0.8 * l1 + 0.2 * (1 - ss)).backward()
 
+    def hip_one_node():
+        x.grad = None
+        photometric_loss(x, y, 0.2).backward()
+
     ref(); g_ref = x.grad.clone()
     hip(); g_hip = x.grad.clone()
     R.profile_enable(1)
     for _ in range(5):
         hip()
     prof = R.profile_report(); R.profile_enable(0)
-    print(json.dumps({"shape": [3, 1080, 1920], "hip_fwd_bwd_ms": round(timed(hip), 4), "torch_fwd_bwd_ms": round(timed(ref), 4),
+    print(json.dumps({"shape": [3, 1080, 1920], "hip_fwd_bwd_ms": round(timed(hip), 4), "hip_one_node_fwd_bwd_ms": round(timed(hip_one_node), 4),
+                      "hip_fwd_bwd_ms_again": round(timed(hip), 4), "hip_one_node_fwd_bwd_ms_again": round(timed(hip_one_node), 4), "torch_fwd_bwd_ms": round(timed(ref), 4),
                       "kernels_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
                       "max_rel_grad_diff": float((g_hip - g_ref).abs().max() / g_ref.abs().max())}))
 

@@ -540,6 +540,40 @@ def test_fused_l1_ssim_matches_reference_golden_and_torch():
         del xi, li, si
 
 
+def test_photometric_loss_is_the_reference_combination_in_one_node():
+    """trase_loss_photometric_forward / _backward (trase_amd.losses.photometric_loss): train.py:235-238's
+    `(1 - lambda) * Ll1 + lambda * (1 - ssim)` against the golden total and gradient of the imported reference
+    (tests/golden/losses.npz) and, bit for bit, against the same combination formed with tensor arithmetic around l1_ssim --
+    also with a cotangent other than 1 (a loss that is scaled before backward)."""
+    import os
+    from trase_amd.losses import l1_ssim, photometric_loss
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+    a = torch.from_numpy(d["a"]).cuda().requires_grad_(True)
+    b = torch.from_numpy(d["b"]).cuda()
+    total, l1, ss = photometric_loss(a, b, 0.2, with_parts=True)
+    total.backward()
+    assert abs(float(total.detach()) - float(d["total"])) < 1e-5
+    assert abs(float(l1) - float(d["l1"])) < 1e-5 and abs(float(ss) - float(d["ssim"])) < 1e-5
+    assert not l1.requires_grad and not ss.requires_grad
+    want = torch.from_numpy(d["grad_a"]).cuda()
+    assert float((a.grad - want).abs().max()) < 1e-5 * float(want.abs().max())
+    torch.manual_seed(5)
+    x = torch.rand(3, 77, 131, device="cuda")
+    y = (x + 0.15 * torch.randn_like(x)).clamp(0, 1)
+    for lam, scale in ((0.2, 1.0), (0.35, 3.0), (0.0, 1.0), (1.0, 0.5)):
+        xa = x.clone().requires_grad_(True)
+        la, sa = l1_ssim(xa, y)
+        ta = (1.0 - lam) * la + lam * (1.0 - sa)
+        (ta * scale).backward()
+        xb = x.clone().requires_grad_(True)
+        tb = photometric_loss(xb, y, lam)
+        (tb * scale).backward()
+        assert torch.equal(ta.detach(), tb.detach()), (lam, float(ta), float(tb))
+        assert torch.equal(xa.grad, xb.grad), (lam, scale, float((xa.grad - xb.grad).abs().max()))
+    with pytest.raises(ValueError):
+        photometric_loss(x, y, 1.5)
+
+
 def _ref_soft_losses(C, C_F, pth, nth, w):
     """utils/loss_utils.py:304-349 restated (soft hard-positive + soft negative), PyTorch."""
     n = C_F.shape[0]

@@ -37,7 +37,7 @@ def make_gaussian_iteration(pc, cams, W: int, H: int, dev, image_scope: bool = T
     image_scope: the state never reads the feature map (train.py:211), so the forward composites colour + depth only
     (trase_amd.renderer.set_forward_scope("image")) and the backward takes the image-only MFMA scope."""
     from .deform import DeformNetworkHIP
-    from .losses import l1_ssim
+    from .losses import photometric_loss
     from .renderer import render, set_forward_scope
     from .synthetic import SynthPipe
     N = pc.get_xyz.shape[0]
@@ -60,8 +60,7 @@ def make_gaussian_iteration(pc, cams, W: int, H: int, dev, image_scope: bool = T
             out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)
         finally:
             set_forward_scope("all")
-        l1, ss = l1_ssim(out["render"], gts[i % 2])
-        (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+        photometric_loss(out["render"], gts[i % 2], 0.2).backward()      # train.py:235-238, lambda_dssim = 0.2 (arguments/__init__.py)
         return out
     return it
 

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   }
 }
 
+// lambda_dssim >= 0: out2 has a third slot that receives train.py:235-238's combination (1 - lambda) l1 + lambda (1 - ssim)
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int nblocks, float inv_count,
-                                                          float* __restrict__ out2) {
+                                                          float* __restrict__ out2, float lambda_dssim) {
   __shared__ double sh[2][256];
   double a = 0.0, b = 0.0;
   for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * 256) {   // eight pairs in flight; same summation order as one by one
@@ -148,13 +149,19 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
     if (threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out2[0] = (float)(sh[0][0] * inv_count); out2[1] = (float)(sh[1][0] * inv_count); }
+  if (threadIdx.x == 0) {
+    const float l1 = (float)(sh[0][0] * inv_count), ss = (float)(sh[1][0] * inv_count);
+    out2[0] = l1; out2[1] = ss;
+    if (lambda_dssim >= 0.f) out2[2] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss);
+  }
 }
 
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
                                                        LossWin win, const float* __restrict__ dmaps,
                                                        const float* __restrict__ g2 /* dL/dl1, dL/dssim */, float inv_count,
-                                                       float* __restrict__ d_img) {
+                                                       float* __restrict__ d_img, int g_stride, float s_l1, float s_ssim) {
+  // (g_stride 1, scales 1: the two cotangents as given; g_stride 0: ONE cotangent dL/dloss of the combined loss, scaled by
+  // d loss / d l1 = 1 - lambda and d loss / d ssim = -lambda -- the products autograd's scalar chain would have formed)
   __shared__ float sd[3][LH][LH + 1];
   __shared__ float hb[3][LH][HP];
   const int c = blockIdx.z;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  const float wl = g2[0] * inv_count, ws = g2[1] * inv_count;
+  const float wl = (g2[0] * s_l1) * inv_count, ws = (g2[g_stride] * s_ssim) * inv_count;
   {
     const int q = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
     float acc[4][3];
@@ -263,11 +270,11 @@ int trase_loss_sizes(int32_t C, int32_t H, int32_t W, size_t* ws_bytes) {
   return TRASE_OK;
 }
 
-int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, void* ws,
-                               size_t ws_bytes, int32_t device, trase_stream_t stream_) {
-  if (!img || !gt || !out2 || C < 1 || H < 1 || W < 1) { set_error("trase_loss_l1_ssim_forward: bad arguments"); return TRASE_ERR_INVALID; }
+static int loss_forward(const char* who, const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, float lambda_dssim,
+                        void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (!img || !gt || !out2 || C < 1 || H < 1 || W < 1) { set_error("%s: bad arguments", who); return TRASE_ERR_INVALID; }
   int nblocks = 0;
-  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, &nblocks)) { set_error("trase_loss_l1_ssim_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, &nblocks)) { set_error("%s: workspace too small", who); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
   float* dmaps = (float*)ws;
@@ -280,26 +287,51 @@ int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int
   TRASE_POST_LAUNCH("ssim_fwd", stream, 0);
   {
     ProfScope ps("loss_reduce", stream);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, 1.0f / ((float)C * H * W), out2);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, 1.0f / ((float)C * H * W), out2,
+                       lambda_dssim);
   }
   TRASE_POST_LAUNCH("loss_reduce", stream, 0);
   return TRASE_OK;
 }
 
-int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
-                                const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream_) {
-  if (!img || !gt || !g2 || !dL_dimg || C < 1 || H < 1 || W < 1) { set_error("trase_loss_l1_ssim_backward: bad arguments"); return TRASE_ERR_INVALID; }
-  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, nullptr)) { set_error("trase_loss_l1_ssim_backward: workspace too small"); return TRASE_ERR_WORKSPACE; }
+int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, void* ws,
+                               size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  return loss_forward("trase_loss_l1_ssim_forward", img, gt, C, H, W, out2, -1.0f, ws, ws_bytes, device, stream_);
+}
+
+int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim, float* out3,
+                                   void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
+  if (!(lambda_dssim >= 0.f && lambda_dssim <= 1.f)) { set_error("trase_loss_photometric_forward: lambda_dssim outside [0, 1]"); return TRASE_ERR_INVALID; }
+  return loss_forward("trase_loss_photometric_forward", img, gt, C, H, W, out3, lambda_dssim, ws, ws_bytes, device, stream_);
+}
+
+static int loss_backward(const char* who, const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2, int g_stride,
+                         float s_l1, float s_ssim, const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device,
+                         trase_stream_t stream_) {
+  if (!img || !gt || !g2 || !dL_dimg || C < 1 || H < 1 || W < 1) { set_error("%s: bad arguments", who); return TRASE_ERR_INVALID; }
+  if (!ws || ws_bytes < loss_ws_bytes(C, H, W, nullptr)) { set_error("%s: workspace too small", who); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
   const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
   {
     ProfScope ps("ssim_bwd", stream);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, stream, img, gt, H, W, make_window(), (const float*)ws, g2,
-                       1.0f / ((float)C * H * W), dL_dimg);
+                       1.0f / ((float)C * H * W), dL_dimg, g_stride, s_l1, s_ssim);
   }
   TRASE_POST_LAUNCH("ssim_bwd", stream, 0);
   return TRASE_OK;
+}
+
+int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, const float* g2,
+                                const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device, trase_stream_t stream_) {
+  return loss_backward("trase_loss_l1_ssim_backward", img, gt, C, H, W, g2, 1, 1.0f, 1.0f, ws, ws_bytes, dL_dimg, device, stream_);
+}
+
+int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                                    const float* g, const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device,
+                                    trase_stream_t stream_) {
+  return loss_backward("trase_loss_photometric_backward", img, gt, C, H, W, g, 0, 1.0f - lambda_dssim, -lambda_dssim, ws, ws_bytes, dL_dimg,
+                       device, stream_);
 }
 
 }  // extern "C"

@@ -53,6 +53,53 @@ class _L1SSIM(torch.autograd.Function):
         return d_img, None
 
 
+class _Photometric(torch.autograd.Function):
+    """One scalar out, one cotangent in: the combination of train.py:235-238 inside the two loss launches."""
+
+    @staticmethod
+    def forward(ctx, img, gt, lambda_dssim):
+        lib = _lib.load()
+        dev = img.device
+        x = img.detach().float().contiguous()
+        y = gt.detach().float().contiguous()
+        c, h, w = x.shape
+        nbytes = C.c_size_t()
+        _lib.check(lib.trase_loss_sizes(c, h, w, C.byref(nbytes)), "trase_loss_sizes")
+        ws = _bytes(nbytes.value, dev)
+        out3 = torch.empty(3, device=dev)
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_loss_photometric_forward(_lib.ptr(x), _lib.ptr(y), c, h, w, float(lambda_dssim), _lib.ptr(out3),
+                                                      _lib.ptr(ws), ws.numel(), d, _stream(dev)), "trase_loss_photometric_forward")
+        ctx.save_for_backward(x, y, ws)
+        ctx.lam = float(lambda_dssim)
+        ctx.mark_non_differentiable(out3)
+        return out3[2], out3
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        lib = _lib.load()
+        x, y, ws = ctx.saved_tensors
+        dev = x.device
+        c, h, w = x.shape
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
+        d_img = torch.empty_like(x)
+        d = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(lib.trase_loss_photometric_backward(_lib.ptr(x), _lib.ptr(y), c, h, w, ctx.lam, _lib.ptr(g), _lib.ptr(ws), ws.numel(),
+                                                       _lib.ptr(d_img), d, _stream(dev)), "trase_loss_photometric_backward")
+        return d_img, None, None
+
+
+def photometric_loss(img: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2, with_parts: bool = False):
+    """``(1 - lambda_dssim) * l1_loss(img, gt) + lambda_dssim * (1 - ssim(img, gt))`` (train.py:235-238) as ONE autograd node: the
+    scalar composition happens inside the loss kernels (forward: in the reduction kernel; backward: the cotangent is scaled
+    in the SSIM backward kernel), so the ~10 one-element kernels PyTorch launches for the reference's two lines are gone.
+    with_parts: also return the detached (l1, ssim) scalars (train.py logs Ll1, :303)."""
+    _check(img, gt)
+    loss, parts = _Photometric.apply(img, gt, lambda_dssim)
+    return (loss, parts[0], parts[1]) if with_parts else loss
+
+
 def _check(img, gt):
     if img.device.type != "cuda":
         raise RuntimeError("trase_amd.losses runs on the GPU only (there is no CPU path)")
