@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference's PyTorch prep ops around GaussianRasterizer instead of the fused render()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-steps", type=int, default=200,
+                    help="untimed steps in front of the W warm-up steps: the GPU's clocks settle under sustained load only "
+                         "(reported as `preroll_steps` in the line; 0 = time a GPU that has just left the sizing pass)")
     ap.add_argument("--exchange-chunks", type=int, default=0,
                     help="Gaussian-index ranges of the overlapped gradient exchange (sink bucket): the all-reduce of a range "
                          "starts while the backward's per-Gaussian tail is still computing the next one; 1 = one all-reduce "
@@ -425,6 +428,12 @@ def main():
     if args.graph:
         for i in range(2 * n_views):      # every view's forward and backward sequence is captured once
             step(i)
+    # Pre-roll: the metric is the throughput of a training loop, i.e. of a GPU that has been busy for a while.  The clock governor
+    # needs ~a second of sustained load to settle (measured, one box, profiles/r5_bench_clock_state.txt: 20 timed steps right
+    # after the sizing pass 903-908 views/s; after 100 / 1000 more steps 904-916 / 916-925; 5 / 30 / 200 ms of idle in front
+    # of the timed steps 868-873 / 845-846 / 825-837).  These steps are untimed, like the W warm-up steps that follow them.
+    for i in range(args.preroll_steps):
+        step(i)
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -441,8 +450,8 @@ def main():
     if not args.graph:           # (a replayed launch graph has no per-kernel events: --graph takes the kernel times of the untimed pass below)
         R.profile_enable(2)      # HIP events around the compositing kernels only, on the launch stream
     import gc
-    gc.collect()
-    gc.disable()                 # (a generation-2 collection inside 20 steps of ~1 ms is a quarter of the timed region)
+    gc.disable()                 # no collector pause inside the 20-step window (NOT gc.collect(): tens of ms of idle GPU in front
+                                 # of the timed steps cost 7-9 %, see above)
     host_t = []
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -536,20 +545,20 @@ def main():
     if world == 1 and not tiles_mode and not args.no_iteration_window and not args.unfused and (N, W, H, F) == (300_000, 1920, 1080, 32):
         try:
             from trase_amd.bench_iterations import make_feature_iteration, make_gaussian_iteration, time_iterations
-            log("secondary window: 8 GAUSSIAN-state + 8 FEATURE-state iterations ...")
+            log("secondary window: 16 GAUSSIAN-state + 16 FEATURE-state iterations ...")
             cams8 = cams_dev[::2]
             it_g = make_gaussian_iteration(pc, cams8, W, H, device)
-            t_g = time_iterations(it_g, iters=8, warm=3)
+            t_g = time_iterations(it_g, iters=16, warm=40)
             it_f, restore = make_feature_iteration(pc, cams8, W, H, device)
             try:
-                t_f = time_iterations(it_f, iters=8, warm=3)
+                t_f = time_iterations(it_f, iters=16, warm=40)
             finally:
                 restore()
             iteration_ms = {"gaussian": round(t_g, 3), "feature": round(t_f, 3),
                             "what": "one whole training iteration without the optimizer step (train.py:157-303), all-HIP path: "
                                     "GAUSSIAN state = deformation MLP with gradients + render() (image scope) + L1/SSIM + backward; "
                                     "FEATURE state = MLP under no_grad + render(KNN-smoothed normalised features) + contrastive "
-                                    "head on 100 masks / 5000 sampled pixels + backward; 8 iterations each after 3 warm-ups"}
+                                    "head on 100 masks / 5000 sampled pixels + backward; 16 iterations each after 40 untimed ones (clocks settled, see preroll_steps)"}
             for p_ in params:
                 p_.grad = None
         except Exception as e:                                  # the headline line must not depend on the secondary window
@@ -592,7 +601,7 @@ def main():
             "metric": ("views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
                        else f"views/sec (fwd+bwd), {W}x{H}, {N} Gaussians, {F}-d feat") + (", one view tile-row sharded over the ranks" if tiles_mode else ""),
             "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "preroll_steps": args.preroll_steps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None,
             "dtype": "f32 (channel contractions: 3-product bf16-split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{'S4 headline' if (N, W, H, F) == (300_000, 1920, 1080, 32) else 'custom'}: {N} Gaussians, {W}x{H}, F={F}, SH deg 3, one view per step per GPU"

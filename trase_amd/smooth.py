@@ -35,7 +35,12 @@ class _SmoothFeatures(torch.autograd.Function):
         P, K = idx.shape
         F = feats.shape[-1]
         f2 = feats.detach().reshape(P, F).float().contiguous()
-        sel_dev = sel.to(device=dev, dtype=torch.int32).contiguous()
+        if sel.device.type == "cpu":
+            # (a copy from pageable host memory blocks the host until the stream has drained -- once per iteration, in front of
+            # the whole render: through the pinned-memory cache the upload is asynchronous)
+            sel_dev = sel.to(torch.int32).contiguous().pin_memory().to(dev, non_blocking=True)
+        else:
+            sel_dev = sel.to(device=dev, dtype=torch.int32).contiguous()
         S = int(sel_dev.numel())
         inv_norm = torch.empty(P, device=dev)
         out = torch.empty(P, F, device=dev)
