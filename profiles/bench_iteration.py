@@ -108,7 +108,7 @@ def main():
     R.set_sync(False, capacity=cap)
 
     def timed(fn, iters=16):
-        for i in range(4):
+        for i in range(30):
             fn(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

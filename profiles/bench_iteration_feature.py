@@ -123,7 +123,7 @@ def main():
     R.set_sync(False, capacity=cap)
 
     def timed(fn, iters=12):
-        for i in range(3):
+        for i in range(30):
             fn(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

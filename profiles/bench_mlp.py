@@ -12,7 +12,7 @@ from trase_amd import rasterizer as R
 
 
 def timed(fn, iters=10):
-    for _ in range(3):
+    for _ in range(30):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

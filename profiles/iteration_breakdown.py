@@ -24,7 +24,7 @@ caps = []
 for i in range(8):
     it(i); caps.append(R.last_status()[2])
 R.set_sync(False, capacity=int(max(caps) * 1.25) + 1024)
-ms = time_iterations(it, iters=16, warm=4)
+ms = time_iterations(it, iters=16, warm=40)
 R.profile_enable(1)
 for i in range(8):
     it(i)
