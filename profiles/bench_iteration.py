@@ -51,9 +51,11 @@ def main():
 
     # the rest of the iteration (train.py:361-389): densification statistics + the two optimizer steps
     lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-2, 5e-3, 1e-3, 2.5e-3]
-    groups = lambda: [{"params": [p], "lr": lr, "name": str(k)} for k, (p, lr) in enumerate(zip(pc.parameters(), lrs))]
-    opt_hip = [FusedAdam(groups(), lr=0.0, eps=1e-15), FusedAdam(list(net.parameters()), lr=8e-4, eps=1e-15)]
-    opt_ref = [torch.optim.Adam(groups(), lr=0.0, eps=1e-15), torch.optim.Adam(list(net.parameters()), lr=8e-4, eps=1e-15)]
+    # (learning rates 0: the update arithmetic is the same, but the scene -- fitted to random targets otherwise -- stays the
+    # one that was sized; with the real rates the pair count drifts with the number of warm-up iterations)
+    groups = lambda: [{"params": [p], "lr": 0.0 * lr, "name": str(k)} for k, (p, lr) in enumerate(zip(pc.parameters(), lrs))]
+    opt_hip = [FusedAdam(groups(), lr=0.0, eps=1e-15), FusedAdam(list(net.parameters()), lr=0.0, eps=1e-15)]
+    opt_ref = [torch.optim.Adam(groups(), lr=0.0, eps=1e-15), torch.optim.Adam(list(net.parameters()), lr=0.0, eps=1e-15)]
     from types import SimpleNamespace
     stats = SimpleNamespace(xyz_gradient_accum=torch.zeros(N, 1, device=dev), denom=torch.zeros(N, 1, device=dev),
                             max_radii2D=torch.zeros(N, device=dev))
