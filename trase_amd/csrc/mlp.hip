@@ -1076,8 +1076,7 @@ static MlpBwdPlan mlp_bwd_plan(void* base, int N) {
   p.live_list = (int*)c;  c += align_up(sizeof(int) * (tiles + 1));
   p.n_live = (int*)c;     c += align_up(sizeof(int) * 4);
   // one workgroup per CU for the big GEMMs (252 = 7 x 36), more and shorter ones for the narrow jobs
-  static const int gh_env = [] { const char* e = getenv("TRASE_MLP_GH"); return e ? atoi(e) : 0; }();
-  const int gh_max = gh_env > 0 ? gh_env : 36;
+  const int gh_max = 36;
   p.Gh = (int)(tiles < (size_t)gh_max ? tiles : gh_max); p.Gp = (int)(tiles < 128 ? tiles : 128);
   p.Gd = p.Gp;
   if (p.Gh < 1) p.Gh = p.Gp = p.Gd = 1;
