@@ -540,6 +540,37 @@ def test_fused_l1_ssim_matches_reference_golden_and_torch():
         del xi, li, si
 
 
+@pytest.mark.parametrize("feat", [16, 0])
+@pytest.mark.parametrize("rows", [None, (1, 4)])
+def test_image_only_cotangent_with_narrow_features_mfma_vs_valu_backward(feat, rows):
+    """with no feature cotangent the backward takes the image-only MFMA scope whatever the forward's feature width
+    -- also for F = 16 / 0, whose FORWARD is the packed-FP32 kernel (a different formulation of the blend exponent).  The
+    gradients must agree with the packed-FP32 backward (TRASE_VARIANT_VALU_BACKWARD) on the whole image and on a tile-row
+    strip: same lists, same gates (n_contrib), sums in a different order -- 2e-5 of each gradient's scale."""
+    import contextlib
+    from tests.util import settings_for, small_case
+    from trase_amd import rasterizer as R
+    act, cam = small_case(n=900, w=144, h=96, feat=feat, seed=3)
+    st = settings_for(cam)
+    gi = torch.randn(3, 96, 144, generator=torch.Generator().manual_seed(11)).cuda()
+    v0 = R._Policy.variant
+    got = {}
+    try:
+        for name, bit in (("mfma", 0), ("valu", 0x40)):
+            R.set_variant(v0 | bit)
+            with (R.tile_rows(*rows) if rows else contextlib.nullcontext()):
+                out, leaves = _gpu_call(act, st)
+                torch.autograd.backward([out[0]], [gi])
+            got[name] = {k: v.grad.clone() for k, v in leaves.items() if v is not None and v.grad is not None}
+    finally:
+        R.set_variant(v0)
+    assert set(got["mfma"]) == set(got["valu"]) and "means3D" in got["mfma"]
+    for k in got["valu"]:
+        a, b = got["mfma"][k], got["valu"][k]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-12) + 1e-9, (k, float((a - b).abs().max()), scale)
+
+
 def test_photometric_loss_is_the_reference_combination_in_one_node():
     """trase_loss_photometric_forward / _backward (trase_amd.losses.photometric_loss): train.py:235-238's
     `(1 - lambda) * Ll1 + lambda * (1 - ssim)` against the golden total and gradient of the imported reference

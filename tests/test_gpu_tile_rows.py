@@ -87,3 +87,48 @@ def test_operator_level_strip_and_empty_strip():
         none = GaussianRasterizer(st)(**kw)
     assert float(none[0].abs().sum()) == 0 and torch.equal(none[1], full[1])
     assert R._Policy.tile_rows == (0, 0)
+
+
+@pytest.mark.parametrize("feat,image_only", [(32, False), (32, True), (16, False), (0, True)])
+def test_strips_through_the_operator_entry_point(feat, image_only):
+    """Tile-row strips through GaussianRasterizer (trase_rast_forward / trase_rast_backward, not the fused render()): the strips'
+    outputs reassemble the whole image and their gradients sum to the whole image's.  Round 5: this entry point's backward
+    reduced the gradient rows of all P depth ranks although a strip forward sorts only the Gaussians with a pair in the strip
+    -- ids read from the unsorted tail, a GPU memory fault; found by the image-only / F = 16 test ADVICE r4 asked for."""
+    from tests import test_gpu_parity as T
+    from tests.util import settings_for, small_case
+    from trase_amd import rasterizer as R
+    H, W = 96, 144
+    act, cam = small_case(n=900, w=W, h=H, feat=feat, seed=5)
+    st = settings_for(cam)
+    g = torch.Generator().manual_seed(3)
+    gi = torch.randn(3, H, W, generator=g).cuda()
+    gf = torch.randn(max(feat, 1), H, W, generator=g).cuda()
+
+    def run(rows):
+        with R.tile_rows(*rows):
+            out, leaves = T._gpu_call(act, st)
+            if image_only or feat == 0:
+                torch.autograd.backward([out[0]], [gi])
+            else:
+                torch.autograd.backward([out[0], out[2]], [gi, gf])
+        grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in leaves.items() if v is not None}
+        return [o.detach().clone() for o in (out[0], out[2], out[3])], grads
+
+    full_out, full_g = run((0, 0))
+    acc = {k: (torch.zeros_like(v) if v is not None else None) for k, v in full_g.items()}
+    for (b, e) in ((0, 2), (2, 3), (3, 6)):
+        outs, gs = run((b, e))
+        y0, y1 = 16 * b, min(16 * e, H)
+        for o, f in zip(outs, full_out):
+            if o.numel():
+                assert torch.equal(o[..., y0:y1, :], f[..., y0:y1, :]), f"strip {b, e}: pixels differ from the whole image"
+        for k, v in gs.items():
+            if v is not None:
+                acc[k] += v
+    for k, v in full_g.items():
+        if v is None:
+            assert acc[k] is None
+            continue
+        scale = float(v.abs().max())
+        assert float((acc[k] - v).abs().max()) <= 2e-5 * max(scale, 1e-12) + 1e-9, (k, float((acc[k] - v).abs().max()), scale)

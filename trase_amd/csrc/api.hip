@@ -477,7 +477,16 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
     rc = launch_render_bwd_gs(c, *s, in2, g, b, im, g2, rows, row_flags, out->depth);
   }
   if (rc) return rc;
-  rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs);
+  // a tile-row strip: the forward compacted the ids of the Gaussians with a pair in the strip in front of the depth order and
+  // sorted only those -- the ranks behind them hold nothing.  The reduction walks the live ranks only (round 5: it used to walk
+  // all P and read ids out of the unsorted tail: a memory fault for strips through THIS entry point; the raw entry point
+  // always did this); the rows it does not write -- Gaussians without a pair: zero gradient -- start at zero.
+  const int live_only = strip_mode(s) ? 1 : 0;
+  if (live_only) {
+    launch_zero_bytes(acc, sizeof(float) * BWD_ACC * (size_t)in->P, stream);
+    if (g2.dL_dsh_objs) launch_zero_bytes(g2.dL_dsh_objs, sizeof(float) * (size_t)in2.F * in->P, stream);
+  }
+  rc = launch_reduce_rows(c, g, pre, in->P, in2.F, rows, row_flags, acc, g2.dL_dsh_objs, nullptr, 0, -1, -1, live_only);
   if (rc) return rc;
   return launch_preprocess_bwd(c, *s, *in, out->radii, g, acc, *gr);
 }
