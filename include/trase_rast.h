@@ -86,7 +86,8 @@ typedef enum TraseVariant {
   TRASE_VARIANT_FEATURES_ONLY_BWD = 0x400,   /* F = 32: only dL/dsh_objs is produced (FEATURE state once densification has
                                               * ended); every other gradient is written as zeros */
   /* -- cross-check formulations (same results to fp32 rounding; the tests compare the MFMA kernels against them) -- */
-  TRASE_VARIANT_VALU_BACKWARD = 0x40,        /* packed-FP32 compositing backward (render_bwd_gs.hip) also for F = 32 */
+  TRASE_VARIANT_VALU_BACKWARD = 0x40,        /* packed-FP32 compositing backward (render_bwd_gs.hip) also for F = 32 (ignored under
+                                              * TRASE_VARIANT_FEATURES_ONLY_BWD: that scope exists in the MFMA backward only) */
   TRASE_VARIANT_VALU_FORWARD = 0x2000,       /* packed-FP32 compositing forward (render.hip) also for F = 32 */
   TRASE_VARIANT_SLOT_LISTS = 0x100000,       /* sub-tile lists always carry emit-order slots (default: packed (id, pair index)
                                               * values whenever every Gaussian has few enough pairs -- decided on the device,

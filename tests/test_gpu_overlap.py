@@ -69,6 +69,35 @@ def test_ranged_tail_equals_the_single_call_bit_for_bit(chunks):
         assert torch.equal(p.grad, r)
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_sink_with_grads_still_attached_accumulates_instead_of_doubling(chunks):
+    """A FlatGradBucket hands its slices out as ``.grad`` when it is built.  With the sink set and those ``.grad`` still in place
+    (the accumulate-mode loop: ``bucket.zero()`` instead of ``p.grad = None``) the backward used to return the SAME bytes as the
+    incoming gradient, and AccumulateGrad added the buffer to itself: every gradient doubled, silently.  Now the backward notices
+    that ``.grad`` is the sink buffer and returns a fresh tensor: the bucket ends up with the plain gradients (and with their sum
+    over two backwards)."""
+    from trase_amd.dp import FlatGradBucket
+    from trase_amd.renderer import set_grad_sink
+    pc, pipe, cam, dev = _scene()
+    params = pc.parameters()
+    for p in params:
+        p.grad = None
+    _backward(pc, pipe, cam, dev)
+    ref = [p.grad.clone() for p in params]
+    bucket = FlatGradBucket(params)              # p.grad = the bucket's slices, zero
+    try:
+        set_grad_sink(**bucket.overlapped(chunks)) if chunks > 1 else set_grad_sink(bucket.sink())
+        _backward(pc, pipe, cam, dev)
+        assert bucket.adopted()
+        for p, r in zip(params, ref):
+            assert torch.equal(p.grad, r), "a gradient was not accumulated once"
+        _backward(pc, pipe, cam, dev)            # no zero in between: the sum of two backwards
+        for p, r in zip(params, ref):
+            assert torch.equal(p.grad, r + r)
+    finally:
+        set_grad_sink(None)
+
+
 def test_overlapped_exchange_through_a_one_rank_rccl_group():
     import torch.distributed as dist
     from trase_amd.dp import FlatGradBucket

@@ -249,6 +249,10 @@ static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const
 // A tile-row strip (second axis) leaves most Gaussians without a pair: their ids are compacted away before the
 // depth sort (binning.hip launch_compact_live), so that the per-Gaussian stages cost what the strip holds, not what the scene does
 static inline bool strip_mode(const TraseRastSettings* s) { return s->tile_row_begin != 0 || s->tile_row_end != 0; }
+// the packed-FP32 cross-check backward knows no scopes: the features-only scope is a property of the MFMA backward and wins
+static inline bool valu_backward(const TraseRastSettings* s) {
+  return (s->variant & TRASE_VARIANT_VALU_BACKWARD) != 0 && (s->variant & TRASE_VARIANT_FEATURES_ONLY_BWD) == 0;
+}
 
 // depth order of the Gaussians (stable sort of the float32 depth bits; ties keep ascending Gaussian index) + the scan of their
 // sub-tile counts in that order.  `keys` = where the preprocess kernel left the keys (strip mode: the sort's SECOND buffer)
@@ -470,7 +474,7 @@ static int backward_impl(const TraseRastSettings* s, const TraseRastInputs* in, 
   // phase 1: one gradient row per (sub-tile, Gaussian) pair, written to the pair's emit-order slot;
   // phase 2: every Gaussian sums its contiguous rows.  No atomics, bit-reproducible.
   // F == 0 here also means "no feature cotangent" (GAUSSIAN-state iterations): the MFMA kernel's image-only scope
-  if ((in2.F == 32 || in2.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+  if ((in2.F == 32 || in2.F == 0) && !valu_backward(s)) {
     rc = launch_render_bwd_hw(c, *s, in2, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
   } else {
     launch_zero_bytes(row_flags, (size_t)ws->capacity, stream);
@@ -678,7 +682,7 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
   if (phase & 1) {
     if (no_feat_cotangent && gr->dL_dgaussian_features && raw->F > 0 && !sparse)
       launch_zero_bytes(gr->dL_dgaussian_features, sizeof(float) * (size_t)raw->F * raw->P, stream);
-    if ((in.F == 32 || in.F == 0) && !(s->variant & TRASE_VARIANT_VALU_BACKWARD)) {
+    if ((in.F == 32 || in.F == 0) && !valu_backward(s)) {
       rc = launch_render_bwd_hw(c, *s, in, g, b, im, g2, rows, row_flags, align_up((size_t)ws->capacity), out->depth);
     } else {
       launch_zero_bytes(row_flags, (size_t)ws->capacity, stream);

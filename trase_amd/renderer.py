@@ -270,6 +270,12 @@ class _RenderRaw(torch.autograd.Function):
                 ref, buf = ent
                 p = ref()
                 if p is not None and id(p) == pid[name] and buf.shape == like.shape and buf.device == like.device:
+                    if p.grad is not None and p.grad.data_ptr() == buf.data_ptr():
+                        # .grad already IS the sink buffer (a FlatGradBucket hands its slices out as .grad when it is built, and
+                        # bucket.zero() keeps them there): autograd will ACCUMULATE into it, and handing the same bytes out as
+                        # the incoming gradient would add the buffer to itself -- silently doubled gradients (round 5, found by
+                        # a combination sweep).  A fresh tensor instead: the sum lands in the bucket through AccumulateGrad.
+                        return torch.empty_like(like)
                     used_sink.add(pid[name])
                     # a FRESH view object: autograd's AccumulateGrad then adopts it as .grad without a copy (it clones a
                     # gradient that somebody else still references), so the gradient is written once, in place, into the
