@@ -249,3 +249,62 @@ def test_random_render_option_combinations_agree_with_the_plain_call(seed):
                 close(g_vsp, b_vsp, tag + " viewspace grads")
         finally:
             R.set_sync(True); R.set_graph("auto"); R.set_variant(0); R.set_lineage(); RR.set_backward_scope("all"); R.set_sparse_strip_grads(False)
+
+
+def test_degenerate_gaussians_neither_fault_nor_hang():
+    """NaN / inf / 1e30 positions, zero, negative, NaN and 1e6 scales, zero and NaN quaternions, opacity 0 / 1 / NaN, NaN colours and
+    features, Gaussians at and behind the camera -- on 2 %, 20 % or all of the Gaussians, under both capacity policies: the call
+    completes (NaNs may come out; the reference's kernels tolerate such inputs too), radii are never negative and the binned pair
+    count stays within Gaussians x sub-tiles.  360 cases of this sweep ran once with scratch seeds."""
+    from tests import test_gpu_parity as T
+    from tests.util import settings_for, small_case
+    from trase_amd import rasterizer as R
+    rng = random.Random(2)
+    Hh, Ww = 96, 160
+    kinds = ["nan_pos", "inf_pos", "zero_scale", "huge_scale", "zero_quat", "op0", "op1", "nan_op", "nan_feat", "at_camera", "behind",
+             "nan_scale", "neg_scale", "nan_quat", "huge_pos", "nan_sh"]
+    for it in range(30):
+        n = rng.choice([1, 40, 600, 2500])
+        act, cam = small_case(n=n, w=Ww, h=Hh, feat=32, seed=rng.randrange(100))
+        frac = rng.choice([0.02, 0.2, 1.0])
+        chosen = rng.sample(kinds, rng.choice([1, 2, 4]))
+        g = torch.Generator().manual_seed(it)
+        cc = cam.camera_center.reshape(1, 3)
+        for kind in chosen:
+            m = torch.rand(n, generator=g) < frac
+            if kind == "nan_pos": act["means3D"][m] = float("nan")
+            if kind == "inf_pos": act["means3D"][m] = float("inf")
+            if kind == "huge_pos": act["means3D"][m] = 1e30
+            if kind == "zero_scale": act["scales"][m] = 0.0
+            if kind == "huge_scale": act["scales"][m] = 1e6
+            if kind == "nan_scale": act["scales"][m] = float("nan")
+            if kind == "neg_scale": act["scales"][m] = -act["scales"][m]
+            if kind == "zero_quat": act["rotations"][m] = 0.0
+            if kind == "nan_quat": act["rotations"][m] = float("nan")
+            if kind == "op0": act["opacities"][m] = 0.0
+            if kind == "op1": act["opacities"][m] = 1.0
+            if kind == "nan_op": act["opacities"][m] = float("nan")
+            if kind == "nan_feat": act["sh_objs"][m] = float("nan")
+            if kind == "nan_sh": act["shs"][m] = float("nan")
+            if kind == "at_camera": act["means3D"][m] = cc.expand(int(m.sum()), 3)
+            if kind == "behind": act["means3D"][m] = cc + (cc - act["means3D"][m])
+        sync = rng.choice([True, False])
+        print(f"[{it}] n={n} frac={frac} kinds={chosen} sync={sync}", flush=True)
+        st = settings_for(cam)
+        gi = torch.randn(3, Hh, Ww, generator=g).cuda()
+        gf = torch.randn(32, Hh, Ww, generator=g).cuda()
+        R.set_sync(True)
+        try:
+            if not sync:
+                T._gpu_call(act, st, need_grad=False)
+                R.set_sync(False, capacity=2 * max(R.last_status()[2], 1) + 1024)
+            out, leaves = T._gpu_call(act, st)
+            torch.autograd.backward([out[0], out[2]], [gi, gf])
+            if not sync:
+                R.check_overflow()
+            torch.cuda.synchronize()
+            assert int(out[1].min()) >= 0
+            if sync:
+                assert 0 <= R.last_status()[2] <= n * ((Hh // 8 + 1) * (Ww // 8 + 1))
+        finally:
+            R.set_sync(True)
