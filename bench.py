@@ -213,6 +213,12 @@ def main():
             port = so.getsockname()[1]
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    # TEST MODE (tests/test_gpu_bench_ranks.py): several ranks share the visible GPU(s) and talk over gloo -- every N > 1 code
+    # path of this file (bucket, exchange schedules, barrier, MAX over ranks, rank 0's line) runs on a one-GPU box; the line it
+    # prints says so and is not a measurement
+    shared_gpu_test = os.environ.get("TRASE_BENCH_SHARED_GPU_TEST") == "1"
+    if shared_gpu_test:
+        local_rank = local_rank % torch.cuda.device_count()
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -220,7 +226,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if shared_gpu_test:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     elif args.force_collectives:
         import socket
         import torch.distributed as dist
@@ -257,6 +266,11 @@ def main():
             args.exchange_chunks = recommended_chunks(bucket.bytes_per_step, max(world, 1), "direct" if args.exchange == "direct" else "ring") \
                 if (world > 1 and args.shard == "views") else 1
     args.exchange_chunks = max(args.exchange_chunks, 1)
+    if shared_gpu_test and world > 1:
+        # gloo completes an asynchronous all-reduce of a device tensor by copying the result back IN PLACE later, which bumps the
+        # tensor's version after FlatGradBucket noted it (its modified-after-hand-off check then fires); RCCL's in-place collective
+        # counts once, at the call.  The overlapped ranges are covered by the one-rank RCCL tests (tests/test_gpu_overlap.py).
+        args.exchange_chunks = 1
     use_sink = bucket is not None and not args.unfused and args.bucket != "accumulate"
     if use_sink:
         # the fused backward writes every gradient once, straight into the bucket: no zero-fill, no accumulation pass
@@ -598,7 +612,7 @@ def main():
         valu_frac = None if valu_insts is None else valu_insts * 4.0 / (N_SIMD * dom_ms * 1e-3 * CLOCK_HZ)
         out = {
             # BASELINE.json's metric names the S4 configuration; other sizes (parity-test configurations) say so
-            "metric": ("views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
+            "metric": ("TEST MODE (ranks share a GPU over gloo: not a measurement) " if shared_gpu_test else "") + ("views/sec (fwd+bwd), 1080p, 300k Gaussians, 32-d feat" if (N, W, H, F) == (300_000, 1920, 1080, 32)
                        else f"views/sec (fwd+bwd), {W}x{H}, {N} Gaussians, {F}-d feat") + (", one view tile-row sharded over the ranks" if tiles_mode else ""),
             "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "preroll_steps": args.preroll_steps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
