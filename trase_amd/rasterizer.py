@@ -174,6 +174,20 @@ class tile_rows:
         _Policy.tile_rows = self.saved
 
 
+class IterationSkipped(RuntimeError):
+    """Raised (by a LATER call: forward, check_overflow) when a sync-free forward turns out to have produced incomplete results
+    -- its pair buffer overflowed, or a 27-bit depth key saturated.  The remedy has already been applied (capacity grown / float
+    depth keys selected) and the guarded consumers of that iteration skipped it on the device, so a training loop can catch this
+    and simply go on::
+
+        try:
+            out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)
+        except rasterizer.IterationSkipped:
+            out = render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale)      # the report concerned an EARLIER iteration
+
+    A RuntimeError subclass: code that catches RuntimeError keeps working."""
+
+
 def _header_verdict(h, cap: int, what: str):
     """h: 32 int32 words of a geom header.  Grows the capacity; raises on overflow / tripped binning guards."""
     r_eff = int(h[2]) & 0xffffffff
@@ -183,13 +197,13 @@ def _header_verdict(h, cap: int, what: str):
         raise RuntimeError(f"trase_amd rasterizer: binning guard tripped in {what} (key flag {int(h[16])}, slot flag {int(h[20])})")
     if int(h[1]) >= 2:         # bit 1 (MAX-reduced over the ranks under data parallelism: any value >= 2): a saturated 27-bit depth key
         _Policy.variant |= VARIANT_DEPTH32
-        raise RuntimeError(f"trase_amd rasterizer: a Gaussian of {what} lies beyond the range of the 27-bit depth keys (view depth > "
+        raise IterationSkipped(f"trase_amd rasterizer: a Gaussian of {what} lies beyond the range of the 27-bit depth keys (view depth > "
                            f"13 107): that call's depth order was not exact beyond that distance.  This process now sorts on the raw "
                            f"float32 depth bits (rasterizer.set_depth_keys(32)).  Guarded consumers of that iteration "
                            f"(FusedAdam.step, add_densification_stats) skipped it on the device; unguarded ones have used its "
                            f"gradients: re-run the iteration, or call set_depth_keys(32) / set_sync(True) up front for such scenes.")
     if int(h[1]):
-        raise RuntimeError(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
+        raise IterationSkipped(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
                            f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
                            f"has been grown to {_Policy.capacity}.  Guarded consumers of that iteration (FusedAdam.step, "
                            f"add_densification_stats) skipped it on the device on every rank (under data parallelism the "
@@ -209,7 +223,7 @@ def _poll_pending(block: bool = False):
             undo = _Policy.rollbacks.pop(id(pin), [])
             try:
                 _header_verdict(pin.tolist(), cap, "a previous sync-free forward")
-            except RuntimeError as e:      # report the first, still drain the rest
+            except RuntimeError as e:      # (IterationSkipped or a tripped guard) report the first, still drain the rest
                 err = err or e
                 for fn in undo:            # host-side bookkeeping of steps the device skipped (Adam step counters)
                     fn()
