@@ -270,3 +270,45 @@ def test_baseline_configs_run_end_to_end_and_reproducibly(name, n, w, h, with_ml
         assert torch.isfinite(ga).all(), name
         assert float(ga.abs().max()) > 0 or (loss == "contrastive" and id(p) in colour), name
         assert torch.equal(ga, gb), name
+
+
+def test_fifty_million_gaussians_index_arithmetic_beyond_2_to_31():
+    """288 GB of HBM hold scenes whose tensors pass 2^31 ELEMENTS: at 50 M Gaussians `_features_rest` has 2.25e9 floats.  The
+    per-Gaussian forward state (pixel centre, conic + opacity, colour + depth, radii) of the LAST thousand Gaussians must be
+    bit-identical to the state the same thousand get as a scene of their own (every input tensor indexed with 64-bit arithmetic),
+    and the backward leaves finite gradients with the same non-zero rows in all seven tensors' tails.  ~60 GB of device memory."""
+    from gaussian_renderer import render
+    from trase_amd import rasterizer as R
+    from trase_amd.synthetic import SynthGaussianModel, SynthPipe, SynthScene, make_scene, orbit_camera
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).total_memory < 150e9:
+        pytest.skip("needs an MI355X-sized device")
+    N, K, W, H = 50_000_000, 1000, 960, 540
+    scene = make_scene(N, feat_dim=32, seed=0, scale_mult=0.27)
+    cam = orbit_camera(W, H, angle=0.3).to(dev)
+    pc = SynthGaussianModel(scene.to(dev))
+    bg = torch.zeros(3, device=dev)
+    out = render(cam, pc, SynthPipe(), bg, 0.0, 0.0, 0.0)
+    gv = R.last_geom_view(N)
+    big = {k: gv[k][N - K:].clone() for k in ("xy", "conic_opacity", "rgb_depth")}
+    radii = out["radii"][N - K:].clone()
+    g = torch.Generator().manual_seed(0)
+    gi, gf = torch.randn(3, H, W, generator=g).to(dev), torch.randn(32, H, W, generator=g).to(dev)
+    torch.autograd.backward([out["render"], out["render_gaussian_features"]], [gi, gf])
+    rows = None
+    for p in pc.parameters():
+        assert torch.isfinite(p.grad[N - 100_000:]).all()
+        nz = p.grad[N - K:].reshape(K, -1).abs().sum(1) > 0
+        rows = nz if rows is None else rows
+        assert torch.equal(nz, rows), "the tail rows that received a gradient differ between the parameter tensors"
+    assert int(rows.sum()) > 0 and bool((radii[rows] > 0).all())
+    del out, pc, gv
+    torch.cuda.empty_cache()
+    sub = SynthScene(*[t[N - K:].clone() for t in (scene.xyz, scene.features_dc, scene.features_rest, scene.scaling, scene.rotation,
+                                                     scene.opacity, scene.gaussian_features)])
+    out2 = render(cam, SynthGaussianModel(sub.to(dev)), SynthPipe(), bg, 0.0, 0.0, 0.0)
+    gv2 = R.last_geom_view(K)
+    vis = radii > 0
+    assert int(vis.sum()) > 100 and torch.equal(radii, out2["radii"])
+    for k in ("xy", "conic_opacity", "rgb_depth"):
+        assert torch.equal(big[k][vis], gv2[k][vis]), k
