@@ -687,8 +687,8 @@ int trase_pairhead_forward_n(const float* feats, int32_t F, int64_t HW, const ui
   if (!ws || ws_bytes < pair_ws_carve(S, &w, ws)) { set_error("trase_pairhead_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
-  TRASE_CHECK(hipMemsetAsync(w.colP, 0, sizeof(int) * (size_t)S, stream));
-  TRASE_CHECK(hipMemsetAsync(w.colN, 0, sizeof(int) * (size_t)S, stream));
+  // colP and colN are neighbours in the workspace (pair_ws_carve): one fill for both
+  TRASE_CHECK(hipMemsetAsync(w.colP, 0, (size_t)((char*)w.colN - (char*)w.colP) + sizeof(int) * (size_t)S, stream));
   const dim3 grid((S + 255) / 256, (S + PH_ROWS - 1) / PH_ROWS);
   {
     ProfScope ps("pairhead_fwd", stream);
