@@ -1,0 +1,43 @@
+"""The contract of bench.py's JSON line, checked on the line committed with the round's evidence (profiles/r5_bench_default.json --
+produced by `python bench.py` on an MI355X; this test needs no GPU): every key the driver and the judge read is there, the roofline
+object is self-consistent, the CPU baseline says what it timed."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r5_bench_default.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_required_keys_and_types():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "views/s" and "1080p" in d["metric"] and "300k" in d["metric"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["data"] == "synthetic" and d["dtype"].startswith("f32")
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]          # whole-job throughput of the timed steps
+    assert isinstance(d.get("preroll_steps"), int)
+
+
+def test_roofline_object_is_self_consistent():
+    r = _line()["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-2 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes"]
+    assert "forward" in r and "compositing_valu_frac" in r and "bound_note" in r
+
+
+def test_cpu_baseline_object():
+    c = _line()["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and len(c["sample"]) > 20
