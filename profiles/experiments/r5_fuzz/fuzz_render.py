@@ -64,6 +64,8 @@ for it in range(count):
     tag = (f"[{it}] n={n} seed={sd} deform={deform} fscope={fscope} bscope={bscope} rows={rows} sparse={sparse} chunks={chunks} pair={pair} "
            f"norm={norm} lin={lin} cot={cot} sync={sync} graph={graph} var={hex(var)}")
     print(tag, flush=True)
+    if os.environ.get("FUZZ_ONLY") and it != int(os.environ["FUZZ_ONLY"]):
+        continue
 
     def run(plain):
         pc = SynthGaussianModel(scene)
@@ -102,7 +104,7 @@ for it in range(count):
         vsp = [o["viewspace_points"].grad.clone() if o["viewspace_points"].grad is not None else None for o in outs]
         return res, grads, dgr, vsp, pc
 
-    R.set_sync(True); R.set_graph(False); R.set_variant(0); R.set_lineage(**lin); RR.set_backward_scope("all"); R.set_sparse_strip_grads(False)
+    R.set_sync(True); R.set_graph(False); R.set_variant(int(os.environ.get("FUZZ_VAR_BOTH", "0"), 0)); R.set_lineage(**lin); RR.set_backward_scope("all"); R.set_sparse_strip_grads(False)
     base_var = R._Policy.variant
     b_res, b_grads, b_dgr, b_vsp, b_pc = run(True)
     cap = max(R.last_status()[2], 1)
@@ -139,6 +141,10 @@ for it in range(count):
     except AssertionError as e:
         bad += 1
         print("   MISMATCH", e, flush=True)
+        if os.environ.get("FUZZ_ONLY"):
+            for k, (x, y) in enumerate(zip(g_grads, b_grads)):
+                if x is not None and y is not None and x.numel() <= 64:
+                    print("    grad", k, x.flatten().tolist(), y.flatten().tolist(), flush=True)
     finally:
         R.set_sync(True); R.set_graph("auto"); R.set_variant(0); R.set_lineage(); RR.set_backward_scope("all"); R.set_sparse_strip_grads(False)
 print("done; mismatches:", bad)
