@@ -439,9 +439,10 @@ int trase_contrastive_backward(const float* C, const float* C_F, const float* we
  * steps it.  The tables (pointers to device tensors, sizes, learning rates, steps) are HOST arrays. */
 /* ---- nearest-neighbour feature matching style loss (utils/loss_utils.py:223-228; train_style_transfer_nnfm.py:201-203) ----
  * loss = mean_i min_j (1 - cos(feat1[:, i], feats2[:, j])) for feat1 (C, N1), feats2 (C, N2) fp32, C a multiple of 64 up
- * to 512 (VGG conv4_1).  The N1 x N2 cosine matrix is never formed: bf16 MFMA GEMM with a running row maximum selects
- * the neighbour, its cosine is re-evaluated in fp32.  The backward differentiates through the arg-min w.r.t. feat1 only
- * (the style reference carries no graph).  `ws` from the forward is handed back to the backward unchanged. */
+ * to 512 (VGG conv4_1), N2 <= 2 097 152.  The N1 x N2 cosine matrix is never formed: a bf16 MFMA GEMM with a running
+ * two-entry row maximum short-lists two neighbours per row, fp32 cosines of the original data decide between them (ties ->
+ * lowest column).  The backward differentiates through the arg-min w.r.t. feat1 only (the style reference carries no
+ * graph).  `ws` from the forward is handed back to the backward unchanged. */
 int trase_nnfm_sizes(int32_t C, int32_t N1, int32_t N2, size_t* ws_bytes);
 int trase_nnfm_forward(const float* feat1, const float* feats2, int32_t C, int32_t N1, int32_t N2, float* loss, void* ws,
                        size_t ws_bytes, int32_t device, trase_stream_t stream);

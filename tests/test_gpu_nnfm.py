@@ -2,9 +2,10 @@
 train_style_transfer_nnfm.py:184-211.
 
 * fixture parity: tests/golden/nnfm.npz = the imported reference's loss_nnfm_style (utils/loss_utils.py:223-228) and its
-  autograd gradient.  The fused kernel selects the nearest neighbour with a bf16 GEMM and re-evaluates the matched cosine in
-  fp32, so the value is exact for the selected pair; a row whose best and second-best neighbours are closer than the bf16
-  resolution may legitimately pick the other one (the fixture records every row's margin).
+  autograd gradient.  The fused kernel short-lists the TWO nearest neighbours of a row with a bf16 GEMM and decides between
+  them with fp32 cosines of the original data, so a row follows the reference's neighbour unless the two are closer than fp32
+  rounding (the fixture records every row's margin; round 5: the single bf16 candidate sent ~0.8 % of the rows to the other
+  neighbour, `test_nnfm_every_row_follows_the_float64_neighbour`).
 * a config-5-sized iteration (2.5 M Gaussians, 1280x960) with a random conv stack standing in for VGG conv4_1 (no weights
   on the box): image-only cotangent, `set_background_zero_grad` cluster mask (scene/gaussian_model.py:155-157), Adam on
   f_dc / f_rest only (scene/gaussian_model.py:267-272)."""
@@ -30,8 +31,8 @@ def test_nnfm_matches_reference_fixture(name):
     loss.backward()
     got, want = f1.grad.cpu().numpy(), G[f"{name}_grad"]
     margin = G[f"{name}_margin"]
-    clear = margin > 1e-3                                   # rows whose nearest neighbour is unambiguous at bf16 resolution
-    assert clear.mean() > 0.5                               # (random 512-d features concentrate: many near-ties in "vgg")
+    clear = margin > 1e-6                                   # rows whose nearest neighbour is unambiguous at fp32 resolution
+    assert clear.mean() > 0.99
     scale = np.abs(want).max()
     assert np.abs(got[:, clear] - want[:, clear]).max() < 2e-5 * scale + 1e-9
     # ambiguous rows: still the gradient of SOME near-tied neighbour -- same magnitude, never garbage
@@ -39,6 +40,34 @@ def test_nnfm_matches_reference_fixture(name):
     # the scalar is deterministic
     f1b = torch.from_numpy(G[f"{name}_f1"]).to(dev)
     assert float(loss_nnfm_style(f1b, f2)) == float(loss)
+
+
+@pytest.mark.parametrize("c,n1,n2,relu", [(512, 1000, 777, False), (512, 4000, 3000, True), (64, 2000, 5000, False),
+                                          (256, 3000, 31, True), (128, 500, 1, False)])
+def test_nnfm_every_row_follows_the_float64_neighbour(c, n1, n2, relu):
+    """Random features concentrate: 7-12 % of the rows have a runner-up within 1e-3 of the best cosine, i.e. inside the
+    rounding of a bf16 product.  Every row whose float64 margin exceeds 1e-6 must carry the gradient of the float64 arg-min."""
+    from trase_amd.losses import loss_nnfm_style
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(c + n1 + n2)
+    a, b = torch.randn(c, n1, generator=g), torch.randn(c, n2, generator=g)
+    if relu:
+        a, b = torch.relu(a + 0.3), torch.relu(b + 0.3)
+    a, b = a.to(dev), b.to(dev)
+    bn = b.double() / b.double().norm(dim=0, keepdim=True)
+    xr = a.double().requires_grad_(True)
+    cos = (xr / xr.norm(dim=0, keepdim=True)).t() @ bn
+    ref = (1.0 - cos.max(dim=1).values).mean()
+    ref.backward()
+    top = cos.detach().topk(min(2, n2), dim=1).values
+    margin = top[:, 0] - top[:, -1] if n2 > 1 else torch.ones(n1, device=dev, dtype=torch.float64)
+    x = a.clone().requires_grad_(True)
+    loss = loss_nnfm_style(x, b)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 2e-7 * max(1.0, abs(float(ref))) + 1e-7
+    scale = float(xr.grad.abs().max())
+    row = (x.grad.double() - xr.grad).abs().amax(dim=0) / scale
+    assert int(((row > 1e-4) & (margin > 1e-6)).sum()) == 0, (int((row > 1e-4).sum()), float(margin[row > 1e-4].max()))
 
 
 def test_nnfm_never_materialises_the_cosine_matrix():
