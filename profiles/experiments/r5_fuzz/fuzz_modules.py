@@ -3,6 +3,7 @@ sizes), mask statistics, the pair head.  Prints each case first."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as Fn
+SEED = 1000 * int(sys.argv[1]) if len(sys.argv) > 1 else 0
 dev = torch.device("cuda", 0)
 bad = 0
 def rel(a, b):
@@ -24,7 +25,7 @@ def ref_ssim(x, y):
     return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
 for shape in [(3, 1, 1), (3, 2, 3), (3, 5, 7), (1, 11, 11), (3, 31, 33), (3, 32, 32), (3, 33, 31), (4, 64, 65), (2, 200, 1), (3, 1, 300), (3, 270, 480)]:
     print("loss", shape, flush=True)
-    torch.manual_seed(sum(shape))
+    torch.manual_seed(sum(shape) + SEED)
     x = torch.rand(*shape, device=dev); y = (x + 0.1 * torch.randn_like(x)).clamp(0, 1)
     xa = x.clone().requires_grad_(True)
     (0.8 * (xa - y).abs().mean() + 0.2 * (1 - ref_ssim(xa, y))).backward()
@@ -39,7 +40,7 @@ from trase_amd.smooth import smooth_features
 from pytorch3d.ops import knn_points
 for n, K, S in [(17, 16, 8), (20, 4, 4), (100, 16, 1), (1000, 16, 16), (5000, 8, 3), (33, 2, 1)]:
     print("smooth", n, K, S, flush=True)
-    g = torch.Generator().manual_seed(n)
+    g = torch.Generator().manual_seed(n + SEED)
     xyz = torch.rand(n, 3, generator=g).to(dev)
     feats = torch.randn(n, 1, 32, generator=g).to(dev)
     idx = knn_points(xyz.unsqueeze(0), xyz.unsqueeze(0), K=K).idx.squeeze(0)
@@ -56,7 +57,7 @@ for n, K, S in [(17, 16, 8), (20, 4, 4), (100, 16, 1), (1000, 16, 16), (5000, 8,
 # ---- NNFM
 for C_, n1, n2 in [(128, 1, 1), (64, 7, 5), (256, 100, 33), (512, 1000, 777), (64, 50, 2000), (192, 1, 300)]:
     print("nnfm", C_, n1, n2, flush=True)
-    g = torch.Generator().manual_seed(n1 + n2)
+    g = torch.Generator().manual_seed(n1 + n2 + SEED)
     a = torch.randn(C_, n1, generator=g).to(dev); b = torch.randn(C_, n2, generator=g).to(dev)
     aa = a.clone().requires_grad_(True)
     an = aa / (aa.norm(dim=0, keepdim=True) + 1e-8) if False else aa
@@ -75,7 +76,7 @@ for C_, n1, n2 in [(128, 1, 1), (64, 7, 5), (256, 100, 33), (512, 1000, 777), (6
 # ---- Adam: many tensors, odd sizes
 from trase_amd.optim import FusedAdam
 print("adam", flush=True)
-torch.manual_seed(0)
+torch.manual_seed(SEED)
 shapes = [(1,), (2,), (3,), (5, 1), (7, 3), (31,), (32,), (33,), (255,), (257, 3), (1000, 15, 3)] + [(k + 1, 2) for k in range(40)]
 a = [torch.randn(*s, device=dev).requires_grad_(True) for s in shapes]
 b = [t.detach().clone().requires_grad_(True) for t in a]
@@ -91,7 +92,7 @@ check("adam", all(rel(pb, pa) < 5e-6 for pa, pb in zip(a, b)), max(rel(pb, pa) f
 from trase_amd.feature_head import mask_stats, contrastive_head
 for N, H, W, rate in [(1, 8, 8, 0.5), (3, 17, 29, 0.3), (64, 33, 65, 0.1), (256, 40, 50, 0.05), (100, 270, 480, 0.002)]:
     print("head", N, H, W, flush=True)
-    g = torch.Generator().manual_seed(N + H)
+    g = torch.Generator().manual_seed(N + H + SEED)
     sam = (torch.rand(N, H, W, generator=g) < 0.3).to(dev)
     cover, size = mask_stats(sam)
     check("cover", torch.equal(cover.to(torch.int64), sam.sum(0).to(torch.int64)))
