@@ -96,6 +96,9 @@ typedef enum TraseVariant {
   TRASE_VARIANT_DEPTH32 = 0x400000,          /* depth sort on the raw float32 depth bits (four 8-bit passes) instead of the default 27-bit
                                               * key (three 9-bit passes, exact for view depth < 13 107): selected by the caller after a
                                               * forward has raised bit 1 of the header's overflow word (a saturated depth key) */
+  TRASE_VARIANT_FORWARD_ONLY = 0x800000,     /* a forward nobody will differentiate (torch.no_grad()): what only the backward reads -- per-Gaussian
+                                              * colour / clamp arrays, per-pixel final transmittance and contributor count -- is not stored.  A
+                                              * backward on such a forward's workspaces is refused */
   TRASE_VARIANT_SPARSE_STRIP_GRADS = 0x200000, /* trase_rast_backward_raw writes ONLY the gradient rows of the Gaussians that have a
                                               * pair in the strip (~1 / world of them); the caller guarantees that every other row
                                               * of the gradient tensors is zero -- persistent tensors, zero-filled once, whose
@@ -224,6 +227,20 @@ typedef struct TraseRastRawInputs {
   const float* d_rotation;          /* (P,4) or NULL */
   const float* gaussian_features;   /* (P,1,F) raw, or NULL when F == 0 */
   float* featn;                     /* (P,F) work buffer */
+  /* render()'s other call patterns, fused as well (round 6; every pointer may be NULL = not used):
+   *   colors_precomp   override_color= (gaussian_renderer/__init__.py:112-113; render.py:240,296,344, gui.py): (P,3) colours taken as
+   *                    they are -- no SH evaluation, features_dc / features_rest are not read and may be NULL;
+   *   mask             mask= (:123-135): (P) bytes, 0 removes the Gaussian from the view (the reference indexes every input by the
+   *                    mask).  out->radii and every gradient stay FULL size (P rows; rows of removed Gaussians: radii 0, gradients
+   *                    0 -- what the index's backward scatters); the caller compacts radii to the subset for render()'s dict;
+   *   d_xyz_se3        is_6dof (:75-80): (P,4,4) row-major transforms, means3D = from_homogenous(M [xyz, 1]); replaces d_xyz;
+   *   sh_dir_undeformed  != 0: pipe.convert_SHs_python (:103-108) -- the SH is evaluated in the direction of the UNDEFORMED xyz
+   *                    (the Python fallback uses pc.get_xyz there), colour clamp as in the rasterizer. */
+  const float* colors_precomp;
+  const uint8_t* mask;
+  const float* d_xyz_se3;
+  int32_t sh_dir_undeformed;
+  int32_t reserved1;
 } TraseRastRawInputs;
 
 typedef struct TraseRastRawGrads {
@@ -232,6 +249,8 @@ typedef struct TraseRastRawGrads {
   float* dL_dfeatures_dc; float* dL_dfeatures_rest; float* dL_dopacity;
   float* dL_dscaling; float* dL_dd_scaling; float* dL_drotation; float* dL_dd_rotation;
   float* dL_dgaussian_features;
+  float* dL_dcolors_precomp;        /* (P,3), with colors_precomp */
+  float* dL_dd_xyz_se3;             /* (P,4,4), with d_xyz_se3 */
 } TraseRastRawGrads;
 
 int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInputs* raw, const TraseRastOutputs* out,

@@ -48,6 +48,7 @@ def _run(n, w, h, pairwise, with_deform, seed=0):
         res = {"maps": [(o["render"].clone(), o["render_gaussian_features"].clone(), o["depth"].clone(), o["radii"].clone()) for o in outs],
                "grads": [p.grad.clone() for p in pc.parameters()],
                "m2d": [o["viewspace_points"].grad.clone() for o in outs],
+               "vis": [o["visibility_filter"].clone() for o in outs],
                "d": [[x.grad.clone() for x in dd] for dd in d] if with_deform else []}
     finally:
         R.set_sync(True)
@@ -63,6 +64,9 @@ def test_pair_forward_is_bit_identical_to_two_serial_views(n, w, h, with_deform)
         for x, y, name in zip(a["maps"][k], b["maps"][k], ("image", "features", "depth", "radii")):
             assert torch.equal(x, y), f"view {k}: {name} differs between render_views and two render() calls"
         assert torch.equal(a["m2d"][k], b["m2d"][k]), f"view {k}: viewspace gradient differs"
+        # the filter a training loop hands to add_densification_stats (it used to be formed before the deferred forward ran)
+        assert torch.equal(a["vis"][k], b["vis"][k]) and torch.equal(b["vis"][k], b["maps"][k][3] > 0), f"view {k}: visibility_filter"
+        assert bool(b["vis"][k].any())
     for i, (x, y) in enumerate(zip(a["grads"], b["grads"])):
         assert torch.equal(x, y), f"parameter {i}: gradient (sum over the two views) differs"
     for k in range(len(a["d"])):

@@ -1303,7 +1303,7 @@ def test_contrastive_head_without_the_count_read_back_equals_the_synchronising_h
         f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
         spx = sp.clone()
         if tagged:
-            spx._trase_expected_count = int(sp.sum())              # what the sampler aims at
+            spx._trase_expected_count = (int(sp.sum()), spx.numel(), spx._version)     # the sampler's tag: (target, pixels, version)
         lp, ln, ps, ns, reg = contrastive_head(f, sam, spx, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True,
                                                with_norm_reg=True)
         (lp + ln + reg).backward()
@@ -1313,12 +1313,28 @@ def test_contrastive_head_without_the_count_read_back_equals_the_synchronising_h
         assert abs(float(x) - float(y)) <= 1e-6 * max(abs(float(x)), 1e-6), (float(x), float(y))
     assert torch.equal(a[5], b[5])
     empty = torch.zeros_like(sp)
-    empty._trase_expected_count = 50
+    empty._trase_expected_count = (50, empty.numel(), empty._version)
     f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
     lp, ln, ps, ns = contrastive_head(f, sam, empty, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True)
     (lp + ln).backward()
     assert float(lp) == 0.0 and float(ln) == 0.0 and bool(torch.isnan(ps)) and bool(torch.isnan(ns))
     assert float(f.grad.abs().max()) == 0.0
+    # the tag describes the tensor AS DRAWN.  Edited in place afterwards (version moved on) the head must count for
+    # itself again; and a draw larger than the buffer its tag sized must be reported by a later call, not pass silently.
+    from trase_amd import feature_head as FH
+    edited = sp.clone()
+    edited._trase_expected_count = (1, edited.numel(), edited._version)       # a tag far too small for this mask ...
+    edited |= sp                                                               # ... but the tensor was edited in place: tag is void
+    f = torch.from_numpy(d["features"]).cuda().requires_grad_(True)
+    lp2, ln2, _, _ = contrastive_head(f, sam, edited, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True)
+    assert abs(float(lp2) - float(a[0])) <= 1e-6 * max(abs(float(a[0])), 1e-6)
+    FH.check_sampled_counts()
+    lying = sp.clone()
+    lying._trase_expected_count = (1, lying.numel(), lying._version)           # valid tag, 1 + 8 + 64 slots for thousands of pixels
+    if int(sp.sum()) > 80:
+        contrastive_head(f.detach(), sam, lying, sm, mode, float(d["positive_th"]), float(d["negative_th"]), True)
+        with pytest.raises(RuntimeError, match="index buffer held"):
+            FH.check_sampled_counts()
 
 
 @pytest.mark.parametrize("mode,use_w", [("soft", True), ("all", True), ("hard", True), ("soft", False)])

@@ -75,6 +75,8 @@ class RastRawInputs(C.Structure):
         ("xyz", C.c_void_p), ("d_xyz", C.c_void_p), ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
         ("opacity", C.c_void_p), ("scaling", C.c_void_p), ("d_scaling", C.c_void_p), ("rotation", C.c_void_p),
         ("d_rotation", C.c_void_p), ("gaussian_features", C.c_void_p), ("featn", C.c_void_p),
+        ("colors_precomp", C.c_void_p), ("mask", C.c_void_p), ("d_xyz_se3", C.c_void_p),
+        ("sh_dir_undeformed", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -85,6 +87,7 @@ class RastRawGrads(C.Structure):
         ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("dL_dopacity", C.c_void_p),
         ("dL_dscaling", C.c_void_p), ("dL_dd_scaling", C.c_void_p), ("dL_drotation", C.c_void_p),
         ("dL_dd_rotation", C.c_void_p), ("dL_dgaussian_features", C.c_void_p),
+        ("dL_dcolors_precomp", C.c_void_p), ("dL_dd_xyz_se3", C.c_void_p),
     ]
 
 

@@ -119,3 +119,47 @@ def time_iterations(fn, iters: int = 8, warm: int = 3) -> float:
         fn(i)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e3
+
+
+def capture_iteration(fn, warm: int = 3, arg: int = 0):
+    """One whole iteration (``fn(arg)``: forward, loss, backward -- every launch of it) captured into a ``torch.cuda.CUDAGraph``.
+    Returns ``(graph, out)``: ``graph.replay()`` re-runs the iteration on the buffers of the capture (``out`` = what ``fn``
+    returned, plus whatever ``.grad`` tensors the backward made: static tensors, refreshed by every replay).
+
+    What a capture freezes: every HOST-side decision of the iteration -- the pair capacity (use ``rasterizer.set_sync(False,
+    capacity=...)`` with headroom: an overflow is still flagged in the geom header and honoured by the guarded device-side
+    consumers, but the host never hears of it), the camera, the smoothing's neighbour-slot draw (a CPU ``randperm``).  Device-side
+    draws (``get_sample_pixel_and_mask(rng="cuda")``) advance with every replay (torch registers its CUDA generator with the
+    graph).  The library's own launch-graph cache steps aside while the caller captures (``run_maybe_graphed``).  Warm-up and
+    capture share one side stream, as torch's CUDA-graph recipe asks."""
+    import gc
+    dev = torch.cuda.current_device()
+    # Autograd graphs of EARLIER iterations must be gone: a parameter's AccumulateGrad node lives as long as a graph references it
+    # and keeps the stream it was created on -- the default stream, for iterations that ran there -- and the backward would then
+    # synchronise the capture with that stream, which invalidates it (torch warns "AccumulateGrad node's stream does not match").
+    # The caller drops its own references (outputs with a grad_fn); cyclic leftovers are collected here.
+    gc.collect()
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            out = fn(arg)
+            del out
+    torch.cuda.current_stream(dev).wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = fn(arg)
+    return g, out
+
+
+def time_graph_replays(graph, iters: int = 16, warm: int = 8) -> float:
+    import time
+    for _ in range(warm):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        graph.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3

@@ -207,6 +207,12 @@ template <class Body>
 static int run_maybe_graphed(int entry_id, std::initializer_list<std::pair<const void*, size_t>> parts, int debug, int device,
                              hipStream_t stream, int P, Body&& body) {
   if (!g_graph_mode || debug || prof_on() || (g_graph_mode == 2 && P > g_graph_auto_p)) return body(stream);
+  {   // the CALLER is capturing (a whole training iteration inside torch.cuda.graph): its graph takes the launches as they are --
+      // a replay of our own cached graph cannot be enqueued on a capturing stream
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return body(stream);
+    (void)hipGetLastError();
+  }
   std::string key((const char*)&entry_id, sizeof(entry_id));
   for (auto& p : parts) if (p.first) key.append((const char*)p.first, p.second); else key.append(p.second, '\0');
   const uint64_t h = fnv1a(key);
@@ -338,7 +344,7 @@ int trase_rast_preprocess(const TraseRastSettings* s, const TraseRastInputs* in,
   LaunchCtx c{stream, s->debug, s->variant};
   GeomBuf g = carve_geom(ws->geom, in->P);
   PreBuf t = carve_pre(ws->pre, in->P);
-  if (in->P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
+  if (in->P == 0) return launch_zero_bytes(g.hdr, sizeof(uint32_t) * HDR_WORDS, stream);   // (P > 0: the preprocess kernel clears it; a kernel, not a memset node: common.h)
   const DepthSortCfg cfg = depth_sort_cfg(s->variant);
   rc = launch_preprocess_fwd(c, *s, *in, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - cfg.start : cfg.start], cfg.key_bits == 27);
   if (rc) return rc;
@@ -503,9 +509,11 @@ static int validate_raw(const TraseRastSettings* s, const TraseRastRawInputs* r)
   if (r->F != 0 && r->F != 16 && r->F != 32) { set_error("feature width %d not compiled in (0,16,32)", r->F); return TRASE_ERR_UNSUPPORTED; }
   if (s->sh_degree < 0 || s->sh_degree > 3) { set_error("sh_degree %d outside 0..3", s->sh_degree); return TRASE_ERR_INVALID; }
   if (r->P == 0) return TRASE_OK;
-  if (!r->xyz || !r->features_dc || !r->features_rest || !r->opacity || !r->scaling || !r->rotation) {
-    set_error("raw inputs: xyz/features_dc/features_rest/opacity/scaling/rotation are required"); return TRASE_ERR_INVALID;
+  if (!r->xyz || !r->opacity || !r->scaling || !r->rotation || (!r->colors_precomp && (!r->features_dc || !r->features_rest))) {
+    set_error("raw inputs: xyz/opacity/scaling/rotation and either features_dc + features_rest or colors_precomp are required"); return TRASE_ERR_INVALID;
   }
+  if (r->colors_precomp && r->sh_dir_undeformed) { set_error("raw inputs: colors_precomp and sh_dir_undeformed exclude each other"); return TRASE_ERR_INVALID; }
+  if (r->d_xyz_se3 && r->d_xyz) { set_error("raw inputs: d_xyz_se3 (is_6dof) replaces d_xyz"); return TRASE_ERR_INVALID; }
   if (r->F > 0 && (!r->gaussian_features || !r->featn)) { set_error("raw inputs: gaussian_features/featn required when F > 0"); return TRASE_ERR_INVALID; }
   return TRASE_OK;
 }
@@ -530,7 +538,7 @@ int trase_rast_preprocess_raw(const TraseRastSettings* s, const TraseRastRawInpu
   LaunchCtx c{stream, s->debug, s->variant};
   GeomBuf g = carve_geom(ws->geom, in.P);
   PreBuf t = carve_pre(ws->pre, in.P);
-  if (in.P == 0) return check_hip(hipMemsetAsync(g.hdr, 0, sizeof(uint32_t) * HDR_WORDS, stream), "hipMemsetAsync(hdr)");   // (P > 0: the preprocess kernel clears it)
+  if (in.P == 0) return launch_zero_bytes(g.hdr, sizeof(uint32_t) * HDR_WORDS, stream);   // (P > 0: the preprocess kernel clears it; a kernel, not a memset node: common.h)
   const DepthSortCfg cfg = depth_sort_cfg(s->variant);
   rc = launch_preprocess_fwd_raw(c, *s, *raw, out->radii, g, t.sort.keys[strip_mode(s) ? 1 - cfg.start : cfg.start], cfg.key_bits == 27, 0u,
                                  depth_dead_key(cfg.key_bits == 27));
@@ -650,6 +658,9 @@ static int backward_raw_phases(const TraseRastSettings* s, const TraseRastRawInp
   rc = check_ws(&in, s, ws, WS_GEOM | WS_PRE | WS_BIN | WS_IMG);
   if (rc) return rc;
   if (!ws->tmp || ws->tmp_bytes < bwd_tmp_bytes(in.P, in.F, ws->capacity)) { set_error("backward tmp workspace too small"); return TRASE_ERR_WORKSPACE; }
+  if (s->variant & TRASE_VARIANT_FORWARD_ONLY) {
+    set_error("backward on a forward that ran with TRASE_VARIANT_FORWARD_ONLY: its backward-only state was never stored"); return TRASE_ERR_INVALID;
+  }
   const bool ranged = p_begin >= 0;
   if (ranged && (p_begin % 64 != 0 || p_end > raw->P || p_end < p_begin || (p_end != raw->P && p_end % 64 != 0))) {
     set_error("backward_raw_gaussians: [%d, %d) must start on a multiple of 64 and end on one or at P = %d", p_begin, p_end, raw->P);

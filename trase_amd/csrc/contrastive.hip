@@ -133,7 +133,7 @@ int trase_contrastive_forward(const float* C, const float* C_F, const float* wei
   TRASE_CHECK(hipSetDevice(device));
   int* col = (int*)ws;
   float* partial = (float*)((char*)ws + align_up(sizeof(int) * (size_t)S));
-  TRASE_CHECK(hipMemsetAsync(col, 0, sizeof(int) * (size_t)S, stream));
+  launch_zero_bytes(col, sizeof(int) * (size_t)S, stream);
   const dim3 grid((S + 255) / 256, (S + CT_ROWS - 1) / CT_ROWS);
   {
     ProfScope ps("contrastive_fwd", stream);

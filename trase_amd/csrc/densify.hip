@@ -274,7 +274,7 @@ int trase_densify_plan(const float* xyz_gradient_accum, const float* denom, cons
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
   const int nblk = (P + 255) / 256;
-  TRASE_CHECK(hipMemsetAsync(w.totals, 0, sizeof(uint32_t) * 8, stream));
+  launch_zero_bytes(w.totals, sizeof(uint32_t) * 8, stream);
   {
     ProfScope ps("densify_plan", stream);
     hipLaunchKernelGGL(densify_plan_kernel, dim3(nblk), dim3(256), 0, stream, xyz_gradient_accum, denom, scaling, opacity, P,

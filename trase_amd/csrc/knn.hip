@@ -330,8 +330,8 @@ int trase_knn_points(const float* p1, int32_t N1, const float* p2, int32_t N2, i
   LaunchCtx c{stream, 0, 0};
   const int blocks = (N1 + 255) / 256;
   if (N2 == 0) {   // nothing to find: pytorch3d pads with idx 0 / dist 0 -- keep that convention
-    TRASE_CHECK(hipMemsetAsync(idx_out, 0, sizeof(int64_t) * (size_t)N1 * K, stream));
-    TRASE_CHECK(hipMemsetAsync(dist_out, 0, sizeof(float) * (size_t)N1 * K, stream));
+    launch_zero_bytes(idx_out, sizeof(int64_t) * (size_t)N1 * K, stream);
+    launch_zero_bytes(dist_out, sizeof(float) * (size_t)N1 * K, stream);
     return TRASE_OK;
   }
   KnnWs w = knn_carve(ws, N2);

@@ -621,7 +621,7 @@ int trase_mask_stats(const uint8_t* sam_masks, int32_t N, int64_t HW, int32_t* c
   if (!sam_masks || !cover_count || !mask_size || N < 1 || N > 8192 || HW < 1) { set_error("trase_mask_stats: bad arguments"); return TRASE_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
-  TRASE_CHECK(hipMemsetAsync(mask_size, 0, sizeof(uint32_t) * (size_t)N, stream));
+  launch_zero_bytes(mask_size, sizeof(uint32_t) * (size_t)N, stream);
   {
     ProfScope ps("mask_stats", stream);
     if ((HW & 15) == 0 && (((size_t)sam_masks | (size_t)cover_count) & 15) == 0)
@@ -688,7 +688,7 @@ int trase_pairhead_forward_n(const float* feats, int32_t F, int64_t HW, const ui
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
   // colP and colN are neighbours in the workspace (pair_ws_carve): one fill for both
-  TRASE_CHECK(hipMemsetAsync(w.colP, 0, (size_t)((char*)w.colN - (char*)w.colP) + sizeof(int) * (size_t)S, stream));
+  launch_zero_bytes(w.colP, (size_t)((char*)w.colN - (char*)w.colP) + sizeof(int) * (size_t)S, stream);
   const dim3 grid((S + 255) / 256, (S + PH_ROWS - 1) / PH_ROWS);
   {
     ProfScope ps("pairhead_fwd", stream);
@@ -724,7 +724,7 @@ int trase_pairhead_backward_n(int32_t F, int64_t HW, const int32_t* pix, int32_t
   if (!ws || ws_bytes < pair_ws_carve(S, &w, const_cast<void*>(ws))) { set_error("trase_pairhead_backward: workspace too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
-  if (!accumulate) TRASE_CHECK(hipMemsetAsync(dL_dfeats, 0, sizeof(float) * (size_t)F * (size_t)HW, stream));
+  if (!accumulate) launch_zero_bytes(dL_dfeats, sizeof(float) * (size_t)F * (size_t)HW, stream);
   {
     ProfScope ps("pairhead_bwd", stream);
     hipLaunchKernelGGL(ph_bwd_kernel, dim3((S + 255) / 256, PH_CHUNKS), dim3(256), 0, stream, w.fn, w.bits, w.a, w.consts, S, (const int*)S_dev,

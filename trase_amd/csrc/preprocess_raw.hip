@@ -28,6 +28,12 @@ struct RawFwdArgs {
   int key27;                 // forward: 27-bit depth keys (common.h depth_sort_key)
   uint32_t key_or, key_dead; // forward: OR-ed into a live Gaussian's depth key / the key of one without a pair (the two-view forward keeps
                              // the view index in the sign bit of the float32 key: z > 0.2, so the bit is free)
+  // render()'s other call patterns (gaussian_renderer/__init__.py:75-80, :103-113, :123-135), read by the INFER instantiations only:
+  const float* colors;       // override_color (P,3): the colour as given, no SH evaluation
+  const uint8_t* mask;       // mask (P bytes): a 0 removes the Gaussian from the view (the reference indexes every input by the mask)
+  const float* se3;          // is_6dof (P,4,4): means3D = from_homogenous(M [xyz, 1]) instead of xyz + d_xyz
+  int sh_dir_raw;            // pipe.convert_SHs_python: the SH direction is taken from the UNDEFORMED position (:105)
+  int fwd_only;              // forward under no_grad: the arrays only the backward reads (rgbd, clamp bits) are not stored
 };
 
 __device__ __forceinline__ void raw_view(const RawFwdArgs& a, View& v) {
@@ -44,12 +50,23 @@ __device__ __forceinline__ void raw_view(const RawFwdArgs& a, View& v) {
 struct Activated { float p[3], sc[3], q[4], opac, qn[4], inv_n, es[3], sig; };
 
 // activations of one Gaussian (also returns what the backward needs: unit quaternion, 1/norm, exp, sigmoid)
+template <bool INFER = false>
 __device__ __forceinline__ void activate(const RawFwdArgs& a, int i, Activated& o) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     o.p[k] = a.xyz[3 * i + k] + (a.d_xyz ? a.d_xyz[3 * i + k] : 0.f);
     o.es[k] = __expf(a.scaling[3 * i + k]);
     o.sc[k] = o.es[k] + (a.d_scaling ? a.d_scaling[3 * i + k] : 0.f);
+  }
+  if constexpr (INFER) {
+    if (a.se3) {               // is_6dof: h = M [x, y, z, 1], p = h.xyz / h.w  (utils/rigid_utils.py:128-150; a true division, as there)
+      const float4* M = reinterpret_cast<const float4*>(a.se3) + 4 * (size_t)i;
+      const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+      const float4 r0 = M[0], r1 = M[1], r2 = M[2], r3 = M[3];
+      const float h0 = r0.x * x + r0.y * y + r0.z * z + r0.w, h1 = r1.x * x + r1.y * y + r1.z * z + r1.w;
+      const float h2 = r2.x * x + r2.y * y + r2.z * z + r2.w, h3 = r3.x * x + r3.y * y + r3.z * z + r3.w;
+      o.p[0] = h0 / h3; o.p[1] = h1 / h3; o.p[2] = h2 / h3;
+    }
   }
   const float4 r = reinterpret_cast<const float4*>(a.rotation)[i];
   const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
@@ -146,7 +163,9 @@ constexpr int RAW_BLOCK = TRASE_RAW_BLOCK;                   // waves x 64 per w
 
 // BLOCK: 64 for the whole image; 256 for a tile-row strip -- most waves have nothing to move there and the kernel is bound by
 // the rate at which workgroups can be dispatched (~250 per microsecond: 39k one-wave workgroups = 0.15 ms at 2.5 M Gaussians)
-template <int F, int BLOCK>
+// INFER: the instantiation that also serves override_color / mask / is_6dof / convert_SHs_python (RawFwdArgs) -- the training
+// instantiation (INFER = false) is compiled without a trace of them
+template <int F, int BLOCK, bool INFER = false>
 __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a, int32_t* __restrict__ radii,
                                                                  float2* __restrict__ xy, float4* __restrict__ conic_o,
                                                                  float4* __restrict__ rgbd, float4* __restrict__ geo, uint32_t* __restrict__ ftab,
@@ -154,6 +173,9 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
                                                                  uint32_t* __restrict__ clamped,
                                                                  uint32_t* __restrict__ depth_keys,
                                                                  uint32_t* __restrict__ hdr) {
+#ifdef TRASE_RAW_SETPRIO
+  __builtin_amdgcn_s_setprio(3);                             // experiment build (profiles/r6_two_streams.md)
+#endif
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
   if (gi == 0) {                                             // clean header (one memset launch less per view) + P for the depth sort
 #pragma unroll
@@ -163,17 +185,26 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
   const bool active = gi < a.P;
   const int i = active ? gi : a.P - 1;
   constexpr bool strip = BLOCK != RAW_BLOCK;                 // the 256-thread instantiation IS the tile-row-strip one
-  __shared__ __attribute__((aligned(16))) float slabs[strip ? 1 : BLOCK / 64][strip ? 4 : REST_SLAB];   // (the strip path moves no slab)
-  float* const slab = slabs[strip ? 0 : (threadIdx.x >> 6)];
+#ifdef TRASE_RAW_NO_SLAB
+  // experiment build (profiles/r6_two_streams.md): no LDS in this kernel at all -- every lane reads its own
+  // f_rest row from memory, as the strip path does
+  constexpr bool noslab = true;
+#else
+  constexpr bool noslab = strip;
+#endif
+  __shared__ __attribute__((aligned(16))) float slabs[noslab ? 1 : BLOCK / 64][noslab ? 4 : REST_SLAB];   // (the strip path moves no slab)
+  float* const slab = slabs[noslab ? 0 : (threadIdx.x >> 6)];
   const int row0 = gi & ~63;                                  // first Gaussian of this wave
   if (row0 >= a.P) return;                                    // (a whole wave past the end: BLOCK > 64 only)
   const bool rest16 = ((reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0);
+  const bool precol = INFER && a.colors != nullptr;          // (wave-uniform) override_color: no SH coefficients are read at all
   RestRegs rr;
-  if (!strip) rest_rows_load(a.f_rest, row0, a.P, rest16, rr);   // (requested first: the geometry arithmetic hides the trip)
+  if (!noslab && !precol) rest_rows_load(a.f_rest, row0, a.P, rest16, rr);   // (requested first: the geometry arithmetic hides the trip)
   View v;
   raw_view(a, v);
   Activated act;
-  activate(a, i, act);
+  activate<INFER>(a, i, act);
+  const bool masked_out = INFER && a.mask != nullptr && a.mask[i] == 0;
   float shl[48];
   const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
   Splat o;
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
   // a second copy of splat_forward differed by one ulp in 15 % of the conics).  What differs between the modes is only WHICH
   // Gaussians get a colour and a record: every visible one, or -- strip -- those with a pair in the strip (~1 / world of them;
   // the 192 bytes of SH coefficients are 1/3 of what a Gaussian moves through this kernel).
-  bool vis = splat_forward<false, false>(v, act.p, act.sc, act.q, cv, shl, col, o) && active;
+  bool vis = splat_forward<false, false>(v, act.p, act.sc, act.q, cv, shl, col, o) && active && !masked_out;
   if (active) radii[i] = vis ? o.radius : 0;
   uint32_t live = 0;
   if (vis) {
@@ -199,13 +230,17 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
     depth_keys[i] = (vis && live) ? (depth_sort_key(o.depth, a.key27 != 0) | a.key_or) : a.key_dead;
   }
   const bool want = vis && (live != 0 || !strip);             // gets a colour and a record
-  if (!strip) {
+  if (!noslab && !precol) {
     rest_rows_to_lds(rr, slab);
-  } else {
+  }
+  if (strip) {
     if (vis && !live) xy[i] = make_float2(o.px, o.py);        // (the lineage pair count R is totalled from radii + centres)
   }
-  if (want) {
-    if (!strip) {
+  if (want && precol) {
+    o.rgb[0] = a.colors[3 * (size_t)i]; o.rgb[1] = a.colors[3 * (size_t)i + 1]; o.rgb[2] = a.colors[3 * (size_t)i + 2];
+    o.clamped = 0u;
+  } else if (want) {
+    if (!noslab) {
       load_sh_split(a, i, slab, shl);
     } else {
       // the few lanes that have a pair read their own rows (all 45 loads in flight at once; a cooperative copy of the rows one
@@ -217,20 +252,25 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_raw_kernel(RawFwdArgs a,
 #pragma unroll
       for (int k = 3; k < 48; ++k) shl[k] = (k < n3) ? rw[k - 3] : 0.f;
     }
-    splat_colour_sh(v, act.p, shl, o);
+    if (INFER && a.sh_dir_raw) {   // convert_SHs_python evaluates the SH at the UNDEFORMED position (gaussian_renderer/__init__.py:105)
+      const float p0[3] = {a.xyz[3 * (size_t)i], a.xyz[3 * (size_t)i + 1], a.xyz[3 * (size_t)i + 2]};
+      splat_colour_sh(v, p0, shl, o);
+    } else {
+      splat_colour_sh(v, act.p, shl, o);
+    }
   }
   vis = want;
   if (vis) {
     xy[i] = make_float2(o.px, o.py);
     conic_o[i] = make_float4(o.ca, o.cb, o.cc, act.opac);
-    rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
+    if (!(INFER && a.fwd_only)) rgbd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);   // (read by the backward and the VALU forward only)
     // the same 40 bytes as ONE 64-byte record: the compositing kernels fetch a list entry's geometry from one cache line
     // (word 2 of the record: the Gaussian's first row slot, written by emit_pairs)
     geo[4 * (size_t)i + 0] = make_float4(o.px, o.py, 0.f, __int_as_float(o.radius));   // .w: the radius, for emit_pairs
     geo[4 * (size_t)i + 1] = make_float4(o.ca, o.cb, o.cc, act.opac);
     geo[4 * (size_t)i + 2] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
     geo[4 * (size_t)i + 3] = split_rgbd(o.rgb[0], o.rgb[1], o.rgb[2], o.depth);
-    clamped[i] = o.clamped;
+    if (!(INFER && a.fwd_only)) clamped[i] = o.clamped;
   }
   // feature rows the compositing kernels read: f / (||f|| + 1e-9)  (gaussian_renderer/__init__.py:120-121).  F / 4 lanes per
   // Gaussian, one float4 each: the wave's 64 rows are read and written as contiguous 1 KB runs; the squared norm is summed
@@ -288,12 +328,17 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   strip_subtile_rows(s, a.sy_lo, a.sy_hi);
   a.strip = (s.tile_row_begin != 0 || s.tile_row_end != 0) ? 1 : 0;
   a.p_begin = 0; a.p_end = raw.P;
+  a.colors = raw.colors_precomp; a.mask = raw.mask; a.se3 = raw.d_xyz_se3; a.sh_dir_raw = raw.sh_dir_undeformed;
+  // the arrays only the backward (and the VALU forward) reads need not be written under no_grad
+  a.fwd_only = ((c.variant & TRASE_VARIANT_FORWARD_ONLY) != 0 && (c.variant & TRASE_VARIANT_VALU_FORWARD) == 0 && raw.F == 32) ? 1 : 0;
+  const bool infer = a.colors || a.mask || a.se3 || a.sh_dir_raw || a.fwd_only;
   const int blk = a.strip ? 256 : RAW_BLOCK;
   const dim3 grid((raw.P + blk - 1) / blk), block(blk);
   {
     ProfScope ps("preprocess_fwd", c.stream);
-#define TRASE_PRF(FF) do { if (a.strip) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF, 256>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr); \
-                           else hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF, RAW_BLOCK>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr); } while (0)
+#define TRASE_PRF2(FF, BB, II) hipLaunchKernelGGL((preprocess_fwd_raw_kernel<FF, BB, II>), grid, block, 0, c.stream, a, radii, g.xy, g.conic_o, g.rgbd, g.geo, g.ftab, g.tiles, g.clamped, depth_keys, g.hdr)
+#define TRASE_PRF(FF) do { if (a.strip) { if (infer) TRASE_PRF2(FF, 256, true); else TRASE_PRF2(FF, 256, false); } \
+                           else { if (infer) TRASE_PRF2(FF, RAW_BLOCK, true); else TRASE_PRF2(FF, RAW_BLOCK, false); } } while (0)
     switch (raw.F) {
       case 0: TRASE_PRF(0); break;
       case 16: TRASE_PRF(16); break;
@@ -301,6 +346,7 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
       default: set_error("preprocess_fwd_raw: feature width %d not compiled in (0,16,32)", raw.F); return TRASE_ERR_UNSUPPORTED;
     }
 #undef TRASE_PRF
+#undef TRASE_PRF2
   }
   TRASE_POST_LAUNCH("preprocess_fwd", c.stream, c.debug);
   return TRASE_OK;
@@ -310,6 +356,8 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
 struct RawBwdOut {
   float* d_xyz; float* d_dxyz; float* d_means2D; float* d_f_dc; float* d_f_rest; float* d_opacity;
   float* d_scaling; float* d_dscaling; float* d_rotation; float* d_drotation;
+  float* d_colors;           // INFER: dL/doverride_color (P,3)
+  float* d_se3;              // INFER: dL/d(the (P,4,4) is_6dof transforms)
   float* d_feat_zero;        // tile-row strips: dL/dgaussian_features rows of the Gaussians WITHOUT a pair are zeroed here
   int F;                     // (reduce_rows only walked the ones that have one), F floats per row
 };
@@ -318,7 +366,29 @@ struct RawBwdOut {
 // live list `ids` (those with a pair in the strip, hdr[HDR_WORDS - 1] of them) and ONLY their rows of the gradient tensors are
 // written -- the caller keeps every other row zero (trase_rast_zero_live_rows).  The f_rest rows are gathered / scattered row by
 // row (one coalesced 180-byte access each) instead of moved as the wave's contiguous slab.
-template <bool LIVE, int BLOCK>
+// the SH block of splat_backward (gs_math.h) on its own, for the call pattern whose SH direction comes from another position than
+// the splat's (pipe.convert_SHs_python: the undeformed xyz): dL/dsh and the direction's gradient w.r.t. THAT position
+__device__ __forceinline__ void sh_backward_at(const View& v, const float p_sh[3], const float* sh, unsigned clamped, const float d_rgb[3],
+                                               float* d_sh, float d_p_sh[3]) {
+  float dr[3];
+  for (int ch = 0; ch < 3; ++ch) dr[ch] = ((clamped >> ch) & 1u) ? 0.f : d_rgb[ch];
+  float d[3], il, bb[16], gx[16], gy[16], gz[16];
+  sh_dir(p_sh, v.cam, d, il);
+  sh_basis(v.deg, d, bb);
+  sh_basis_grad(v.deg, d, gx, gy, gz);
+  float dd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
+    d_sh[3 * k] = bb[k] * dr[0]; d_sh[3 * k + 1] = bb[k] * dr[1]; d_sh[3 * k + 2] = bb[k] * dr[2];
+    const float w = s0 * dr[0] + s1 * dr[1] + s2 * dr[2];
+    dd[0] += gx[k] * w; dd[1] += gy[k] * w; dd[2] += gz[k] * w;
+  }
+  const float dot = d[0] * dd[0] + d[1] * dd[1] + d[2] * dd[2];
+  for (int k = 0; k < 3; ++k) d_p_sh[k] = (dd[k] - d[k] * dot) * il;
+}
+
+template <bool LIVE, int BLOCK, bool INFER = false>
 __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a, const int32_t* __restrict__ radii,
                                                                    const uint32_t* __restrict__ clamped,
                                                                    const uint32_t* __restrict__ tiles,
@@ -336,9 +406,11 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a,
   float* const slab = slabs[threadIdx.x >> 6];
   const int row0 = gidx & ~63;
   const bool wave_vis = __ballot(vis) != 0ull;
+  const bool precol = INFER && a.colors != nullptr;          // (wave-uniform) override_color: no SH anywhere
+  float d_p_raw[3] = {0.f, 0.f, 0.f};                          // INFER: the part of dL/dposition that belongs to the UNDEFORMED xyz only
   if (LIVE) {
     // (every lane reads and writes its own 180-byte rows: the ids are scattered, there is no slab to move)
-  } else if (wave_vis) {
+  } else if (wave_vis && !precol) {
     RestRegs rr;
     rest_rows_load(a.f_rest, row0, a.P, (reinterpret_cast<uintptr_t>(a.f_rest) & 15) == 0, rr);
     rest_rows_to_lds(rr, slab);
@@ -369,9 +441,11 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a,
     gi.d_rgb[2] = r2.x; gi.d_depth = r2.y;
     View v;
     raw_view(a, v);
-    activate(a, i, act);
+    activate<INFER>(a, i, act);
     float shl[48];
-    if (LIVE) {
+    if (precol) {
+      // (no coefficients)
+    } else if (LIVE) {
       const int n3 = 3 * ncoef(a.deg);
       const float* dc = a.f_dc + 3 * (size_t)i;
       const float* rw = a.f_rest + (size_t)i * REST_W;
@@ -382,12 +456,54 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a,
       load_sh_split(a, i, slab, shl);
     }
     const float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    splat_backward<false, true>(v, act.p, act.sc, act.q, cv, shl, clamped[i], gi, go, dsh);
+    if (precol) {
+      splat_backward<false, false>(v, act.p, act.sc, act.q, cv, shl, 0u, gi, go, dsh);     // the colour is an input: its gradient is d_rgb itself
+    } else if (INFER && a.sh_dir_raw) {
+      const float p0[3] = {a.xyz[3 * (size_t)i], a.xyz[3 * (size_t)i + 1], a.xyz[3 * (size_t)i + 2]};
+      splat_backward<false, false>(v, act.p, act.sc, act.q, cv, shl, 0u, gi, go, dsh);
+      sh_backward_at(v, p0, shl, clamped[i], gi.d_rgb, dsh, d_p_raw);
+    } else {
+      splat_backward<false, true>(v, act.p, act.sc, act.q, cv, shl, clamped[i], gi, go, dsh);
+    }
   }
   // chain through the activations
   if (active) {
-  if (o.d_xyz) { o.d_xyz[3 * i] = go.d_p[0]; o.d_xyz[3 * i + 1] = go.d_p[1]; o.d_xyz[3 * i + 2] = go.d_p[2]; }
+  if (INFER && a.se3) {
+    // p = h.xyz / h.w, h = M [x, y, z, 1]: dL/dh = (g / h.w, -<g, p> / h.w); dL/dM = dL/dh [x, y, z, 1]^T; dL/dxyz = M[:, :3]^T dL/dh
+    float dx[3] = {0.f, 0.f, 0.f}, dM[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dM[k] = 0.f;
+    if (vis) {
+      const float4* M = reinterpret_cast<const float4*>(a.se3) + 4 * (size_t)i;
+      const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+      const float4 r0 = M[0], r1 = M[1], r2 = M[2], r3 = M[3];
+      const float h3 = r3.x * x + r3.y * y + r3.z * z + r3.w;
+      const float inv = 1.0f / h3;
+      const float dh[4] = {go.d_p[0] * inv, go.d_p[1] * inv, go.d_p[2] * inv,
+                           -(go.d_p[0] * act.p[0] + go.d_p[1] * act.p[1] + go.d_p[2] * act.p[2]) * inv};
+      const float ph[4] = {x, y, z, 1.0f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dM[4 * r + cc] = dh[r] * ph[cc];
+      dx[0] = dh[0] * r0.x + dh[1] * r1.x + dh[2] * r2.x + dh[3] * r3.x;
+      dx[1] = dh[0] * r0.y + dh[1] * r1.y + dh[2] * r2.y + dh[3] * r3.y;
+      dx[2] = dh[0] * r0.z + dh[1] * r1.z + dh[2] * r2.z + dh[3] * r3.z;
+    }
+    if (o.d_xyz) { o.d_xyz[3 * i] = dx[0] + d_p_raw[0]; o.d_xyz[3 * i + 1] = dx[1] + d_p_raw[1]; o.d_xyz[3 * i + 2] = dx[2] + d_p_raw[2]; }
+    if (o.d_se3) {
+      float4* D = reinterpret_cast<float4*>(o.d_se3) + 4 * (size_t)i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[r] = make_float4(dM[4 * r], dM[4 * r + 1], dM[4 * r + 2], dM[4 * r + 3]);
+    }
+  } else {
+  if (o.d_xyz) {
+    if constexpr (INFER) { o.d_xyz[3 * i] = go.d_p[0] + d_p_raw[0]; o.d_xyz[3 * i + 1] = go.d_p[1] + d_p_raw[1]; o.d_xyz[3 * i + 2] = go.d_p[2] + d_p_raw[2]; }
+    else { o.d_xyz[3 * i] = go.d_p[0]; o.d_xyz[3 * i + 1] = go.d_p[1]; o.d_xyz[3 * i + 2] = go.d_p[2]; }
+  }
   if (o.d_dxyz) { o.d_dxyz[3 * i] = go.d_p[0]; o.d_dxyz[3 * i + 1] = go.d_p[1]; o.d_dxyz[3 * i + 2] = go.d_p[2]; }
+  }
+  if (INFER && o.d_colors) { o.d_colors[3 * (size_t)i] = gi.d_rgb[0]; o.d_colors[3 * (size_t)i + 1] = gi.d_rgb[1]; o.d_colors[3 * (size_t)i + 2] = gi.d_rgb[2]; }
   if (o.d_means2D) { o.d_means2D[3 * i] = gi.d_ndcx; o.d_means2D[3 * i + 1] = gi.d_ndcy; o.d_means2D[3 * i + 2] = 0.f; }
   if (o.d_opacity) o.d_opacity[i] = d_op * act.sig * (1.0f - act.sig);
   if (o.d_scaling) {
@@ -403,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a,
         make_float4((go.d_quat[0] - act.qn[0] * dot) * act.inv_n, (go.d_quat[1] - act.qn[1] * dot) * act.inv_n,
                     (go.d_quat[2] - act.qn[2] * dot) * act.inv_n, (go.d_quat[3] - act.qn[3] * dot) * act.inv_n);
   }
-  if (o.d_f_dc) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
+  if (o.d_f_dc && !precol) { o.d_f_dc[3 * i] = dsh[0]; o.d_f_dc[3 * i + 1] = dsh[1]; o.d_f_dc[3 * i + 2] = dsh[2]; }
   }
   if (o.d_feat_zero) {
     // eight lanes per 128-byte row (F = 32; four for F = 16): the wave's rows as contiguous runs
@@ -415,6 +531,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_raw_kernel(RawFwdArgs a,
       if ((dead >> gl) & 1ull) reinterpret_cast<float4*>(o.d_feat_zero + (size_t)(row0 + gl) * o.F)[lane % lpg] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  if (precol) return;                                      // (override_color: the caller passes no SH gradient tensors)
   if (LIVE) {
     if (o.d_f_rest && active) {
       float* rw = o.d_f_rest + (size_t)i * REST_W;
@@ -487,12 +604,19 @@ int launch_preprocess_bwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   o.d_f_rest = gr.dL_dfeatures_rest; o.d_opacity = gr.dL_dopacity; o.d_scaling = gr.dL_dscaling;
   o.d_dscaling = gr.dL_dd_scaling; o.d_rotation = gr.dL_drotation; o.d_drotation = gr.dL_dd_rotation;
   o.d_feat_zero = (zero_dead_feats && (raw.F == 16 || raw.F == 32)) ? gr.dL_dgaussian_features : nullptr; o.F = raw.F;
+  o.d_colors = gr.dL_dcolors_precomp; o.d_se3 = gr.dL_dd_xyz_se3;
+  a.colors = raw.colors_precomp; a.mask = raw.mask; a.se3 = raw.d_xyz_se3; a.sh_dir_raw = raw.sh_dir_undeformed; a.fwd_only = 0;
+  const bool infer = a.colors || a.se3 || a.sh_dir_raw;       // (a mask needs nothing here: a masked-out Gaussian has radii == 0)
   a.strip = 0;
   {
     ProfScope ps("preprocess_bwd", c.stream);
-    if (live_ids)     // sparse strip gradients: the live list only (grid for P -- the count lives on the device; whole waves behind it leave at once)
+    if (live_ids) {   // sparse strip gradients: the live list only (grid for P -- the count lives on the device; whole waves behind it leave at once)
+      if (infer) { set_error("preprocess_bwd_raw: sparse strip gradients are a training path (no override_color / is_6dof / convert_SHs_python)"); return TRASE_ERR_UNSUPPORTED; }
       hipLaunchKernelGGL((preprocess_bwd_raw_kernel<true, 256>), dim3((raw.P + 255) / 256), dim3(256), 0, c.stream, a, radii, g.clamped, g.tiles,
                          acc, o, live_ids, g.hdr + (HDR_WORDS - 1));
+    } else if (infer)
+      hipLaunchKernelGGL((preprocess_bwd_raw_kernel<false, RAW_BLOCK, true>), dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0,
+                         c.stream, a, radii, g.clamped, g.tiles, acc, o, nullptr, nullptr);
     else
       hipLaunchKernelGGL((preprocess_bwd_raw_kernel<false, RAW_BLOCK>), dim3((p_end - p_begin + RAW_BLOCK - 1) / RAW_BLOCK), dim3(RAW_BLOCK), 0,
                          c.stream, a, radii, g.clamped, g.tiles, acc, o, nullptr, nullptr);

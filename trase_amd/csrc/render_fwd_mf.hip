@@ -324,8 +324,10 @@ void render_fwd_mf_kernel(FwdMfArgs a) {
   if (h == 0) {
     if (inside) {
       const size_t pix = (size_t)(y0 + pi) * a.W + x0 + pj;
-      a.final_T[pix] = Tc;
-      a.n_contrib[pix] = lastc;
+      if (!(a.lineage & TRASE_VARIANT_FORWARD_ONLY)) {   // (what only the backward reads: skipped under no_grad)
+        a.final_T[pix] = Tc;
+        a.n_contrib[pix] = lastc;
+      }
       if (a.lineage & TRASE_VARIANT_DEPTH_NORM) {        // lineage switch: depth / accumulated alpha
         const float A = 1.0f - Tc;
         dacc = A > 1e-10f ? dacc / A : 0.0f;
@@ -378,7 +380,7 @@ int launch_render_fwd_mf(const LaunchCtx& c, const TraseRastSettings& s, const T
   a.hdr = g.hdr; a.geo = g.geo; a.ftab = g.ftab;
   a.out_img = out.image; a.out_feat = out.feats; a.out_depth = out.depth; a.final_T = im.final_T; a.n_contrib = im.n_contrib;
   a.W = s.image_width; a.H = s.image_height;
-  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM); a.feat_bg = s.feat_bg;
+  a.lineage = c.variant & (TRASE_VARIANT_FEATS_BG | TRASE_VARIANT_DEPTH_NORM | TRASE_VARIANT_FORWARD_ONLY); a.feat_bg = s.feat_bg;
   a.order_mode = 16;
 #ifdef TRASE_AB
   a.order_mode = (c.variant & TRASE_VARIANT_AB_ORDER_IMAGE) ? 0 : ((c.variant & TRASE_VARIANT_AB_ORDER_8) ? 8 : 16);

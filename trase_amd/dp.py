@@ -214,8 +214,18 @@ class FlatGradBucket:
             # the collectives in flight and never be reduced: remember the views' versions as the last range leaves them
             self._versions = {id(p): v._version for p, v in zip(self.params, self._views) if id(p) in self._exchanged}
 
+    def _finish_phased(self):
+        # a previous allreduce_phased() whose phase B nobody waited for: the side stream may still be reducing self.flat (and
+        # using the staging buffer this path shares) while gather_grads() / the next backward write it -- make the current
+        # stream wait (a loop that forgot wait_rest(), or mixed the two APIs, raced silently)
+        ex = getattr(self, "_last_phased", None)
+        if ex is not None:
+            ex.wait_rest()
+            self._last_phased = None
+
     def allreduce(self, average: bool = False):
         import torch.distributed as dist
+        self._finish_phased()
         pending, exchanged = getattr(self, "_pending", []), getattr(self, "_exchanged", set())
         for w in pending:
             w.wait()                                         # the current stream waits for the ranges' collectives
@@ -371,8 +381,10 @@ class FlatGradBucket:
         import torch.distributed as dist
         if getattr(self, "_pending", None):
             raise RuntimeError("FlatGradBucket.allreduce_phased: ranges of an overlapped exchange are pending; use allreduce()")
+        self._finish_phased()
         self.gather_grads()
         ex = PhasedExchange(self, average)
+        self._last_phased = ex
         if not self._collectives_on():
             return ex
         first_ids = {id(p) for p in first}

@@ -74,8 +74,36 @@ def get_sample_pixel_and_mask(sam_masks, num_sampled_pixels, num_sampled_masks, 
     sampled_pixel = torch.rand(sam_masks.shape[-2], sam_masks.shape[-1], device=where).to(dev) < pixel_sample_rate
     sampled_pixel = torch.logical_and(sampled_pixel, cover_count != 0)
     # (how many pixels the draw aims at: lets contrastive_head size its buffers without reading the count back from the device)
-    sampled_pixel._trase_expected_count = int(num_sampled_pixels)
+    # tied to THIS tensor's contents: (target count, number of pixels of the draw, version counter) -- an in-place edit afterwards
+    # (`sampled_pixel |= ...`) bumps the version and contrastive_head falls back to counting
+    sampled_pixel._trase_expected_count = (int(num_sampled_pixels), int(sampled_pixel.numel()), int(sampled_pixel._version))
     return sampled_pixel, sampled_mask
+
+
+_COUNT_CHECKS: list = []      # (event, pinned int32[2] copy of the device count, capacity) of sync-free compactions not yet verified
+
+
+def _poll_count_checks(block: bool = False):
+    """A compaction whose true count (count[1]) exceeded the buffer it was given dropped its highest pixels: reported here, by a
+    LATER call of the head (or check_sampled_counts()), without making any call wait for the device."""
+    keep = []
+    for ev, pin, cap in _COUNT_CHECKS:
+        if block:
+            ev.synchronize()
+        if block or ev.query():
+            if int(pin[1]) > cap:
+                _COUNT_CHECKS[:] = []
+                raise RuntimeError(f"trase_amd.feature_head: a sync-free contrastive_head call sampled {int(pin[1])} pixels but its index "
+                                   f"buffer held {cap}: the highest pixels of that draw were dropped from its losses.  Pass a boolean "
+                                   f"mask that does not come from get_sample_pixel_and_mask (counted on the host) for such draws.")
+        else:
+            keep.append((ev, pin, cap))
+    _COUNT_CHECKS[:] = keep
+
+
+def check_sampled_counts():
+    """Blocking: verify every sync-free contrastive_head call issued so far (see _poll_count_checks)."""
+    _poll_count_checks(block=True)
 
 
 class _PairHead(torch.autograd.Function):
@@ -162,8 +190,14 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
     if n_sampled > 256:
         raise ValueError(f"{n_sampled} sampled masks (the membership bit sets hold 256)")
     expected = getattr(sampled_pixel, "_trase_expected_count", None)
+    if expected is not None:
+        # only while the tensor still IS the draw the count describes (same number of pixels, not edited in place since)
+        expected = expected[0] if (isinstance(expected, tuple) and expected[1] == H * W
+                                   and expected[2] == sampled_pixel._version) else None
     s_dev = None
     if expected is not None and sampled_pixel.dtype == torch.bool:
+        if not torch.cuda.is_current_stream_capturing():
+            _poll_count_checks()
         # no read-back (round 5): the indices are compacted on the device into a buffer sized for the draw's target plus eight
         # standard deviations of the binomial count; every kernel of the head takes the count from the device.  (A draw that
         # overflowed the buffer -- probability ~ 1e-15 -- would drop its highest pixels; count[1] keeps the true number.)
@@ -177,6 +211,12 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
         cws = _bytes(nb.value, dev)
         _lib.check(lib.trase_compact_pixels(_lib.ptr(flags), H * W, _lib.ptr(pix), cap, _lib.ptr(s_dev), _lib.ptr(cws), cws.numel(),
                                             _dev_index(dev), _stream(dev)), "trase_compact_pixels")
+        if len(_COUNT_CHECKS) < 64 and not torch.cuda.is_current_stream_capturing():   # the true count is looked at later, off the critical path
+            pin = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pin.copy_(s_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _COUNT_CHECKS.append((ev, pin, cap))
     else:
         pix = torch.nonzero(sampled_pixel.reshape(-1)).reshape(-1).to(torch.int32)       # ascending = boolean-index order (synchronises)
         if pix.numel() == 0:

@@ -103,6 +103,7 @@ VARIANT_DEPTH_GRAD, VARIANT_FEATS_BG, VARIANT_DEPTH_NORM = 0x100, 0x10000, 0x200
 VARIANT_FEATURES_ONLY_BWD = 0x400                                                       # backward scope
 VARIANT_VALU_BACKWARD, VARIANT_VALU_FORWARD, VARIANT_SLOT_LISTS = 0x40, 0x2000, 0x100000  # cross-check formulations
 VARIANT_SPARSE_STRIP_GRADS = 0x200000                                                   # tile-row strips: live rows only
+VARIANT_FORWARD_ONLY = 0x800000           # a forward under no_grad: backward-only state is not stored (set per call by the fused render())
 VARIANT_DEPTH32 = 0x400000                # depth sort on the raw float32 depth bits (the fallback of the 27-bit keys, see set_depth_keys)
 
 
@@ -195,14 +196,14 @@ def _header_verdict(h, cap: int, what: str):
         _Policy.capacity = max(_Policy.capacity, int(r_eff * 1.25) + 1024)
     if int(h[16]) or int(h[20]):
         raise RuntimeError(f"trase_amd rasterizer: binning guard tripped in {what} (key flag {int(h[16])}, slot flag {int(h[20])})")
-    if int(h[1]) >= 2:         # bit 1 (MAX-reduced over the ranks under data parallelism: any value >= 2): a saturated 27-bit depth key
+    if int(h[1]) & 2:          # bit 1 (OR-ed over the ranks under data parallelism): a saturated 27-bit depth key
         _Policy.variant |= VARIANT_DEPTH32
         raise IterationSkipped(f"trase_amd rasterizer: a Gaussian of {what} lies beyond the range of the 27-bit depth keys (view depth > "
                            f"13 107): that call's depth order was not exact beyond that distance.  This process now sorts on the raw "
                            f"float32 depth bits (rasterizer.set_depth_keys(32)).  Guarded consumers of that iteration "
                            f"(FusedAdam.step, add_densification_stats) skipped it on the device; unguarded ones have used its "
                            f"gradients: re-run the iteration, or call set_depth_keys(32) / set_sync(True) up front for such scenes.")
-    if int(h[1]):
+    if int(h[1]) & 1:
         raise IterationSkipped(f"trase_amd rasterizer: the pair buffer overflowed in {what}: {r_eff} (sub-tile, Gaussian) pairs "
                            f"needed, capacity was {cap}; that call's outputs and gradients were incomplete.  The capacity "
                            f"has been grown to {_Policy.capacity}.  Guarded consumers of that iteration (FusedAdam.step, "
@@ -264,8 +265,13 @@ def current_guard():
             # live count, pack bits of THIS rank's strip) stays local, so reports and capacity growth describe this rank
             idx = _flag_index(buf.device)
             flags = buf.index_select(0, idx)
+            # word 1 is a BIT FIELD (bit 0 pair overflow, bit 1 saturated depth key): a MAX over the ranks of the word itself
+            # turns {1, 2} into 2 and loses the overflow -- its two bits travel as words of their own and meet again
+            bits = torch.stack([flags[0] & 1, flags[0] & 2])
+            flags = torch.cat([flags, bits])
             dist.all_reduce(flags, op=dist.ReduceOp.MAX)
-            buf.index_copy_(0, idx, flags)
+            flags[0] = flags[-2] | flags[-1]
+            buf.index_copy_(0, idx, flags[:-2])
             pin.copy_(buf[:32], non_blocking=True)
             if guard.is_cuda:
                 ev.record(torch.cuda.current_stream(guard.device))     # the poll now waits for the reduced copy
@@ -305,7 +311,8 @@ def _pick_capacity(lib, ws, stream, rerun_stage1=None) -> int:
             return need
         _Policy.capacity = int(need * 1.5) + 1024      # first sync-free call: measured once, with headroom
         return _Policy.capacity
-    _poll_pending()
+    if not _capturing():
+        _poll_pending()
     return max(int(_Policy.capacity), 1)
 
 
@@ -341,6 +348,12 @@ def _after_render(geom: torch.Tensor, capacity: int, binb: Optional[torch.Tensor
     _Policy.last_bin, _Policy.last_hw = binb, hw
     _Policy.last_strip = tuple(_Policy.tile_rows)
     _Policy.guard_reduced = None
+    if not _Policy.sync and _capturing():
+        # inside torch.cuda.graph: nothing may be read back (a pinned copy + event recorded here would be replayed, never polled).
+        # The overflow flag still lives in the geom header and the guarded consumers (FusedAdam.step, add_densification_stats)
+        # test it on the device at every replay; the HOST never hears of it -- size the capacity generously before capturing.
+        _Policy.forward_seq += 1
+        return
     if not _Policy.sync:
         _Policy.forward_seq += 1
         if _PIN_RING:
@@ -417,6 +430,11 @@ def last_geom_view(P: int) -> dict:
     return geom_view(_Policy.last_geom, P)
 
 
+def _capturing() -> bool:
+    """True while the current stream is being captured into a graph (whole-iteration capture with torch.cuda.graph)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 _LAST_STREAM: dict = {}     # device index -> the stream of the library's most recent launch sequence on that device
 _UNORDERED_STREAMS = os.environ.get("TRASE_UNORDERED_STREAMS", "0") != "0"   # experiments only (profiles/r4_two_streams.md): no cross-stream wait
 
@@ -430,6 +448,10 @@ def _stream(device) -> C.c_void_p:
     compositing kernel (transposing LDS reads, `ds_read_b64_tr_b16`) of another sequence is resident on their CU
     (profiles/r4_two_streams.md).  Costs nothing while the caller stays on one stream."""
     cur = torch.cuda.current_stream(device)
+    if _capturing():
+        # stream capture (torch.cuda.graph): the capture stream was ordered behind the caller's stream by whoever began the capture;
+        # an event wait recorded here would tie the graph to work outside it.  The bookkeeping below stays as it was before the capture.
+        return C.c_void_p(cur.cuda_stream)
     prev = _LAST_STREAM.get(cur.device_index)
     if prev is None or prev.cuda_stream != cur.cuda_stream:
         if prev is not None and not _UNORDERED_STREAMS:

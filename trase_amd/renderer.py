@@ -19,6 +19,7 @@ from .sh import sh_colors_python
 from .smooth import smoothed_gaussian_features
 from .rasterizer import VARIANT_SPARSE_STRIP_GRADS as _r_VARIANT_SPARSE
 from .rasterizer import VARIANT_DEPTH32 as _r_VARIANT_DEPTH32
+from .rasterizer import VARIANT_FORWARD_ONLY as _r_VARIANT_FORWARD_ONLY
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _Policy, _after_render, _release_last, _bytes, _fill_settings,
                          _output_maps, _pick_capacity, _prep, _sizes, _stream)
 
@@ -114,7 +115,9 @@ def chunk_ranges(P: int, chunks: int):
 class _RenderRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat, means2D,
-                raster_settings, norm_features):
+                raster_settings, norm_features, override_color=None, mask=None, se3=None, sh_dir_raw=False):
+        # override_color (P,3) / mask (P) bool / se3 (P,4,4): render()'s inference call patterns (gaussian_renderer/__init__.py:75-80,
+        # :112-113, :123-135), sh_dir_raw: pipe.convert_SHs_python (:103-108) -- all inside the per-Gaussian kernels (round 6)
         lib = _lib.load()
         device = xyz.device
         if device.type != "cuda":
@@ -127,10 +130,20 @@ class _RenderRaw(torch.autograd.Function):
         scaling, rotation = T(scaling, "scaling"), T(rotation, "rotation")
         d_xyz, d_scaling, d_rotation = T(d_xyz, "d_xyz"), T(d_scaling, "d_scaling"), T(d_rotation, "d_rotation")
         gfeat = T(gfeat, "gaussian_features")
+        override_color, se3 = T(override_color, "override_color"), T(se3, "d_xyz (is_6dof)")
         P = xyz.shape[0]
         F = gfeat.shape[-1] if gfeat is not None else 0
         if f_rest.shape[1] != 15 or f_dc.shape[1] != 1:
             raise ValueError("fused render expects features_dc (P,1,3) and features_rest (P,15,3)")
+        if override_color is not None and tuple(override_color.shape) != (P, 3):
+            raise ValueError(f"override_color must be ({P}, 3), got {tuple(override_color.shape)}")
+        if se3 is not None and tuple(se3.shape) != (P, 4, 4):
+            raise ValueError(f"is_6dof: d_xyz must be ({P}, 4, 4), got {tuple(se3.shape)}")
+        mask_u8 = None
+        if mask is not None:
+            if mask.dtype != torch.bool or tuple(mask.shape) != (P,) or mask.device != device:
+                raise ValueError(f"mask must be a bool tensor of shape ({P},) on {device}")
+            mask_u8 = mask.contiguous().view(torch.uint8)
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         keep: list = []
         s = _fill_settings(raster_settings, device, keep)
@@ -143,6 +156,13 @@ class _RenderRaw(torch.autograd.Function):
         raw.rotation, raw.d_rotation = _lib.ptr(rotation), _lib.ptr(d_rotation)
         raw.gaussian_features = _lib.ptr(gfeat) if F > 0 else None
         raw.featn = _lib.ptr(featn)
+        raw.colors_precomp, raw.mask, raw.d_xyz_se3 = _lib.ptr(override_color), _lib.ptr(mask_u8), _lib.ptr(se3)
+        raw.sh_dir_undeformed = int(bool(sh_dir_raw))
+        # a forward nobody differentiates (torch.no_grad(), or no input asks for a gradient): the state only a backward reads is
+        # not written (TRASE_VARIANT_FORWARD_ONLY).
+        fwd_only = not (torch.is_grad_enabled() and any(ctx.needs_input_grad))
+        if fwd_only:
+            s.variant |= _r_VARIANT_FORWARD_ONLY
 
         image, feats, depth = _output_maps(F, H, W, device, bool(s.tile_row_begin or s.tile_row_end))
         radii = torch.empty(P, dtype=torch.int32, device=device)
@@ -195,22 +215,31 @@ class _RenderRaw(torch.autograd.Function):
         ctx.param_ids = param_ids              # which parameter OBJECTS the gradients belong to (grad-sink lookup)
         ctx.norm_features = bool(norm_features)
         ctx.opt = (d_xyz is not None, d_scaling is not None, d_rotation is not None, gfeat is not None)
+        ctx.extra = (override_color is not None, mask_u8 is not None, se3 is not None, bool(sh_dir_raw))
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(radii)
         z = xyz.new_empty(0)
+        # under `mask` the reference hands the rasterizer the SUBSET (gaussian_renderer/__init__.py:123-135) and gets the subset's
+        # radii back: the dict's `radii` / `visibility_filter` have mask.sum() entries.  The kernels keep full-size arrays (a
+        # removed Gaussian has radius 0); the subset is taken here -- the one synchronising op of this path (the reference's
+        # seven boolean indexings synchronise seven times).
+        radii_out = radii[mask] if mask is not None else radii
+        ctx.mark_non_differentiable(radii_out)
         ctx.save_for_backward(xyz, d_xyz if d_xyz is not None else z, f_dc, f_rest, opacity, scaling,
                               d_scaling if d_scaling is not None else z, rotation,
                               d_rotation if d_rotation is not None else z, gfeat if gfeat is not None else z,
                               radii, geom, binb, img, pre, featn,
-                              depth if (s.variant & 0x20100) == 0x20100 else None)   # normalised depth + depth gradient
-        return image, radii, feats, depth
+                              depth if (s.variant & 0x20100) == 0x20100 else None,   # normalised depth + depth gradient
+                              override_color if override_color is not None else z,
+                              mask_u8 if mask_u8 is not None else z, se3 if se3 is not None else z)
+        return image, radii_out, feats, depth
 
     @staticmethod
     def backward(ctx, grad_image, grad_radii, grad_feats, grad_depth):
         lib = _lib.load()
         (xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat,
-         radii, geom, binb, img, pre, featn, depth_out) = ctx.saved_tensors
+         radii, geom, binb, img, pre, featn, depth_out, override_color, mask_u8, se3) = ctx.saved_tensors
         has_dxyz, has_dscale, has_drot, has_feat = ctx.opt
+        has_color, has_mask, has_se3, sh_dir_raw = ctx.extra
         P, F, H, W = ctx.dims
         device = xyz.device
         keep: list = []
@@ -226,6 +255,10 @@ class _RenderRaw(torch.autograd.Function):
         raw.rotation, raw.d_rotation = _lib.ptr(rotation), (_lib.ptr(d_rotation) if has_drot else None)
         raw.gaussian_features = _lib.ptr(gfeat) if (has_feat and F > 0) else None
         raw.featn = _lib.ptr(featn)
+        raw.colors_precomp = _lib.ptr(override_color) if has_color else None
+        raw.mask = _lib.ptr(mask_u8) if has_mask else None
+        raw.d_xyz_se3 = _lib.ptr(se3) if has_se3 else None
+        raw.sh_dir_undeformed = int(sh_dir_raw)
         out = _lib.RastOutputs()
         out.radii = _lib.ptr(radii)
         out.depth = _lib.ptr(depth_out)
@@ -287,7 +320,9 @@ class _RenderRaw(torch.autograd.Function):
         g_xyz = alloc(True, xyz, "xyz" if need[0] else None, "xyz")
         g_dxyz = alloc(need[1] and has_dxyz, xyz, None, "dxyz")    # the deformation offsets are not bucket parameters
         g_m2d = alloc(True, xyz, None, "m2d") if sparse else torch.empty(P, 3, device=device)
-        g_dc, g_rest = alloc(need[2], f_dc, "f_dc", "f_dc"), alloc(need[3], f_rest, "f_rest", "f_rest")
+        g_dc, g_rest = alloc(need[2] and not has_color, f_dc, "f_dc", "f_dc"), alloc(need[3] and not has_color, f_rest, "f_rest", "f_rest")
+        g_color = torch.empty_like(override_color) if (has_color and need[13]) else None
+        g_se3 = torch.empty_like(se3) if (has_se3 and need[15]) else None
         g_op, g_sc, g_rot = (alloc(need[4], opacity, "opacity", "opacity"), alloc(need[5], scaling, "scaling", "scaling"),
                              alloc(need[6 + 1], rotation, "rotation", "rotation"))
         g_dsc = alloc(need[6] and has_dscale, scaling, None, "dscaling")
@@ -302,6 +337,7 @@ class _RenderRaw(torch.autograd.Function):
         g.dL_dscaling, g.dL_dd_scaling = _lib.ptr(g_sc), _lib.ptr(g_dsc)
         g.dL_drotation, g.dL_dd_rotation = _lib.ptr(g_rot), _lib.ptr(g_drot)
         g.dL_dgaussian_features = _lib.ptr(g_feat)
+        g.dL_dcolors_precomp, g.dL_dd_xyz_se3 = _lib.ptr(g_color), _lib.ptr(g_se3)
         if sparse:
             # the rows the PREVIOUS strip backward wrote go back to zero first (every buffer of the cache, whether or not this
             # backward uses it); then this one writes the rows of its own live Gaussians
@@ -338,11 +374,11 @@ class _RenderRaw(torch.autograd.Function):
             _lib.check(lib.trase_rast_backward_raw(C.byref(s), C.byref(raw), C.byref(out), C.byref(ws), C.byref(g),
                                                    _stream(device)), "trase_rast_backward_raw")
         if P == 0:
-            for t in (g_xyz, g_dxyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat):
+            for t in (g_xyz, g_dxyz, g_m2d, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat, g_color, g_se3):
                 if t is not None:
                     t.zero_()
         return (g_xyz if need[0] else None, g_dxyz, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat,
-                g_m2d if need[10] else None, None, None)
+                g_m2d if need[10] else None, None, None, g_color, None, g_se3, None)
 
 
 # ---- two views per launch sequence ---------------------------------------------------------------------------------------
@@ -380,6 +416,8 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, d_xyz, d_rotation, d_sca
     global _PAIR
     cams = list(viewpoint_cameras)
     per = lambda d, i: d[i] if isinstance(d, (list, tuple)) else d
+    if kwargs.get("mask") is not None:       # (the subset's radii are taken right behind the forward: nothing to defer)
+        return [render(c, pc, pipe, bg_color, per(d_xyz, i), per(d_rotation, i), per(d_scaling, i), **kwargs) for i, c in enumerate(cams)]
     outs = []
     for i in range(0, len(cams), 2):
         if i + 1 >= len(cams):
@@ -392,6 +430,10 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, d_xyz, d_rotation, d_sca
             pair = [render(cams[j], pc, pipe, bg_color, per(d_xyz, j), per(d_rotation, j), per(d_scaling, j), **kwargs) for j in (i, i + 1)]
             recs, _PAIR = _PAIR, None
             _flush_pair(recs)
+            # render() formed `radii > 0` while the forward was only RECORDED (radii still unwritten: the compare ran ahead of the
+            # kernels that fill it -- ADVICE r5); now that the launch sequence is in the stream, form it again
+            for o in pair:
+                o["visibility_filter"] = o["radii"] > 0
         finally:
             _PAIR = None
         outs.extend(pair)
@@ -412,15 +454,26 @@ def _zero_dummy(like: torch.Tensor) -> torch.Tensor:
 
 
 def _fusable(pc, pipe, d_xyz, d_rotation, d_scaling, is_6dof, override_color, mask, is_smooth) -> bool:
-    if is_6dof or override_color is not None or mask is not None:
+    """Every call pattern of the reference's render() takes the fused raw-parameter path (round 6: override_color, mask, is_6dof and
+    the two Python fallbacks of the pipe included); what is left for the operator-level composition are malformed deformation
+    arguments and SH layouts other than (P,1,3) + (P,15,3)."""
+    N = pc._xyz.shape[0]
+    if is_6dof:
+        if torch.is_tensor(d_xyz) and tuple(d_xyz.shape) != (N, 4, 4):
+            return False
+    elif torch.is_tensor(d_xyz) and d_xyz.dim() != 2:
         return False
-    if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
+    elif not torch.is_tensor(d_xyz) and float(d_xyz) != 0.0:
         return False
-    for d in (d_xyz, d_rotation, d_scaling):
+    for d in (d_rotation, d_scaling):
         if torch.is_tensor(d) and d.dim() != 2:
             return False
         if not torch.is_tensor(d) and float(d) != 0.0:
             return False
+    if override_color is not None and not (torch.is_tensor(override_color) and tuple(override_color.shape) == (N, 3)):
+        return False
+    if mask is not None and not (torch.is_tensor(mask) and mask.dtype == torch.bool and tuple(mask.shape) == (N,)):
+        return False
     return pc._features_rest.shape[1] == 15 and pc._features_dc.shape[1] == 1
 
 
@@ -451,10 +504,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
         else:
             gfeat = smoothed_gaussian_features(pc, K=smooth_K, dropout=0.5) if is_smooth_gaussian_features \
                 else pc._gaussian_features
+        cov_python = bool(getattr(pipe, "compute_cov3D_python", False))
+        # pipe.compute_cov3D_python (gaussian_renderer/__init__.py:93-94): pc.get_covariance(scaling_modifier) is built from the
+        # UNDEFORMED scaling and rotation (scene/gaussian_model.py:216-217) -- the kernels' own Sigma = R S S R^T of exp(_scaling) *
+        # modifier and normalize(_rotation), i.e. the fused path with the two deformation terms left out
+        # pipe.convert_SHs_python (:103-108): clamp_min(eval_sh(...) + 0.5, 0) in the direction of the UNDEFORMED position
+        sh_py = bool(getattr(pipe, "convert_SHs_python", False)) and override_color is None
         rendered_image, radii, rendered_feats, depth = _RenderRaw.apply(
-            pc._xyz, T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, T(d_scaling),
-            pc._rotation, T(d_rotation), gfeat, screenspace_points, raster_settings,
-            norm_gaussian_features)
+            pc._xyz, None if is_6dof else T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling,
+            None if cov_python else T(d_scaling), pc._rotation, None if cov_python else T(d_rotation), gfeat, screenspace_points,
+            raster_settings, norm_gaussian_features, override_color, mask, T(d_xyz) if is_6dof else None, sh_py)
     else:
         # the reference's own composition around the (HIP) rasterizer
         rasterizer = GaussianRasterizer(raster_settings=raster_settings)
@@ -499,5 +558,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
         rendered_image, radii, rendered_feats, depth = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, sh_objs=sh_objs, colors_precomp=colors_precomp,
             opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+    # (render_views: the forward is deferred, `radii` not yet written -- the filter is formed after the flush)
+    return {"render": rendered_image, "viewspace_points": screenspace_points,
+            "visibility_filter": (radii > 0) if _PAIR is None else None,
             "radii": radii, "render_gaussian_features": rendered_feats, "depth": depth}

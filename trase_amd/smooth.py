@@ -38,7 +38,15 @@ class _SmoothFeatures(torch.autograd.Function):
         if sel.device.type == "cpu":
             # (a copy from pageable host memory blocks the host until the stream has drained -- once per iteration, in front of
             # the whole render: through the pinned-memory cache the upload is asynchronous)
-            sel_dev = sel.to(torch.int32).contiguous().pin_memory().to(dev, non_blocking=True)
+            if torch.cuda.is_current_stream_capturing():
+                # whole-iteration capture (torch.cuda.graph): no host-to-device copy inside a capture (a pinned allocation, and the
+                # event query of the pinned-memory cache behind it, invalidate the capture on ROCm 7) -- the few slot numbers are
+                # written by fill kernels with the values as launch arguments.  The draw is FROZEN into the graph.
+                sel_dev = torch.empty(int(sel.numel()), dtype=torch.int32, device=dev)
+                for j, k in enumerate(sel.tolist()):
+                    sel_dev[j:j + 1].fill_(int(k))
+            else:
+                sel_dev = sel.to(torch.int32).contiguous().pin_memory().to(dev, non_blocking=True)
         else:
             sel_dev = sel.to(device=dev, dtype=torch.int32).contiguous()
         S = int(sel_dev.numel())
