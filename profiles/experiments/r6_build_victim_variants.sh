@@ -16,3 +16,12 @@ build noslp "-fno-slp-vectorize" &
 build prio "-DTRASE_RAW_SETPRIO" &
 wait
 ls -la ../lib/variants
+# allnoslp: EVERY translation unit without SLP vectorisation (no compiler-generated v_pk_*_f32 anywhere in the library)
+mkdir -p build/allnoslp
+for f in api preprocess preprocess_raw binning render render_fwd_mf render_bwd_gs render_bwd_hw selftest knn mlp smooth loss optim contrastive densify pairhead nnfm; do
+  x=""; [ $f = pairhead ] && x="-ffp-contract=off"
+  $HIPCC $FLAGS -fno-slp-vectorize $x -c $f.hip -o build/allnoslp/$f.o &
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libtrase_rast_allnoslp.so build/allnoslp/*.o
+ls -la ../lib/variants

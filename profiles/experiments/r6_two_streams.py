@@ -29,8 +29,7 @@ gi, gf = torch.randn(3, H, W, device=dev), torch.randn(F, H, W, device=dev)
 
 
 def victim(i):
-    with torch.no_grad():
-        o = render(cams[i % 16], pc, pipe, bg, 0.0, 0.0, 0.0)
+    o = render(cams[i % 16], pc, pipe, bg, 0.0, 0.0, 0.0)      # (grad mode on: a no_grad forward does not store the colour array read below)
     g = R._Policy.last_geom
     return g[256 + 24 * N: 256 + 40 * N].clone().view(torch.float32).view(N, 4), o["radii"].clone()
 

@@ -72,10 +72,10 @@ def _run(state, monkeypatch):
         graph, (_, static) = capture_iteration(it, warm=2)
         for k in range(8):
             for t in static:                                     # a replay that wrote nothing would otherwise pass on the capture's values
-                if t.dtype.is_floating_point:
-                    t.fill_(float("nan"))
+                if t.dtype.is_floating_point:           # (.data: some are views handed out by an autograd node)
+                    t.data.fill_(float("nan"))
                 else:
-                    t.fill_(-7)
+                    t.data.fill_(-7)
             graph.replay()
             torch.cuda.synchronize()
             assert len(static) == len(eager)

@@ -71,3 +71,44 @@ def test_views_on_several_streams_match_the_serial_run():
             assert not bad, f"views {bad} issued on alternating streams differ from the serial run"
     finally:
         R.set_sync(True)
+
+
+def test_unordered_streams_are_bit_identical_since_the_library_has_no_packed_fp32():
+    """Round 6: the corruption that made the cross-stream ordering necessary hit compiler-generated packed-FP32 VALU instructions
+    (v_pk_*_f32) of a wave beside a kernel feeding transposing LDS reads into MFMAs; the library is built with
+    -fno-slp-vectorize since.  With the ordering OFF (rasterizer.set_stream_ordering(False)) views round-robin on two and three
+    streams -- gradients through torch.autograd.grad: no shared .grad across streams -- must equal the serial run bit for bit."""
+    from gaussian_renderer import render
+    from trase_amd import rasterizer as R
+    n, w, h, feat = 300_000, 1920, 1080, 32
+    dev, pc, pipe, cams, gi, gf = _setup(n, w, h, feat)
+    bg = torch.zeros(3, device=dev)
+    params = pc.parameters()
+
+    def view(i):
+        o = render(cams[i % 8], pc, pipe, bg, 0.0, 0.0, 0.0)
+        gr = torch.autograd.grad([o["render"], o["render_gaussian_features"]], params + [o["viewspace_points"]], [gi, gf], allow_unused=True)
+        ts = [o["render"], o["render_gaussian_features"], o["depth"], o["radii"]] + [t for t in gr if t is not None]
+        return torch.stack([t.contiguous().view(torch.int32).to(torch.int64).sum() for t in ts])
+    R.set_sync(True)
+    try:
+        caps = []
+        for i in range(8):
+            view(i)
+            caps.append(R.last_status()[2])
+        R.set_sync(False, capacity=int(max(caps) * 1.25) + 1024)
+        ref = [view(i).cpu() for i in range(8)]
+        R.set_stream_ordering(False)
+        for ns in (2, 3):
+            streams = [torch.cuda.Stream() for _ in range(ns)]
+            torch.cuda.synchronize()
+            got = []
+            for i in range(48):
+                with torch.cuda.stream(streams[i % ns]):
+                    got.append(view(i))
+            torch.cuda.synchronize()
+            bad = [i for i, d in enumerate(got) if not torch.equal(ref[i % 8], d.cpu())]
+            assert not bad, f"{ns} streams, ordering off: views {bad} differ from the serial run"
+    finally:
+        R.set_stream_ordering(True)
+        R.set_sync(True)

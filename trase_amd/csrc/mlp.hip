@@ -1030,7 +1030,428 @@ __global__ __launch_bounds__(256) void mlp_wreduce_kernel(WreduceJobs jobs) {
   }
 }
 
-static size_t mlp_ws_bytes() {
+// =====================================================================================================================
+// Round 6: the chain kernels in a register-chained, OUTPUT-stationary organisation ("RC").
+//
+// Why: the block kernels above are bound by LDS throughput, not by the matrix pipe.  Per layer and CU they move 768 KB of
+// fragment reads (256 B/clk), 256 KB of weight-slab stores and 128 KB of activation stores (ds_write_b128 / _b64: ~80 B/clk,
+// MI355X_MICROARCH.md "LDS") = ~7 900 LDS cycles against 8 192 matrix-pipe cycles: every imperfection of the overlap is lost time
+// (measured: 39 % of the bf16 peak).  Here
+//   * a WAVE owns 64 rows (two 32-row groups) and ALL 256 columns of a layer; the workgroup (4 waves, one per SIMD, 256 rows)
+//     shares nothing but the weights;
+//   * activations never touch LDS: the fp32 accumulators of an output block, converted to bf16 in place, ARE two B fragments of
+//     the next layer (the weights' K order is permuted to the accumulator layout: k = 32 (ks/2) + 16 (ks%2) + 8 (e/4) + 4 h + e%4
+//     for element e of half h in K-step ks);
+//   * the loop is output-stationary: for each 32-column output block all K-steps run into two accumulators (one per row group),
+//     so one 1-KB weight fragment read from LDS feeds two MFMAs (0.5 KB / MFMA instead of 0.75 + the activation traffic), the
+//     live accumulators are 32 registers instead of 256, and a block's epilogue (bias is the accumulator's initial value; ReLU +
+//     bf16 = 2 VALU per 4 values) issues in the shadow of the next block's MFMAs;
+//   * the weights are ONE linear stream of 1-KB fragments in consumption order (1008 of them for the forward), staged once per
+//     256 rows through a three-slot ring of 16-fragment groups: per group one workgroup barrier, placed in the middle of the
+//     previous group so that the fragment reads run ahead across group boundaries.
+// LDS per layer and CU: 512 KB of reads + 128 KB of stores = ~3 700 cycles against the same 8 192 matrix-pipe cycles.
+constexpr int RC_ROWS = 256;                 // rows per workgroup (4 waves x 64)
+constexpr int RC_G = 16;                     // fragments per staged group (16 KB)
+constexpr int RC_SLOTS = 3;                  // ring slots (groups)
+constexpr int RC_PE_KS = EMBP / 16;          // 6 encoding K-steps
+constexpr int RC_F_L0 = 8 * RC_PE_KS;        // fragments of layer 0 (48)
+constexpr int RC_F_HID = 8 * 16;             // fragments of a hidden layer (128)
+constexpr int RC_F_SKIP = 8 * (RC_PE_KS + 16);   // fragments of the skip layer (176)
+constexpr int RC_F_HEAD = 16;
+constexpr int RC_FWD_FRAGS = RC_F_L0 + 6 * RC_F_HID + RC_F_SKIP + RC_F_HEAD;   // 1008 = 63 groups
+static_assert(RC_FWD_FRAGS % RC_G == 0, "whole groups");
+
+// input column of element e (0..7) of lane half h in hidden K-step ks of the permuted order
+__host__ __device__ constexpr int rc_kperm(int ks, int h, int e) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (e >> 2) + 4 * h + (e & 3); }
+__host__ __device__ constexpr int rc_layer_frag0(int l) {        // first fragment of layer l in the forward stream (l == MD: heads)
+  return l == 0 ? 0 : (l <= SKIP ? RC_F_L0 + (l - 1) * RC_F_HID : RC_F_L0 + (l - 2) * RC_F_HID + RC_F_SKIP);
+}
+
+struct RcNet {
+  const __bf16* wstream;   // [RC_FWD_FRAGS][64 lanes][8]: MFMA A fragments (lane = h * 32 + output column of the block) in consumption order
+  const float* bias;       // [MD][256] then [32] (heads)
+  const float* temb;       // is_blender: the 30 shared timenet outputs; else nullptr
+};
+
+// weight packing for the RC kernels: one thread per fragment element
+__global__ __launch_bounds__(256) void mlp_pack_rc_kernel(MlpPackArgs a, __bf16* __restrict__ ws, float* __restrict__ bias) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < MD * MW) bias[idx] = a.b[idx / MW][idx % MW];
+  if (idx < HEADP) {
+    float v = 0.f;
+    if (idx < 3) v = a.b_warp[idx]; else if (idx < 7) v = a.b_rot[idx - 3]; else if (idx < 10) v = a.b_scale[idx - 7];
+    bias[MD * MW + idx] = v;
+  }
+  if (idx >= RC_FWD_FRAGS * 512) return;
+  const int frag = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, n = lane & 31, h = lane >> 5;
+  const int EMB = a.emb;
+  float v = 0.f;
+  int l = MD;
+  for (int k = MD - 1; k >= 0; --k) if (frag < rc_layer_frag0(k + 1)) l = k;
+  const int f = frag - rc_layer_frag0(l);
+  if (l == MD) {                                   // heads: one block, 16 hidden K-steps
+    const int k = rc_kperm(f, h, e);
+    if (n < 3) v = a.w_warp[n * MW + k]; else if (n < 7) v = a.w_rot[(n - 3) * MW + k]; else if (n < 10) v = a.w_scale[(n - 7) * MW + k];
+  } else {
+    const int pe_ks = (l == 0 || l == SKIP) ? RC_PE_KS : 0;
+    const int per_block = pe_ks + (l == 0 ? 0 : 16);
+    const int nb = f / per_block, ks = f % per_block;
+    const int row = nb * 32 + n;
+    const int kin = l == 0 ? EMB : (l == SKIP ? EMB + MW : MW);
+    if (ks < pe_ks) {
+      const int c = 16 * ks + 8 * h + e;                               // encoding columns in natural order
+      if (c < EMB) v = a.w[l][row * kin + c];
+    } else {
+      v = a.w[l][row * kin + (l == SKIP ? EMB : 0) + rc_kperm(ks - pe_ks, h, e)];
+    }
+  }
+  ws[idx] = (__bf16)v;
+}
+
+// One wave's view of the weight stream: ring slot addresses are compile-time offsets from the lane's base
+struct RcStream {
+  const __bf16* g;          // global stream + this thread's staging offset
+  unsigned char* ring;      // LDS ring base
+  uint4 st[4];              // staging registers: this wave's four fragments of the group being fetched
+};
+
+// 8-byte slot permutation of the 64-byte rows of a wave's transposition scratch (SAVE): slot ^ rc_swz(row) makes both the
+// epilogue's ds_write_b64 (16 lanes = 16 rows, one slot) and the transposing reads (32 lanes = 8 rows x 4 slots) conflict-free
+__device__ __forceinline__ int rc_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 2) & 1) << 2); }
+
+// SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations, the ReLU gates as
+// bits and the encoding image: the SAME saved state as mlp_fwd_blk_body (the backward does not care which forward produced it).
+// FULL: every row of the workgroup's 256 exists (image stores unconditional).
+template <bool SAVE, bool FULL>
+__device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring, float* __restrict__ s_bias, const RcNet& net,
+                                                const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                                                float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
+                                                const int* __restrict__ ro, unsigned char* __restrict__ pe_store,
+                                                unsigned char* __restrict__ scratch = nullptr,
+                                                __bf16* __restrict__ actsT = nullptr, uint32_t* __restrict__ gates = nullptr,
+                                                __bf16* __restrict__ peT = nullptr) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int row0 = blockIdx.x * RC_ROWS + wave * 64;
+  // ---- biases into LDS (8.1 KB), inputs into registers --------------------------------------------------------------
+  for (int i = threadIdx.x; i < MD * MW + HEADP; i += 256) s_bias[i] = net.bias[i];
+  float px[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int gm = min(row0 + 32 * g + m, N - 1);
+    if (ro) gm = ro[gm];
+    px[g][0] = x[3 * gm]; px[g][1] = x[3 * gm + 1]; px[g][2] = x[3 * gm + 2]; px[g][3] = t[(size_t)gm * t_stride];
+  }
+  const bool blender = net.temb != nullptr;
+  float tb[32];
+  {
+    const float* tp = blender ? net.temb : net.bias;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tb[i] = (i < EMB_B - 63) ? tp[i] : 0.f;
+  }
+  // ---- weight stream -----------------------------------------------------------------------------------------------
+  // group G holds fragments 16 G .. 16 G + 15; wave w stages fragments 4 w .. 4 w + 3 of a group (lane: its 16 bytes of each)
+  const __bf16* gsrc = net.wstream + (size_t)(wave * 4) * 512 + (size_t)lane * 8;
+  unsigned char* const wr = ring + (wave * 4) * 1024 + lane * 16;      // where this lane parks its pieces inside a slot
+  const unsigned char* const rd = ring + lane * 16;                      // where it reads a fragment from
+  uint4 st0, st1, st2, st3;                    // (named scalars: as an array the staging registers were promoted to LDS)
+  auto stage_load = [&](int grp) {
+    const __bf16* p = gsrc + (size_t)grp * RC_G * 512;
+    st0 = *reinterpret_cast<const uint4*>(p); st1 = *reinterpret_cast<const uint4*>(p + 512);
+    st2 = *reinterpret_cast<const uint4*>(p + 1024); st3 = *reinterpret_cast<const uint4*>(p + 1536);
+  };
+  auto stage_park = [&](int grp) {
+    unsigned char* q = wr + (grp % RC_SLOTS) * (RC_G * 1024);
+    *reinterpret_cast<uint4*>(q) = st0; *reinterpret_cast<uint4*>(q + 1024) = st1;
+    *reinterpret_cast<uint4*>(q + 2048) = st2; *reinterpret_cast<uint4*>(q + 3072) = st3;
+  };
+  auto frag_read = [&](int f) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(rd + ((f / RC_G) % RC_SLOTS) * (RC_G * 1024) + (f % RC_G) * 1024);
+  };
+  constexpr int NGRP = RC_FWD_FRAGS / RC_G;
+  stage_load(0);
+  stage_park(0);
+  stage_load(1);
+  lds_barrier();
+  // fragment look-ahead: three reads in flight
+  constexpr int LA = 3;
+  bf16x8 wf[LA + 1];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) wf[i] = frag_read(i);
+  // called once per fragment, BEFORE its MFMAs: the group bookkeeping of the stream position f, and the look-ahead read
+  auto advance = [&](int f) {
+    if (f % RC_G == 0) {                       // start of group f/16: park group +1 (fetched during the previous group), fetch group +2
+      const int grp = f / RC_G;
+      if (grp + 1 < NGRP) stage_park(grp + 1);
+      if (grp + 2 < NGRP) stage_load(grp + 2);
+    }
+    if (f % RC_G == RC_G / 2) lds_barrier();   // everybody has parked group +1 (and finished reading group -1): +1 is readable
+    if (f + LA < RC_FWD_FRAGS) wf[(f + LA) % (LA + 1)] = frag_read(f + LA);
+  };
+
+  // the activations of a layer as B fragments, [row group][K-step].  Two banks alternate as a layer's input and output; one lives
+  // in the ARCHITECTURAL registers and one in the ACCUMULATION registers (MFMA reads its B operand from either file; the packed
+  // conversion writes architectural registers only, so the odd layers' outputs are moved over by v_accvgpr_write) -- with both
+  // banks in one file the allocator has no room left for the fragment look-ahead
+  bf16x8 bankA[2][16], bankB[2][16];
+  // the encoding's fragments (layers 0 and 5): generated once, parked in a wave-private 12-KB piece of LDS (lane-linear, read back
+  // like a weight fragment) -- 48 registers that the hidden layers would otherwise carry for nothing
+  unsigned char* const pe_lds = pe_store + wave * (2 * RC_PE_KS * 1024) + lane * 16;
+  bf16x8 pe[2][RC_PE_KS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    pe[g][0] = blk_pe_fragment<0>(h, px[g], blender, tb); pe[g][1] = blk_pe_fragment<1>(h, px[g], blender, tb);
+    pe[g][2] = blk_pe_fragment<2>(h, px[g], blender, tb); pe[g][3] = blk_pe_fragment<3>(h, px[g], blender, tb);
+    pe[g][4] = blk_pe_fragment<4>(h, px[g], blender, tb); pe[g][5] = blk_pe_fragment<5>(h, px[g], blender, tb);
+#pragma unroll
+    for (int k = 0; k < RC_PE_KS; ++k) *reinterpret_cast<bf16x8*>(pe_lds + (g * RC_PE_KS + k) * 1024) = pe[g][k];
+  }
+  auto pe_frag = [&](int g, int k) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(pe_lds + (g * RC_PE_KS + k) * 1024); };
+  // ---- SAVE: the wave's transposition scratch (64 rows x 64 bytes, slots permuted by rc_swz) ----------------------------
+  unsigned char* const scr = SAVE ? scratch + wave * 4096 : nullptr;
+  const int tiles = (N + 31) >> 5;
+  const int u_row0 = __builtin_amdgcn_readfirstlane(row0);
+  PatchLane pl;                                     // (only img_elem / row4 are used: patch_store)
+  int tr_off = 0;                                   // this lane's byte offset for a transposing read of patch (r0 = 0, c0 = 0)
+  int tr_sw = 0;
+  if constexpr (SAVE) {
+    const int grp = lane >> 4, i = lane & 15, jj = i >> 2, cc = i & 3;
+    pl.img_elem = i * 16 + 4 * grp; pl.row4 = 4 * grp; pl.lds_elem = 0; pl.sw = 0; pl.cch = 0;
+    tr_off = (4 * grp + jj) * 64; tr_sw = rc_swz(4 * grp + jj);
+    tr_off += 0 * cc;
+  }
+  // 16-row x 16-column patch (r0 multiple of 16, c0 in {0, 16}) of the scratch, transposed: lane (grp, i) <- column c0 + i, rows r0 + 4 grp ..
+  auto scr_patch_read = [&](int r0, int c0) -> s16x4p {
+    typedef __attribute__((address_space(3))) s16x4p lds_s16x4;
+    const int cc = lane & 3;
+    const int slot = ((c0 >> 2) + cc) ^ tr_sw;      // (r0 is a multiple of 16: rc_swz(row) does not depend on it)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + r0 * 64 + tr_off + slot * 8));
+  };
+  // four bf16 (columns col4 .. col4 + 3 of the scratch block, col4 a multiple of 4) of row `r` (= 32 g + m)
+  auto scr_write4 = [&](int r, int col4, s16x4 v) {
+    *reinterpret_cast<s16x4*>(scr + r * 64 + (((col4 >> 2) ^ rc_swz(r)) * 8)) = v;
+  };
+  // the image patches of the block sitting in the scratch: `which` = 0..3 -> row patch `which` (16 rows), both column patches
+  auto image_store = [&](__bf16* __restrict__ img, int img_cols, int col0, int which) {
+#ifdef RC_DBG_NOIMG
+    return;
+#endif
+    const s16x4p v0 = scr_patch_read(16 * which, 0), v1 = scr_patch_read(16 * which, 16);
+#ifdef RC_DBG_NOSTORE
+    asm volatile("" :: "v"(v0), "v"(v1));
+    return;
+#endif
+    const int growb = u_row0 + 16 * which;
+    __bf16* const base = img + (size_t)(growb >> 5) * ((size_t)img_cols * 32) + (size_t)((growb >> 4) & 1) * ((size_t)img_cols * 16) + (size_t)col0 * 16;
+    if constexpr (FULL) { patch_store(v0, pl, base, 16); patch_store(v1, pl, base + 256, 16); }
+    else if ((growb & ~31) < N) {
+      const int rv = min(max(N - growb, 0), 16);
+      patch_store(v0, pl, base, rv); patch_store(v1, pl, base + 256, rv);
+    }
+  };
+  if constexpr (SAVE) {
+    // the encoding as a transposed image [tile][half][96 columns][16 rows]: three passes of 32 columns through the scratch
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 f8 = __builtin_bit_cast(s16x8, pe[g][2 * pass + k2]);       // lane (m, h): columns 16 (2 pass + k2) + 8 h + 0..7
+          const s16x4 a4 = {f8[0], f8[1], f8[2], f8[3]}, b4 = {f8[4], f8[5], f8[6], f8[7]};
+          scr_write4(32 * g + m, 16 * k2 + 8 * h, a4);
+          scr_write4(32 * g + m, 16 * k2 + 8 * h + 4, b4);
+        }
+#pragma unroll
+      for (int which = 0; which < 4; ++which) image_store(peT, EMBP, 32 * pass, which);
+    }
+  }
+  uint32_t gw[2][4];                                 // SAVE: this lane's ReLU gates of the layer, [row group][word]
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  auto to_acc_file = [](bf16x8 v) -> bf16x8 {
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    const i32x4v s4 = __builtin_bit_cast(i32x4v, v);
+    int a0, a1, a2, a3;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a0) : "v"(s4[0]));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a1) : "v"(s4[1]));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a2) : "v"(s4[2]));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a3) : "v"(s4[3]));
+    const i32x4v r = {a0, a1, a2, a3};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  // Accumulators are double-buffered per output block: the epilogue of block b (ReLU + bf16 -> two B fragments of the next layer
+  // per row group) is issued in FOUR pieces behind the first K-steps of block b + 1 -- one wave per SIMD hides up to five
+  // single-issue instructions per MFMA (MI355X_MICROARCH.md), and a piece is ~10-20 of them behind two MFMAs.  The last block of a
+  // layer finishes inside the first block of the next layer (its fragments are K-steps 14 / 15 there: needed last).
+  f32x16 acc[2][2];
+  // piece p = 2 g + s2 of the epilogue of the block in acc[slot]: fragment (g, K-step 2 nb + s2) of `out`
+  auto epi_piece = [&](auto out_acc_c, bf16x8 (&out)[2][16], int slot, int nb, int p) {
+    constexpr bool OUT_ACC = decltype(out_acc_c)::value;
+    const int g = p >> 1, s2 = p & 1;
+    const f32x16& a = acc[slot][g];
+    const s16x4 lo = relu_bf16x4(a[8 * s2], a[8 * s2 + 1], a[8 * s2 + 2], a[8 * s2 + 3]);
+    const s16x4 hi = relu_bf16x4(a[8 * s2 + 4], a[8 * s2 + 5], a[8 * s2 + 6], a[8 * s2 + 7]);
+    if constexpr (SAVE) {
+      // registers 4 q + j (q = 2 s2, 2 s2 + 1) <-> columns 32 nb + 8 q + 4 h + j: gate bits as in mlp_fwd_blk_body (word nb / 2, bit
+      // (nb & 1) 16 + 4 q + j of the (row, h) record), and the block's [row][column] image for the transposing reads
+      const uint32_t b8 = gate_bits4(lo) | (gate_bits4(hi) << 4);
+      const uint32_t sh = b8 << ((nb & 1) * 16 + 8 * s2);
+      if ((nb & 1) == 0 && s2 == 0) gw[g][nb >> 1] = sh; else gw[g][nb >> 1] |= sh;
+      scr_write4(32 * g + m, 16 * s2 + 4 * h, lo);
+      scr_write4(32 * g + m, 16 * s2 + 8 + 4 * h, hi);
+    }
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (OUT_ACC) out[g][2 * nb + s2] = to_acc_file(__builtin_bit_cast(bf16x8, v));
+    else out[g][2 * nb + s2] = __builtin_bit_cast(bf16x8, v);
+  };
+  // SAVE: what follows the four pieces of a block -- `w` = 0..3: the image patches of row patch w (the block is in the scratch);
+  // after the last block of a layer also the layer's gate words
+  auto epi_image = [&](int l, int nb, int w) {
+    if constexpr (SAVE) {
+      image_store(actsT + (size_t)l * tiles * (MW * 32), MW, 32 * nb, w);
+      if (nb == 7 && w == 3) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int grow = row0 + 32 * g + m;
+          if (FULL || grow < N)
+            *reinterpret_cast<uint4*>(gates + (((size_t)l * N + grow) * 2 + h) * 4) = make_uint4(gw[g][0], gw[g][1], gw[g][2], gw[g][3]);
+        }
+      }
+    }
+  };
+  // one layer: IN -> OUT.  PE_KS encoding K-steps first (layers 0 and 5), then HID hidden K-steps out of `in`.
+  // `pending(step)`: the previous layer's last block (its output bank is THIS layer's input: K-steps 14, 15) -- steps 0..3 its
+  // epilogue pieces, 4..7 (SAVE) its image patches
+  auto layer = [&](auto l_c, auto out_acc_c, bf16x8 (&in)[2][16], bf16x8 (&out)[2][16], auto&& pending) {
+    constexpr int L = decltype(l_c)::value;
+    constexpr int PE_KS = (L == 0 || L == SKIP) ? RC_PE_KS : 0, HID = L == 0 ? 0 : 16, KS = PE_KS + HID;
+    constexpr int F0 = rc_layer_frag0(L);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      // the block's biases: the accumulators' initial value (lane (m, h), register 4 q + j <-> column 32 nb + 8 q + 4 h + j)
+      f32x16 binit;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4v b4 = *reinterpret_cast<const f32x4v*>(s_bias + L * MW + nb * 32 + 8 * q + 4 * h);
+        binit[4 * q] = b4[0]; binit[4 * q + 1] = b4[1]; binit[4 * q + 2] = b4[2]; binit[4 * q + 3] = b4[3];
+      }
+      const int slot = nb & 1;
+      auto prev = [&](int step) {                 // the block before this one
+        if (nb == 0) pending(step);
+        else if (step < 4) epi_piece(out_acc_c, out, slot ^ 1, nb - 1, step);
+        else epi_image(L, nb - 1, step - 4);
+      };
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int f = F0 + nb * KS + ks;
+        advance(f);
+        const bf16x8 w = wf[f % (LA + 1)];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const bf16x8 a = ks < PE_KS ? pe_frag(g, ks < PE_KS ? ks : 0) : in[g][ks >= PE_KS ? ks - PE_KS : 0];
+          acc[slot][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, ks == 0 ? binit : acc[slot][g], 0, 0, 0);
+        }
+        // the previous block's epilogue: one piece per K-step 1..4; SAVE: its image patches behind K-steps 6..9 (a short
+        // block -- layer 0: six K-steps -- takes all four behind its last one)
+        if (ks >= 1 && ks <= 4) prev(ks - 1);
+        if (SAVE && KS >= 10 && ks >= 6 && ks <= 9) prev(ks - 2);
+        if (SAVE && KS < 10 && ks == KS - 1) { prev(4); prev(5); prev(6); prev(7); }
+      }
+    }
+  };
+  auto none = [](int) {};
+  constexpr std::true_type ACC{};
+  constexpr std::false_type ARCH{};
+  // the last block (7, in acc[1]) of layer l, whose output bank is `out`
+  auto last_of = [&](auto out_acc_c, bf16x8 (&out)[2][16], int l) {
+    return [&, l, out_acc_c](int step) { if (step < 4) epi_piece(out_acc_c, out, 1, 7, step); else epi_image(l, 7, step - 4); };
+  };
+  // bankA: accumulation file, bankB: architectural file
+  layer(std::integral_constant<int, 0>{}, ACC, bankB, bankA, none);
+  layer(std::integral_constant<int, 1>{}, ARCH, bankA, bankB, last_of(ACC, bankA, 0));
+  layer(std::integral_constant<int, 2>{}, ACC, bankB, bankA, last_of(ARCH, bankB, 1));
+  layer(std::integral_constant<int, 3>{}, ARCH, bankA, bankB, last_of(ACC, bankA, 2));
+  layer(std::integral_constant<int, 4>{}, ACC, bankB, bankA, last_of(ARCH, bankB, 3));
+  layer(std::integral_constant<int, 5>{}, ARCH, bankA, bankB, last_of(ACC, bankA, 4));
+  layer(std::integral_constant<int, 6>{}, ACC, bankB, bankA, last_of(ARCH, bankB, 5));
+  layer(std::integral_constant<int, 7>{}, ARCH, bankA, bankB, last_of(ACC, bankA, 6));
+  {
+    auto fin = last_of(ARCH, bankB, 7);             // (the last layer's last block: nothing left to hide it behind)
+#pragma unroll
+    for (int st_ = 0; st_ < (SAVE ? 8 : 4); ++st_) fin(st_);
+  }
+  // heads: one 32-wide output block (10 used) out of bankB
+  f32x16 hacc[2];
+  {
+    f32x16 binit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4v b4 = *reinterpret_cast<const f32x4v*>(s_bias + MD * MW + 8 * q + 4 * h);
+      binit[4 * q] = b4[0]; binit[4 * q + 1] = b4[1]; binit[4 * q + 2] = b4[2]; binit[4 * q + 3] = b4[3];
+    }
+    constexpr int F0 = rc_layer_frag0(MD);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      advance(F0 + ks);
+      const bf16x8 w = wf[(F0 + ks) % (LA + 1)];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) hacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, bankB[g][ks], ks == 0 ? binit : hacc[g], 0, 0, 0);
+    }
+  }
+  // the ten outputs of a row sit in two lanes (h = 0: outputs 0-3, 8, 9; h = 1: 4-7): see mlp_fwd_blk_body
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int grow = row0 + 32 * g + m;
+    const bool ok = grow < N;
+    if (ok && ro) grow = ro[grow];
+    float o[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) o[r] = hacc[g][r];
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[3]), __float_as_uint(o[3]), false, false);
+    const float other3 = __uint_as_float(h ? sw[0] : sw[1]);
+    if (ok) {
+      if (h == 0) {
+        float* px3 = d_xyz + (size_t)grow * 3;
+        px3[0] = o[0]; px3[1] = o[1]; px3[2] = o[2];
+        float* ps3 = d_scale + (size_t)grow * 3;
+        ps3[0] = other3; ps3[1] = o[4]; ps3[2] = o[5];
+      } else {
+        *reinterpret_cast<float4*>(d_rot + (size_t)grow * 4) = make_float4(other3, o[0], o[1], o[2]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_fwd_rc_kernel(RcNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                       float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[RC_SLOTS * RC_G * 1024];      // 48 KiB
+  __shared__ __attribute__((aligned(16))) float s_bias[MD * MW + HEADP];
+  __shared__ __attribute__((aligned(1024))) unsigned char pe_store[4 * 2 * RC_PE_KS * 1024];  // per wave: 12 encoding fragments
+  mlp_fwd_rc_body<false, false>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, pe_store);
+}
+
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void mlp_fwd_train_rc_kernel(RcNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                             float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
+                             __bf16* __restrict__ actsT, uint4* __restrict__ gates, const int* __restrict__ ro, __bf16* __restrict__ peT) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[RC_SLOTS * RC_G * 1024];      // 48 KiB
+  __shared__ __attribute__((aligned(16))) float s_bias[MD * MW + HEADP];
+  __shared__ __attribute__((aligned(64))) unsigned char scratch[4 * 4096];                   // per wave: 64 rows x 64 bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char pe_store[4 * 2 * RC_PE_KS * 1024];
+  if ((int)(blockIdx.x + 1) * RC_ROWS <= N)
+    mlp_fwd_rc_body<true, true>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, ro, pe_store, scratch, actsT, reinterpret_cast<uint32_t*>(gates), peT);
+  else
+    mlp_fwd_rc_body<true, false>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, ro, pe_store, scratch, actsT, reinterpret_cast<uint32_t*>(gates), peT);
+}
+
+static size_t mlp_rc_ws_bytes() {
+  return align_up(sizeof(__bf16) * (size_t)RC_FWD_FRAGS * 512) + align_up(sizeof(float) * (MD * MW + HEADP));
+}
+static size_t mlp_ws_bytes_blk() {
   size_t b = 0;
   for (int l = 0; l < MD; ++l) {
     const int kp = l == 0 ? EMBP : (l == SKIP ? EMBP + MW : MW);
@@ -1039,6 +1460,14 @@ static size_t mlp_ws_bytes() {
   b += align_up(sizeof(__bf16) * (size_t)HEADP * MW) + align_up(sizeof(float) * HEADP);
   return b;
 }
+// both organisations' packed weights fit (the block kernels' first, the RC stream behind them): TRASE_MLP_RC switches per call
+static size_t mlp_ws_bytes() { return mlp_ws_bytes_blk() + mlp_rc_ws_bytes(); }
+// TRASE_MLP_RC: 1 (default) = the register-chained INFERENCE kernel of round 6 (0.248 against 0.300 ms at 300k rows), 0 = the block
+// kernel (cross-check / A/B baseline).  TRASE_MLP_RC_TRAIN: 1 = the register-chained TRAINING forward; default 0 -- with the saved
+// state's extra issue slots (scratch stores, gate bits, transposing reads, image stores: ~250 single-issue instructions per 32
+// MFMAs where ~160 hide) it measures 0.50 ms against the block kernel's 0.44 (profiles/r6_ab_experiments.txt)
+static bool mlp_use_rc() { static const bool on = [] { const char* e = getenv("TRASE_MLP_RC"); return !e || atoi(e) != 0; }(); return on; }
+static bool mlp_use_rc_train() { static const bool on = [] { const char* e = getenv("TRASE_MLP_RC_TRAIN"); return e && atoi(e) != 0; }(); return on; }
 
 // ---- buffer plans of the training pair ---------------------------------------------------------------------
 struct MlpSaved {            // written by the training forward, read by the backward
@@ -1129,6 +1558,26 @@ static int mlp_pack_forward(const TraseMlpWeights* w, void* ws, MlpNet& net, hip
   return TRASE_OK;
 }
 
+// pack the fp32 parameters into the RC weight stream (behind the block kernels' region of `ws`)
+static int mlp_pack_rc(const TraseMlpWeights* w, void* ws, RcNet& net, hipStream_t stream) {
+  MlpPackArgs pa;
+  for (int l = 0; l < MD; ++l) { pa.w[l] = w->weight[l]; pa.b[l] = w->bias[l]; pa.out_w[l] = nullptr; pa.out_b[l] = nullptr; }
+  pa.out_wh = nullptr; pa.out_bh = nullptr;
+  pa.w_warp = w->w_warp; pa.b_warp = w->b_warp; pa.w_rot = w->w_rotation; pa.b_rot = w->b_rotation;
+  pa.w_scale = w->w_scaling; pa.b_scale = w->b_scaling;
+  pa.emb = w->is_blender ? EMB_B : EMB_T;
+  char* c = (char*)ws + mlp_ws_bytes_blk();
+  __bf16* stream_w = (__bf16*)c; c += align_up(sizeof(__bf16) * (size_t)RC_FWD_FRAGS * 512);
+  float* bias = (float*)c;
+  net.wstream = stream_w; net.bias = bias; net.temb = nullptr;
+  {
+    ProfScope ps("mlp_pack", stream);
+    hipLaunchKernelGGL(mlp_pack_rc_kernel, dim3((RC_FWD_FRAGS * 512 + 255) / 256), dim3(256), 0, stream, pa, stream_w, bias);
+  }
+  TRASE_POST_LAUNCH("mlp_pack", stream, 0);
+  return TRASE_OK;
+}
+
 }  // namespace trase
 
 using namespace trase;
@@ -1159,12 +1608,21 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
   if (!ws || ws_bytes < mlp_ws_bytes()) { set_error("trase_mlp_forward: workspace too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
+  if (w->is_blender && t_stride != 0) { set_error("trase_mlp_forward: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
+  if (mlp_use_rc()) {
+    RcNet rnet;
+    if (int rc = mlp_pack_rc(w, ws, rnet, stream)) return rc;
+    if (w->is_blender) rnet.temb = t;
+    {
+      ProfScope ps("mlp_fwd", stream);
+      hipLaunchKernelGGL(mlp_fwd_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
+    }
+    TRASE_POST_LAUNCH("mlp_fwd", stream, 0);
+    return TRASE_OK;
+  }
   MlpNet net;
   if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
-  if (w->is_blender) {                                     // t = the 30 timenet outputs shared by all rows
-    if (t_stride != 0) { set_error("trase_mlp_forward: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
-    net.temb = t;
-  }
+  if (w->is_blender) net.temb = t;                         // t = the 30 timenet outputs shared by all rows
   {
     ProfScope ps("mlp_fwd", stream);
     const dim3 block(MWAVES * WAVE);
@@ -1195,12 +1653,22 @@ int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const
   if (!saved || saved_bytes < sv.bytes) { set_error("trase_mlp_forward_train: saved-state buffer too small"); return TRASE_ERR_WORKSPACE; }
   hipStream_t stream = (hipStream_t)stream_;
   TRASE_CHECK(hipSetDevice(device));
+  if (w->is_blender && t_stride != 0) { set_error("trase_mlp_forward_train: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
+  if (mlp_use_rc_train()) {
+    RcNet rnet;
+    if (int rc = mlp_pack_rc(w, ws, rnet, stream)) return rc;
+    if (w->is_blender) rnet.temb = t;
+    {
+      ProfScope ps("mlp_fwd_train", stream);
+      hipLaunchKernelGGL(mlp_fwd_train_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N,
+                         d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order, sv.peT);
+    }
+    TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
+    return TRASE_OK;
+  }
   MlpNet net;
   if (int rc = mlp_pack_forward(w, ws, net, stream)) return rc;
-  if (w->is_blender) {
-    if (t_stride != 0) { set_error("trase_mlp_forward_train: is_blender takes the timenet output (30 floats) with t_stride 0"); return TRASE_ERR_INVALID; }
-    net.temb = t;
-  }
+  if (w->is_blender) net.temb = t;
   {
     ProfScope ps("mlp_fwd_train", stream);
     const dim3 block(MWAVES * WAVE);

@@ -329,9 +329,11 @@ int launch_preprocess_fwd_raw(const LaunchCtx& c, const TraseRastSettings& s, co
   a.strip = (s.tile_row_begin != 0 || s.tile_row_end != 0) ? 1 : 0;
   a.p_begin = 0; a.p_end = raw.P;
   a.colors = raw.colors_precomp; a.mask = raw.mask; a.se3 = raw.d_xyz_se3; a.sh_dir_raw = raw.sh_dir_undeformed;
-  // the arrays only the backward (and the VALU forward) reads need not be written under no_grad
-  a.fwd_only = ((c.variant & TRASE_VARIANT_FORWARD_ONLY) != 0 && (c.variant & TRASE_VARIANT_VALU_FORWARD) == 0 && raw.F == 32) ? 1 : 0;
-  const bool infer = a.colors || a.mask || a.se3 || a.sh_dir_raw || a.fwd_only;
+  // (TRASE_VARIANT_FORWARD_ONLY is honoured by the compositing kernel only: here it would have to select another instantiation
+  // than the training forward's, and two compilations of the same arithmetic are not bit-identical -- a no_grad render must equal
+  // the training render of the same view; the 20 bytes per Gaussian at stake are 7 % of this kernel's traffic)
+  a.fwd_only = 0;
+  const bool infer = a.colors || a.mask || a.se3 || a.sh_dir_raw;
   const int blk = a.strip ? 256 : RAW_BLOCK;
   const dim3 grid((raw.P + blk - 1) / blk), block(blk);
   {

@@ -413,7 +413,8 @@ def last_tile_row_loads(allreduce: bool = False) -> torch.Tensor:
 def geom_view(geom: torch.Tensor, P: int) -> dict:
     """Typed views of the per-Gaussian forward state inside a geom workspace (introspection for the parity tests;
     the counterpart of inspecting the reference's geomBuffer): xy (P,2), conic_opacity (P,4), rgb_depth (P,4),
-    tiles (P,) int32.  Entries of culled Gaussians (radii == 0) are undefined."""
+    tiles (P,) int32.  Entries of culled Gaussians (radii == 0) are undefined; `rgb_depth` is not written by a fused render()
+    that ran under torch.no_grad() (TRASE_VARIANT_FORWARD_ONLY: only a backward reads it)."""
     off = (C.c_int64 * 6)()
     _lib.check(_lib.load().trase_rast_geom_layout(int(P), C.byref(off)), "trase_rast_geom_layout")
 
@@ -437,6 +438,18 @@ def _capturing() -> bool:
 
 _LAST_STREAM: dict = {}     # device index -> the stream of the library's most recent launch sequence on that device
 _UNORDERED_STREAMS = os.environ.get("TRASE_UNORDERED_STREAMS", "0") != "0"   # experiments only (profiles/r4_two_streams.md): no cross-stream wait
+
+
+def set_stream_ordering(flag: bool = True):
+    """True (default): launch sequences of the library on DIFFERENT streams of one device are kept in order (a device-side wait on a
+    change of stream) -- the conservative guard of rounds 4-5.  False: every call simply goes to the caller's current stream, like
+    any torch operator; views on two streams then share the chip (+5 % views/s at S4, `views_in_flight_2` of the bench line).
+    Safe since round 6: the corruption the guard was built against hit compiler-generated packed-FP32 VALU instructions beside
+    MFMA + transposing-read kernels, and the library is built without them (profiles/r6_two_streams.md; 288 views in flight on 2 / 3
+    streams bit-identical to the serial run).  Gradients of views in flight must not share `.grad` tensors (use
+    torch.autograd.grad, or per-stream parameters): autograd's accumulation across streams is the caller's business."""
+    global _UNORDERED_STREAMS
+    _UNORDERED_STREAMS = not bool(flag)
 
 
 def _stream(device) -> C.c_void_p:

@@ -115,7 +115,7 @@ def chunk_ranges(P: int, chunks: int):
 class _RenderRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, d_xyz, f_dc, f_rest, opacity, scaling, d_scaling, rotation, d_rotation, gfeat, means2D,
-                raster_settings, norm_features, override_color=None, mask=None, se3=None, sh_dir_raw=False):
+                raster_settings, norm_features, override_color=None, mask=None, se3=None, sh_dir_raw=False, fwd_only=False):
         # override_color (P,3) / mask (P) bool / se3 (P,4,4): render()'s inference call patterns (gaussian_renderer/__init__.py:75-80,
         # :112-113, :123-135), sh_dir_raw: pipe.convert_SHs_python (:103-108) -- all inside the per-Gaussian kernels (round 6)
         lib = _lib.load()
@@ -158,9 +158,9 @@ class _RenderRaw(torch.autograd.Function):
         raw.featn = _lib.ptr(featn)
         raw.colors_precomp, raw.mask, raw.d_xyz_se3 = _lib.ptr(override_color), _lib.ptr(mask_u8), _lib.ptr(se3)
         raw.sh_dir_undeformed = int(bool(sh_dir_raw))
-        # a forward nobody differentiates (torch.no_grad(), or no input asks for a gradient): the state only a backward reads is
-        # not written (TRASE_VARIANT_FORWARD_ONLY).
-        fwd_only = not (torch.is_grad_enabled() and any(ctx.needs_input_grad))
+        # fwd_only: render() was called under torch.no_grad() -- nobody will differentiate this forward, and the state only a
+        # backward reads is not written (TRASE_VARIANT_FORWARD_ONLY).  (Decided by the caller: inside an autograd Function's
+        # forward the grad mode is always off.)
         if fwd_only:
             s.variant |= _r_VARIANT_FORWARD_ONLY
 
@@ -378,7 +378,7 @@ class _RenderRaw(torch.autograd.Function):
                 if t is not None:
                     t.zero_()
         return (g_xyz if need[0] else None, g_dxyz, g_dc, g_rest, g_op, g_sc, g_dsc, g_rot, g_drot, g_feat,
-                g_m2d if need[10] else None, None, None, g_color, None, g_se3, None)
+                g_m2d if need[10] else None, None, None, g_color, None, g_se3, None, None)
 
 
 # ---- two views per launch sequence ---------------------------------------------------------------------------------------
@@ -513,7 +513,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, d_xyz, d_rotation
         rendered_image, radii, rendered_feats, depth = _RenderRaw.apply(
             pc._xyz, None if is_6dof else T(d_xyz), pc._features_dc, pc._features_rest, pc._opacity, pc._scaling,
             None if cov_python else T(d_scaling), pc._rotation, None if cov_python else T(d_rotation), gfeat, screenspace_points,
-            raster_settings, norm_gaussian_features, override_color, mask, T(d_xyz) if is_6dof else None, sh_py)
+            raster_settings, norm_gaussian_features, override_color, mask, T(d_xyz) if is_6dof else None, sh_py,
+            not torch.is_grad_enabled())
     else:
         # the reference's own composition around the (HIP) rasterizer
         rasterizer = GaussianRasterizer(raster_settings=raster_settings)
