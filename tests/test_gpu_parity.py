@@ -808,17 +808,28 @@ def test_deform_mlp_matches_reference_golden():
     # torch.autocast(bfloat16)).  The tight check against a bf16-evaluated reference is the next test.
     leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     dxg, drg, dsg = deform_forward(leaf, x, t)
-    assert torch.equal(dxg, dx) and torch.equal(drg, dr) and torch.equal(dsg, ds)
+    # (round 6: inference runs the register-chained kernel, training the block kernel -- the same bf16 products summed in another
+    # order, and an activation that lands on the other side of a bf16 rounding boundary moves its consumers by one bf16 ulp: equal to
+    # the accuracy both have against fp32 (4e-4 of scale), no longer bit for bit)
+    for a_, b_ in ((dxg, dx), (drg, dr), (dsg, ds)):
+        assert float((a_ - b_).abs().max()) <= 4e-4 * max(float(b_.abs().max()), 1.0), "training forward vs inference forward"
     gx, gr, gs = (torch.from_numpy(d[k]).cuda() for k in ("gx", "gr", "gs"))
     torch.autograd.backward((dxg, drg, dsg), (gx, gr, gs))
     for k, p in leaf.items():
         want = torch.from_numpy(d["grad_" + k]).cuda()
         assert p.grad.shape == want.shape
         rel = float((p.grad - want).norm() / want.norm())
-        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else 0.2)
+        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else HIDDEN_GRAD_TOL)
+        print(f"[measured] default net grad {k}: rel L2 to the fp32 golden {rel:.4f} (bar {tol})")
         assert rel < tol, f"grad {k}: relative L2 distance to the fp32 golden gradient {rel:.3e}"
     with pytest.raises(NotImplementedError):
         deform_forward(leaf, x.clone().requires_grad_(True), t)
+
+
+# hidden-layer weight gradients of the bf16 network against the fp32 golden (ReLU gate flips + bf16 dZ between layers): the bars are
+# 1.3 x the largest distance measured on MI355X (round 6; until then 0.2 / 0.25 without a measurement beside them); that training
+# through these gradients behaves like fp32 training is tests/test_gpu_mlp_convergence.py's business
+HIDDEN_GRAD_TOL, HIDDEN_GRAD_TOL_BLENDER = 0.152, 0.173      # measured worst tensors: 0.1168 (linear.0.bias), 0.1331 (is_blender linear.1.bias)
 
 
 def _bf16_evaluated_net(net, x, t):
@@ -958,13 +969,14 @@ def test_deform_mlp_blender_variant_matches_reference_golden_and_bf16_autograd()
         assert torch.equal(got, got0), name
     leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     og = deform_forward(leaf, x, t, is_blender=True)
-    assert all(torch.equal(a, b) for a, b in zip(og, out))
+    assert all(float((a - b).abs().max()) <= 4e-4 * max(float(b.abs().max()), 1.0) for a, b in zip(og, out))      # (see the default network's test)
     torch.autograd.backward(og, tuple(torch.from_numpy(d[k]).cuda() for k in ("gx", "gr", "gs")))
     for k, p in leaf.items():
         want = torch.from_numpy(d["grad_" + k]).cuda()
         assert p.grad is not None and p.grad.shape == want.shape, k
         rel = float((p.grad - want).norm() / want.norm())
-        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else 0.25)
+        tol = 5e-3 if k.startswith("gaussian_") and k.endswith("bias") else (2e-2 if k.startswith("gaussian_") else HIDDEN_GRAD_TOL_BLENDER)
+        print(f"[measured] is_blender net grad {k}: rel L2 to the fp32 golden {rel:.4f} (bar {tol})")
         assert rel < tol, f"grad {k}: relative L2 distance to the fp32 golden gradient {rel:.3e}"
     # (b) bf16-evaluated autograd, many rows
     torch.manual_seed(5)
