@@ -102,7 +102,7 @@ ImgBuf carve_img(void* ptr, int W, int H) {
 }
 static size_t sort_bytes_common(size_t n, int digit_bits = 8) {   // hist + digit_total
   const size_t nd = (size_t)1 << digit_bits;
-  return align_up(sizeof(uint32_t) * nd * (size_t)rs_blocks(n)) + align_up(sizeof(uint32_t) * nd * 8);
+  return align_up(sizeof(uint32_t) * nd * (size_t)rs_blocks(n) * rs_hist_copies(rs_blocks(n))) + align_up(sizeof(uint32_t) * nd * 8);
 }
 // bits of a packed list value left for the pair index (HDR_PACK); 0 = the variant's kernels need emit-order slots
 static int list_pack_bits(const TraseRastSettings* s, int P) {
@@ -126,9 +126,10 @@ PreBuf carve_pre(void* ptr, int P) {
   t.id_end = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.live_ids = (uint32_t*)c; c += align_up(sizeof(uint32_t) * p);
   t.block_sums = (uint32_t*)c; c += align_up(sizeof(uint32_t) * (p / 1024 + 2) * 3);
-  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * ((size_t)1 << DEPTH_MAX_DIGIT_BITS) * (size_t)rs_blocks(p));
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * ((size_t)1 << DEPTH_MAX_DIGIT_BITS) * (size_t)rs_blocks(p) * rs_hist_copies(rs_blocks(p)));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(p);
+  t.sort.hist_copies = rs_hist_copies(rs_blocks(p));
   return t;
 }
 size_t tmp_bytes(int64_t cap) {
@@ -143,9 +144,10 @@ PairBuf carve_tmp(void* ptr, int64_t cap) {
   t.spare_vals = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n);
   t.pair_gauss = (uint32_t*)c; c += align_up(sizeof(uint32_t) * n);
   t.sort.vals[0] = t.sort.vals[1] = nullptr;
-  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n));
+  t.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n) * rs_hist_copies(rs_blocks(n)));
   t.sort.digit_total = (uint32_t*)c;
   t.sort.nb_max = rs_blocks(n);
+  t.sort.hist_copies = rs_hist_copies(rs_blocks(n));
   return t;
 }
 size_t bwd_tmp_bytes(int P, int F, int64_t cap) {
@@ -571,7 +573,8 @@ static int forward_raw_pair_impl(const TraseRastSettings* const s[2], const Tras
   SortBufs cs;
   for (int i = 0; i < 2; ++i) { cs.keys[i] = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * n); }
   for (int i = 0; i < 2; ++i) { cs.vals[i] = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * n); }
-  cs.hist = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n));
+  cs.hist = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * 256 * (size_t)rs_blocks(n) * rs_hist_copies(rs_blocks(n)));
+  cs.hist_copies = rs_hist_copies(rs_blocks(n));
   cs.digit_total = (uint32_t*)cp; cp += align_up(sizeof(uint32_t) * 256 * 8);
   cs.nb_max = rs_blocks(n);
   uint32_t* n_word = (uint32_t*)cp;

@@ -38,8 +38,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                                 int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t* __restrict__ digit_total, int nb_max,
-                                                                uint32_t flag_key = 0u, uint32_t* __restrict__ flag_word = nullptr) {
+                                                                uint32_t flag_key = 0u, uint32_t* __restrict__ flag_word = nullptr,
+                                                                uint32_t* __restrict__ zero_from = nullptr, uint32_t zero_words = 0u) {
   constexpr int ND = 1 << DB;
+  // short sorts: the histograms of the LATER passes are filled by the scatter kernels with atomics -- cleared here (grid-stride,
+  // by every workgroup of the launch, also the ones behind n)
+  for (uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * RS_THREADS) zero_from[i] = 0u;
   const uint32_t n = dev_n(n_ptr, cap);
   const uint32_t base = blockIdx.x * RS_TILE;
   if (base >= n) return;
@@ -149,11 +153,15 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(const uint32_t* __restr
 // lanes holding the same digit find each other through DB bit-plane ballots; the rank inside the
 // round is the number of lower lanes in the peer set, the rank across rounds comes from a
 // per-wave running counter in LDS.
-template <bool IOTA, int DB>
+// SMALL (short sorts, see RS_SMALL_NB): `hist` holds the RAW per-workgroup counts of this pass -- every workgroup sums its digits' rows
+// itself (counts of the workgroups before it, and of all); `hist_next` (when not null) receives the counts of the next pass's digit
+// at the items' destinations
+template <bool IOTA, int DB, bool SMALL = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
-    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total, int nb_max) {
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total, int nb_max,
+    uint32_t* __restrict__ hist_next = nullptr, int shift_next = 0, uint32_t mask_next = 0u) {
   constexpr int ND = 1 << DB;
   constexpr int DPT = ND / RS_THREADS;          // digits per thread in the per-digit steps: thread t owns [t DPT, (t + 1) DPT)
   const uint32_t n = dev_n(n_ptr, cap);
@@ -172,10 +180,27 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   volatile uint32_t* cnt = wcount[wave];
   // (thread t: the global totals of its digits and this workgroup's offsets inside them -- requested now, used after the ranking)
   uint32_t my_digit_total[DPT], my_hist[DPT];
+  if constexpr (SMALL) {
+    const int nb = (int)((n + RS_TILE - 1) / RS_TILE);
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      const uint32_t* row = hist + (size_t)(threadIdx.x * DPT + j) * nb_max;
+      uint32_t before = 0, total = 0;
+      for (int b0 = 0; b0 < nb; b0 += 8) {            // eight loads in flight
+        uint32_t v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (b0 + u < nb) ? row[b0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { total += v8[u]; before += (b0 + u < (int)blockIdx.x) ? v8[u] : 0u; }
+      }
+      my_digit_total[j] = total; my_hist[j] = before;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < DPT; ++j) {
     my_digit_total[j] = digit_total[threadIdx.x * DPT + j];
     my_hist[j] = hist[(size_t)(threadIdx.x * DPT + j) * nb_max + blockIdx.x];
+  }
   }
   // every key and value of the thread is requested up front: inside the ranking loop (volatile LDS counters, wave barriers)
   // the compiler waited for each round's pair of loads before ranking it -- eight dependent round trips per workgroup
@@ -265,6 +290,23 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t dst = gbase[dg] + (j - lstart[dg]);
     keys_out[dst] = kk;
     vals_out[dst] = st_v[j];
+    if constexpr (SMALL) {
+      if (hist_next) {
+        // consecutive items of the block's sorted order mostly share (next digit, destination workgroup) -- depth keys of a small
+        // scene agree in their upper digits, sub-tile ids come in runs: one atomic per RUN inside the wave (as radix_hist does),
+        // not per item (1 000 atomics on ONE word cost 25 us)
+        const uint32_t word = ((kk >> shift_next) & mask_next) * (uint32_t)nb_max + dst / RS_TILE;
+        const uint32_t prev = (uint32_t)__shfl_up((int)word, 1);
+        const bool start = lane == 0 || prev != word;
+        const unsigned long long starts = __ballot(start), act = __ballot(true);
+        if (start) {
+          const unsigned long long later = (lane == 63) ? 0ull : (starts >> (lane + 1));
+          const unsigned nact = (unsigned)__popcll(act);               // active lanes are a prefix of the wave (j ascending)
+          const unsigned next = later ? (lane + 1 + (unsigned)__builtin_ctzll(later)) : nact;
+          atomicAdd(hist_next + word, next - lane);
+        }
+      }
+    }
   }
 }
 
@@ -321,6 +363,40 @@ static int radix_sort_pairs_t(const LaunchCtx& c, const SortBufs& t, const uint3
   if (nb > t.nb_max) { set_error("radix_sort_pairs: nb %d > nb_max %d", nb, t.nb_max); return TRASE_ERR_WORKSPACE; }
   const int passes = radix_passes(bit_lo, bit_hi, DB);
   if (passes > 8) return TRASE_ERR_INVALID;
+  static const bool small_off = [] { const char* e = getenv("TRASE_SORT_SMALL"); return e && atoi(e) == 0; }();
+  if (nb <= RS_SMALL_NB && t.hist_copies >= passes && !small_off) {
+    // short sort: 1 + passes launches (see RS_SMALL_NB in common.h)
+    const size_t hw = (size_t)ND * t.nb_max;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = bit_lo + DB * p;
+      const int nbits = (bit_hi - shift) < DB ? (bit_hi - shift) : DB;
+      const uint32_t mask = (1u << nbits) - 1u;
+      const int shift_n = shift + DB;
+      const int nbits_n = (bit_hi - shift_n) < DB ? (bit_hi - shift_n) : DB;
+      uint32_t* hist_p = t.hist + hw * p;
+      uint32_t* hist_n = (p + 1 < passes) ? t.hist + hw * (p + 1) : nullptr;
+      if (p == 0) {
+        ProfScope ps("radix_hist", c.stream);
+        hipLaunchKernelGGL(radix_hist_kernel<DB>, dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], n_ptr, n_cap, shift, mask, hist_p,
+                           t.digit_total, t.nb_max, flag_key, flag_word, t.hist + hw, (uint32_t)(hw * (passes - 1)));
+      }
+      TRASE_POST_LAUNCH("radix_hist", c.stream, c.debug);
+      {
+        ProfScope ps("radix_scatter", c.stream);
+        const uint32_t mask_n = hist_n ? ((1u << nbits_n) - 1u) : 0u;
+        if (vals_are_iota && p == 0)
+          hipLaunchKernelGGL((radix_scatter_kernel<true, DB, true>), dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], t.vals[cur],
+                             t.keys[cur ^ 1], t.vals[cur ^ 1], n_ptr, n_cap, shift, mask, hist_p, t.digit_total, t.nb_max, hist_n, shift_n, mask_n);
+        else
+          hipLaunchKernelGGL((radix_scatter_kernel<false, DB, true>), dim3(nb), dim3(RS_THREADS), 0, c.stream, t.keys[cur], t.vals[cur],
+                             t.keys[cur ^ 1], t.vals[cur ^ 1], n_ptr, n_cap, shift, mask, hist_p, t.digit_total, t.nb_max, hist_n, shift_n, mask_n);
+      }
+      TRASE_POST_LAUNCH("radix_scatter", c.stream, c.debug);
+      cur ^= 1;
+    }
+    *out_idx = cur;
+    return TRASE_OK;
+  }
   for (int p = 0; p < passes; ++p) {
     const int shift = bit_lo + DB * p;
     const int nbits = (bit_hi - shift) < DB ? (bit_hi - shift) : DB;

@@ -305,7 +305,17 @@ struct SortBufs {          // ping-pong storage of one radix sort
   uint32_t* hist;          // (digits * nb_max), digits = 256 (2048 for the depth sort)
   uint32_t* digit_total;   // (digits * passes) one row per radix pass
   int nb_max;
+  int hist_copies;         // how many (digits * nb_max) histograms `hist` holds: >= the number of passes enables the short sorts' fused passes
 };
+// Short sorts (at most RS_SMALL_NB workgroups of 2048 items = 32k items: BASELINE config 1, small test scenes): a pass is ONE launch --
+// the scatter workgroups scan the per-workgroup histograms themselves and count the NEXT pass's digits at the destinations with
+// global integer atomics (deterministic; one per run of equal words inside a wave), so a sort of p passes is 1 + p launches instead
+// of 3 p.  Measured (profiles/r6_ab_experiments.txt): 1 000 Gaussians at 128 x 128: radix kernels 0.105 -> 0.060 ms per view.  NOT
+// for longer sorts: device-scope atomics are served behind the per-XCD L2s -- at 150k keys (74 workgroups) a fused pass took 28 us
+// against 15 us for its three launches
+constexpr int RS_SMALL_NB = 16;
+constexpr int RS_SMALL_COPIES = 4;
+inline int rs_hist_copies(int nb) { return nb <= RS_SMALL_NB ? RS_SMALL_COPIES : 1; }
 struct PreBuf {            // stage-1 scratch (P-sized), read again by stage 2
   SortBufs sort;           // depth sort; sorted ids end in sort.vals[0]
   uint32_t* offsets;       // (P) inclusive scan of tiles in depth-rank order

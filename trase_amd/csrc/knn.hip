@@ -261,6 +261,7 @@ static KnnWs knn_carve(void* ptr, int N) {
   w.sort.hist = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * nb);
   w.sort.digit_total = (uint32_t*)c; c += align_up(sizeof(uint32_t) * 256 * 8);
   w.sort.nb_max = (int)nb;
+  w.sort.hist_copies = 1;
   w.buckets = (uint2*)c;
   return w;
 }
