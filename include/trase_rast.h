@@ -420,10 +420,12 @@ int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, in
 /* The combination train.py:235-238 forms with scalar tensor arithmetic, `(1 - lambda_dssim) * Ll1 + lambda_dssim * (1 - ssim(image,
  * gt))`, inside the same two launches: out3 = {l1, ssim, loss} (device floats); the backward takes ONE cotangent g = dL/dloss (a
  * device float) and scales it by (1 - lambda) and -lambda itself -- the ~10 scalar kernels autograd launches for the composition
- * (and their host time) disappear.  lambda_dssim in [0, 1]. */
-int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+ * (and their host time) disappear.  lambda_dssim in [0, 1], a DOUBLE as in the reference's Python: the two weights are (float)(1.0 -
+ * lambda) and (float)lambda, what torch's tensor-times-Python-scalar arithmetic multiplies with (1.0f - (float)lambda is one ulp off
+ * for lambda = 0.35). */
+int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, double lambda_dssim,
                                    float* out3, void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream);
-int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, double lambda_dssim,
                                     const float* g, const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device,
                                     trase_stream_t stream);
 

@@ -173,9 +173,9 @@ SYMBOLS = [
                                              C.c_size_t, C.c_int32, C.c_void_p]),
     ("trase_loss_l1_ssim_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
-    ("trase_loss_photometric_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+    ("trase_loss_photometric_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
                                                  C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
-    ("trase_loss_photometric_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+    ("trase_loss_photometric_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
                                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     ("trase_contrastive_sizes", C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     ("trase_contrastive_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,

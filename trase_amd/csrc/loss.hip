@@ -128,9 +128,19 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   }
 }
 
+// (1 - lambda) l1 + lambda (1 - ssim) with every operation rounded on its own (HIP's default -ffp-contract=fast fuses a * b + c,
+// also through __fmul_rn / __fadd_rn, which are plain operators there)
+__device__ __noinline__ float combine_rounded(float w1, float l1, float w2, float ss) {
+#pragma clang fp contract(off)
+  const float p1 = w1 * l1;
+  const float om = 1.0f - ss;
+  const float p2 = w2 * om;
+  return p1 + p2;
+}
+
 // lambda_dssim >= 0: out2 has a third slot that receives train.py:235-238's combination (1 - lambda) l1 + lambda (1 - ssim)
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int nblocks, float inv_count,
-                                                          float* __restrict__ out2, float lambda_dssim) {
+                                                          float* __restrict__ out2, float lambda_dssim, float one_minus_lambda) {
   __shared__ double sh[2][256];
   double a = 0.0, b = 0.0;
   for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * 256) {   // eight pairs in flight; same summation order as one by one
@@ -152,7 +162,9 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   if (threadIdx.x == 0) {
     const float l1 = (float)(sh[0][0] * inv_count), ss = (float)(sh[1][0] * inv_count);
     out2[0] = l1; out2[1] = ss;
-    if (lambda_dssim >= 0.f) out2[2] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss);
+    // the two products and the sum individually rounded, as torch's tensor arithmetic forms train.py:235-238 (a contracted fma
+    // differs in the last bit: the combination is asserted bit-identical to the composition around l1_ssim)
+    if (lambda_dssim >= 0.f) out2[2] = combine_rounded(one_minus_lambda, l1, lambda_dssim, ss);
   }
 }
 
@@ -270,7 +282,7 @@ int trase_loss_sizes(int32_t C, int32_t H, int32_t W, size_t* ws_bytes) {
   return TRASE_OK;
 }
 
-static int loss_forward(const char* who, const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, float lambda_dssim,
+static int loss_forward(const char* who, const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, double lambda_dssim,
                         void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
   if (!img || !gt || !out2 || C < 1 || H < 1 || W < 1) { set_error("%s: bad arguments", who); return TRASE_ERR_INVALID; }
   int nblocks = 0;
@@ -288,7 +300,7 @@ static int loss_forward(const char* who, const float* img, const float* gt, int3
   {
     ProfScope ps("loss_reduce", stream);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, 1.0f / ((float)C * H * W), out2,
-                       lambda_dssim);
+                       (float)lambda_dssim, (float)(1.0 - lambda_dssim));
   }
   TRASE_POST_LAUNCH("loss_reduce", stream, 0);
   return TRASE_OK;
@@ -296,12 +308,12 @@ static int loss_forward(const char* who, const float* img, const float* gt, int3
 
 int trase_loss_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* out2, void* ws,
                                size_t ws_bytes, int32_t device, trase_stream_t stream_) {
-  return loss_forward("trase_loss_l1_ssim_forward", img, gt, C, H, W, out2, -1.0f, ws, ws_bytes, device, stream_);
+  return loss_forward("trase_loss_l1_ssim_forward", img, gt, C, H, W, out2, -1.0, ws, ws_bytes, device, stream_);
 }
 
-int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim, float* out3,
+int trase_loss_photometric_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, double lambda_dssim, float* out3,
                                    void* ws, size_t ws_bytes, int32_t device, trase_stream_t stream_) {
-  if (!(lambda_dssim >= 0.f && lambda_dssim <= 1.f)) { set_error("trase_loss_photometric_forward: lambda_dssim outside [0, 1]"); return TRASE_ERR_INVALID; }
+  if (!(lambda_dssim >= 0.0 && lambda_dssim <= 1.0)) { set_error("trase_loss_photometric_forward: lambda_dssim outside [0, 1]"); return TRASE_ERR_INVALID; }
   return loss_forward("trase_loss_photometric_forward", img, gt, C, H, W, out3, lambda_dssim, ws, ws_bytes, device, stream_);
 }
 
@@ -327,10 +339,10 @@ int trase_loss_l1_ssim_backward(const float* img, const float* gt, int32_t C, in
   return loss_backward("trase_loss_l1_ssim_backward", img, gt, C, H, W, g2, 1, 1.0f, 1.0f, ws, ws_bytes, dL_dimg, device, stream_);
 }
 
-int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+int trase_loss_photometric_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, double lambda_dssim,
                                     const float* g, const void* ws, size_t ws_bytes, float* dL_dimg, int32_t device,
                                     trase_stream_t stream_) {
-  return loss_backward("trase_loss_photometric_backward", img, gt, C, H, W, g, 0, 1.0f - lambda_dssim, -lambda_dssim, ws, ws_bytes, dL_dimg,
+  return loss_backward("trase_loss_photometric_backward", img, gt, C, H, W, g, 0, (float)(1.0 - lambda_dssim), -(float)lambda_dssim, ws, ws_bytes, dL_dimg,
                        device, stream_);
 }
 
