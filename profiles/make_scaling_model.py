@@ -6,7 +6,7 @@ GPU at once) gradient exchange.  Inputs: single-GPU measurements of this round (
 multi-GPU hardware; the point of the table is to say what each axis costs once the exchange is counted and which axis
 BASELINE config 5 should use.
 
-    python profiles/make_scaling_model.py > profiles/r5_scaling_model.json"""
+    python profiles/make_scaling_model.py > profiles/r6_scaling_model.json"""
 import json
 import os
 import sys
@@ -101,6 +101,34 @@ for w in (2, 4, 8):
     rows[str(w)] = rec
 ph["feature_state"] = {"bucket_bytes": n4 * 128, "world": rows}
 out["axis_1_phased_exchange_S4_whole_iterations"] = ph
+# ---- round 6: the visible-set exchange (trase_amd.dp.FlatGradBucket.allreduce_visible) -----------------------------------------------
+# a rank contributes only the rows its view touched (radii > 0) and receives back only the rows ANY rank touched.  Both phases use
+# all W-1 links like the direct exchange; per link a rank sends v x (its share of an owner's shard) in the reduce phase and u x (its own
+# shard) in the gather phase, v / u = measured visible / union fractions of the bench's camera sets (profiles/r6_visibility.json,
+# profiles/measure_visibility.py); + one more collective latency for the all-gather of the bit masks (P / 8 bytes).
+vis_path = os.path.join(HERE, "r6_visibility.json")
+if os.path.exists(vis_path):
+    vis = json.load(open(vis_path))
+    link = XGMI_LINK_GBS_PER_DIR * XGMI_LINK_EFFICIENCY * 1e9
+    vs = {"inputs": vis, "note": "MODEL (unmeasured on multi-GPU hardware): time = (v + u) x shard_bytes / link + 3 collective latencies; dense direct = "
+          "2 x shard_bytes / link + 2 latencies.  The synthetic orbit scenes keep 75 % (S4) / 90 % (S5) of the Gaussians in view: the saving is "
+          "what culling leaves -- a scene seen from inside, or a camera rig that splits the scene, has more to give."}
+    for name, sz in SIZES.items():
+        rows = {}
+        for state, bpg in (("GAUSSIAN state", 236), ("FEATURE state", 128)):
+            per_w = {}
+            for w in (2, 4, 8):
+                v, u = vis[name][str(w)]["visible_fraction_per_rank"], vis[name][str(w)]["union_fraction"]
+                shard = sz["n"] * bpg / w
+                t_vis = (v + u) * shard / link * 1e3 + 3 * COLLECTIVE_LATENCY_MS
+                t_dense = exchange_model_ms(sz["n"] * bpg, w, "direct")
+                per_w[str(w)] = {"bytes_sent_per_rank_dense": int(2 * shard * (w - 1)), "bytes_sent_per_rank_visible": int((v + u) * shard * (w - 1) + sz["n"] / 8 * (w - 1)),
+                                 "exchange_ms_dense_direct": round(t_dense, 3), "exchange_ms_visible": round(t_vis, 3), "ratio": round(t_vis / t_dense, 3),
+                                 "weak_scaling_efficiency_dense": round(sz["view_ms"] / (sz["view_ms"] + t_dense), 3),
+                                 "weak_scaling_efficiency_visible": round(sz["view_ms"] / (sz["view_ms"] + t_vis), 3)}
+            rows[state] = per_w
+        vs[name] = rows
+    out["axis_1_visible_set_exchange"] = vs
 v8 = out["axis_1_view_parallel"]["S5"]["buckets"]["all parameters"]["world"]["8"]["direct"]
 t8 = dict(out["axis_2_tile_rows_of_one_view"]["all parameters"]["world"]["8"]["direct"],
           slowest_strip_ms_measured_one_gpu=out["axis_2_tile_rows_of_one_view"]["all parameters"]["world"]["8"]["slowest_strip_ms_measured_one_gpu"])

@@ -431,3 +431,55 @@ def test_phased_exchange_is_bit_identical_to_the_plain_exchange_over_three_itera
     out = mgr.dict()
     mp.spawn(_phased_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True, 2: True}
+
+
+def _visible_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trase_amd.dp import FlatGradBucket
+    P = 1000 + 37                                                     # not a multiple of the world size or of 8
+    g = torch.Generator().manual_seed(3)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4), (7, 5)]      # six per-Gaussian tensors + one "MLP" parameter
+    base = [torch.randn(s, generator=g) for s in shapes]
+    vis_all = [(torch.rand(P, generator=g) < f) for f in (0.6, 0.35, 0.8)][:world]
+    vis_all[0][:40] = False; vis_all[1][:40] = False                  # rows nobody (of the first two) sees, a fully dead head for world 2
+
+    def grads_of(r):            # rank r's "view": its visible rows non-zero (and rank-specific), every other row exactly zero
+        out_ = []
+        for k, b in enumerate(base):
+            t = b * float(r + 1) + 0.01 * k
+            if b.shape[0] == P:
+                t = t * vis_all[r].reshape(P, *([1] * (b.dim() - 1))).to(t.dtype)
+            out_.append(t)
+        return out_
+    results = {}
+    for mode in ("dense", "visible"):
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        bucket = FlatGradBucket(params, exchange="direct")
+        for v, t in zip(bucket._views, grads_of(rank)):
+            v.copy_(t)
+        if mode == "dense":
+            bucket.allreduce()
+        else:
+            st = bucket.allreduce_visible(vis_all[rank])
+            results["stats"] = st
+        results[mode] = [v.clone() for v in bucket._views]
+    ok = all(torch.equal(a, b) for a, b in zip(results["dense"], results["visible"]))
+    # and both are the mathematical sum
+    want = [sum(gs) for gs in zip(*[grads_of(r) for r in range(world)])]
+    ok = ok and all(torch.allclose(a, w, rtol=1e-6, atol=1e-6) for a, w in zip(results["visible"], want))
+    st = results["stats"]
+    ok = ok and st["rows_sent"] < P and st["bytes_sent"] < st["bytes_dense"]
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_visible_set_exchange_equals_the_dense_rank_ordered_sum_bit_for_bit():
+    """each rank contributes only the rows its view can have touched (radii > 0); the owner-ordered sums must
+    equal the dense "direct" exchange bit for bit, at world 2 and 3, with rows that no rank sees and a ragged last shard."""
+    for world in (2, 3):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_visible_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {r: True for r in range(world)}, (world, dict(out))

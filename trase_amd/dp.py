@@ -356,6 +356,118 @@ class FlatGradBucket:
         self._exchange_padded(buf, shard)
         t.copy_(buf[:n])
 
+    # ---- visible-set exchange: only the rows a rank can have touched --------------------------------------------------------
+    def allreduce_visible(self, visible: torch.Tensor, average: bool = False) -> dict:
+        """SUM over the ranks like ``allreduce()``, but a rank CONTRIBUTES only the rows of the per-Gaussian tensors that its
+        view can have touched: ``visible`` = this rank's ``radii > 0`` (P bools).  A Gaussian the view culled has an exactly-zero
+        gradient row in every per-Gaussian tensor (gaussian_renderer/__init__.py:152; the fused backward writes zeros there), so
+        leaving those rows out changes nothing -- and a view touches 55-70 % of the Gaussians at S4.
+
+          1. the ranks all-gather their visibility bit masks (P / 8 bytes each);
+          2. reduce-scatter by OWNER: Gaussian i belongs to rank i // ceil(P / W); every rank sends each owner the rows
+             {visible here} n {owner's shard} of all per-Gaussian tensors, packed (no index travels: the masks say which rows);
+          3. the owner adds the contributions in RANK ORDER onto zeros (rows nobody saw stay zero) -- the same sums, in the same
+             order, as the "direct" dense exchange forms them: replicas bit-identical by construction;
+          4. all-gather of the reduced rows: an owner sends every peer the rows of its shard that ANY rank saw (the union).
+        Parameters without a leading Gaussian dimension (the deformation MLP) take the ordinary dense exchange.
+        Point-to-point transfers to / from every peer at once (one ncclGroup per phase on RCCL; gloo in the CPU tests).
+        Returns {"rows_sent", "rows_received_reduce", "rows_received_gather", "bytes_sent", "bytes_dense"} of this rank.
+        UNMEASURED on multi-GPU hardware; tests/test_dp_gloo.py proves the sum equals the dense rank-ordered one bit for bit."""
+        import torch.distributed as dist
+        self._finish_phased()
+        if getattr(self, "_pending", None):
+            raise RuntimeError("FlatGradBucket.allreduce_visible: ranges of an overlapped exchange are pending; use allreduce()")
+        self.gather_grads()
+        P = int(visible.numel())
+        per_g = [(p, v) for p, v in zip(self.params, self._views) if p.dim() >= 1 and p.shape[0] == P]
+        rest = [v for p, v in zip(self.params, self._views) if not (p.dim() >= 1 and p.shape[0] == P)]
+        widths = [v.numel() // P for _, v in per_g]
+        D = sum(widths)
+        stats = {"rows_sent": 0, "rows_received_reduce": 0, "rows_received_gather": 0, "bytes_sent": 0,
+                 "bytes_dense": 2 * self.bytes_per_step}
+        if not self._collectives_on():
+            return stats
+        world, rank = dist.get_world_size(), dist.get_rank()
+        dev = self.flat.device
+        vis = visible.to(device=dev, dtype=torch.bool).reshape(P)
+        # 1. everybody's mask (bit-packed)
+        pad = (-P) % 8
+        bits = torch.nn.functional.pad(vis, (0, pad)).reshape(-1, 8).to(torch.uint8)
+        packed = (bits * (1 << torch.arange(8, device=dev, dtype=torch.uint8))).sum(dim=1, dtype=torch.uint8)
+        allp = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(allp, packed)
+        unpack = lambda q: ((q.unsqueeze(1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1)[:P].to(torch.bool)
+        masks = [unpack(q) for q in allp]
+        shard = (P + world - 1) // world
+        lo = lambda o: min(o * shard, P)
+        hi = lambda o: min((o + 1) * shard, P)
+        rows2d = [v.reshape(P, w) for (_, v), w in zip(per_g, widths)]
+
+        def pack(idx):            # rows `idx` of every per-Gaussian tensor, tensor-major
+            return torch.cat([r.index_select(0, idx).reshape(-1) for r in rows2d]) if idx.numel() else self.flat.new_empty(0)
+        # 2. my visible rows to their owners; the peers' visible rows of MY shard to me
+        send_idx = [torch.nonzero(masks[rank][lo(o):hi(o)]).reshape(-1) + lo(o) for o in range(world)]
+        recv_idx = [torch.nonzero(masks[r][lo(rank):hi(rank)]).reshape(-1) + lo(rank) for r in range(world)]
+        send = [pack(send_idx[o]) if o != rank else None for o in range(world)]
+        recv = [self.flat.new_empty(recv_idx[r].numel() * D) if r != rank else None for r in range(world)]
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            if send[peer].numel():
+                ops.append(dist.P2POp(dist.isend, send[peer], peer))
+            if recv[peer].numel():
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        # 3. the owner's sums, contributions added in rank order onto zeros
+        n_mine = hi(rank) - lo(rank)
+        acc = [self.flat.new_zeros(n_mine, w) for w in widths]
+        for r in range(world):
+            idx = recv_idx[r] - lo(rank)
+            if idx.numel() == 0:
+                continue
+            off = 0
+            for a, r2, w in zip(acc, rows2d, widths):
+                rows = r2.index_select(0, recv_idx[r]) if r == rank else recv[r][off:off + idx.numel() * w].view(idx.numel(), w)
+                a.index_add_(0, idx, rows)          # (idx holds every row once: nothing is accumulated in an unspecified order)
+                off += idx.numel() * w
+        # 4. the union rows of every shard to everybody
+        union = torch.stack(masks).any(dim=0)
+        uni_idx = [torch.nonzero(union[lo(o):hi(o)]).reshape(-1) + lo(o) for o in range(world)]
+        mine_u = uni_idx[rank] - lo(rank)
+        out_chunk = torch.cat([a.index_select(0, mine_u).reshape(-1) for a in acc]) if mine_u.numel() else self.flat.new_empty(0)
+        got = [self.flat.new_empty(uni_idx[o].numel() * D) if o != rank else out_chunk for o in range(world)]
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            if out_chunk.numel():
+                ops.append(dist.P2POp(dist.isend, out_chunk, peer))
+            if got[peer].numel():
+                ops.append(dist.P2POp(dist.irecv, got[peer], peer))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for o in range(world):
+            n = uni_idx[o].numel()
+            if n == 0:
+                continue
+            off = 0
+            for r2, w in zip(rows2d, widths):
+                r2.index_copy_(0, uni_idx[o], got[o][off:off + n * w].view(n, w))
+                off += n * w
+        # rows outside every union: zero on every rank already (nobody saw them)
+        for v in rest:
+            self._exchange_run(v.reshape(-1))
+        if average:
+            self.flat.div_(world)
+        es = self.flat.element_size()
+        stats["rows_sent"] = int(sum(send_idx[o].numel() for o in range(world) if o != rank))
+        stats["rows_received_reduce"] = int(sum(recv_idx[r].numel() for r in range(world) if r != rank))
+        stats["rows_received_gather"] = int(sum(uni_idx[o].numel() for o in range(world) if o != rank))
+        stats["bytes_sent"] = (stats["rows_sent"] + (world - 1) * int(mine_u.numel())) * D * es + (world - 1) * int(packed.numel())
+        return stats
+
     # ---- phased exchange: hidden behind the NEXT iteration --------------------------------------------------------------
     def allreduce_phased(self, first: Iterable[torch.Tensor], sh_rest=None, average: bool = False) -> "PhasedExchange":
         """The exchange in two phases, for a loop that hides most of it behind the next iteration's first kernels.
