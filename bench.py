@@ -337,13 +337,13 @@ def main():
         if args.forward_only:          # rendering one frame (inference / GUI / evaluation): no backward, no gradient exchange
             with torch.no_grad(), (R.tile_rows(b, e) if (b, e) != (0, 0) else _nullctx()):
                 out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
-                if world > 1:
+                if world > 1 and (b, e) != (0, 0):       # (the whole-view sizing pass has nothing to gather)
                     dp.allgather_strips(out["render"], strip["part"], H)
             return out["radii"]
         with R.tile_rows(b, e) if (b, e) != (0, 0) else _nullctx():
             out = render(cams_dev[i % n_views], pc, pipe, bg, 0.0, 0.0, 0.0)
             img, radii, feats = out["render"], out["radii"], out["render_gaussian_features"]
-            if world > 1:
+            if world > 1 and (b, e) != (0, 0):
                 img = dp.allgather_strips(img, strip["part"], H)
             torch.autograd.backward([img, feats], [g_img, g_feat])
         if bucket is not None:

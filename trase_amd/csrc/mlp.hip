@@ -1268,6 +1268,12 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
     }
   }
   uint32_t gw[2][4];                                 // SAVE: this lane's ReLU gates of the layer, [row group][word]
+#ifdef RC_L2
+  int l2_off[4];                                     // element offset of this lane's 8-byte piece of column group q inside a 16-row image tile
+  __bf16* const actsT_l2 = actsT;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) l2_off[q] = (m >> 4) * 4096 + h * 64 + (((m & 15) + 4 * q) & 15) * 4;
+#endif
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   auto to_acc_file = [](bf16x8 v) -> bf16x8 {
     typedef int i32x4v __attribute__((ext_vector_type(4)));
@@ -1286,12 +1292,31 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   // layer finishes inside the first block of the next layer (its fragments are K-steps 14 / 15 there: needed last).
   f32x16 acc[2][2];
   // piece p = 2 g + s2 of the epilogue of the block in acc[slot]: fragment (g, K-step 2 nb + s2) of `out`
-  auto epi_piece = [&](auto out_acc_c, bf16x8 (&out)[2][16], int slot, int nb, int p) {
+  auto epi_piece = [&](auto out_acc_c, bf16x8 (&out)[2][16], int slot, int nb, int p, int l) {
     constexpr bool OUT_ACC = decltype(out_acc_c)::value;
     const int g = p >> 1, s2 = p & 1;
     const f32x16& a = acc[slot][g];
     const s16x4 lo = relu_bf16x4(a[8 * s2], a[8 * s2 + 1], a[8 * s2 + 2], a[8 * s2 + 3]);
     const s16x4 hi = relu_bf16x4(a[8 * s2 + 4], a[8 * s2 + 5], a[8 * s2 + 6], a[8 * s2 + 7]);
+#ifdef RC_L2
+    if constexpr (SAVE) {
+      // TIMING EXPERIMENT (profiles/r6_ab_experiments.txt): image layout [row/16][col/4][rotated row%16][col%4] written straight from the
+      // registers (two 8-byte stores per piece), gate bits by four packed minima + shifts
+      typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+      const u2v_ ul = __builtin_bit_cast(u2v_, lo), uh = __builtin_bit_cast(u2v_, hi);
+      unsigned t0, t1, t2, t3;
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(ul.x), "s"(0x00010001u));
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(ul.y), "s"(0x00010001u));
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(uh.x), "s"(0x00010001u));
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(uh.y), "s"(0x00010001u));
+      const uint32_t w8 = t0 | (t1 << 1) | (t2 << 2) | (t3 << 3);
+      const int pp = 2 * (nb & 1) + s2;
+      if (pp == 0) gw[g][nb >> 1] = w8; else gw[g][nb >> 1] |= w8 << (4 * pp);
+      __bf16* const img = actsT_l2 + (size_t)l * tiles * (MW * 32) + (size_t)((u_row0 >> 4) + 2 * g) * 4096 + (size_t)(8 * nb + 4 * s2) * 64;
+      __builtin_nontemporal_store(ul, reinterpret_cast<u2v_*>(img + l2_off[2 * s2]));
+      __builtin_nontemporal_store(uh, reinterpret_cast<u2v_*>(img + 128 + l2_off[2 * s2 + 1]));
+    }
+#else
     if constexpr (SAVE) {
       // registers 4 q + j (q = 2 s2, 2 s2 + 1) <-> columns 32 nb + 8 q + 4 h + j: gate bits as in mlp_fwd_blk_body (word nb / 2, bit
       // (nb & 1) 16 + 4 q + j of the (row, h) record), and the block's [row][column] image for the transposing reads
@@ -1301,6 +1326,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
       scr_write4(32 * g + m, 16 * s2 + 4 * h, lo);
       scr_write4(32 * g + m, 16 * s2 + 8 + 4 * h, hi);
     }
+#endif
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if constexpr (OUT_ACC) out[g][2 * nb + s2] = to_acc_file(__builtin_bit_cast(bf16x8, v));
@@ -1310,7 +1336,9 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   // after the last block of a layer also the layer's gate words
   auto epi_image = [&](int l, int nb, int w) {
     if constexpr (SAVE) {
+#ifndef RC_L2
       image_store(actsT + (size_t)l * tiles * (MW * 32), MW, 32 * nb, w);
+#endif
       if (nb == 7 && w == 3) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -1340,7 +1368,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
       const int slot = nb & 1;
       auto prev = [&](int step) {                 // the block before this one
         if (nb == 0) pending(step);
-        else if (step < 4) epi_piece(out_acc_c, out, slot ^ 1, nb - 1, step);
+        else if (step < 4) epi_piece(out_acc_c, out, slot ^ 1, nb - 1, step, L);
         else epi_image(L, nb - 1, step - 4);
       };
 #pragma unroll
@@ -1366,7 +1394,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   constexpr std::false_type ARCH{};
   // the last block (7, in acc[1]) of layer l, whose output bank is `out`
   auto last_of = [&](auto out_acc_c, bf16x8 (&out)[2][16], int l) {
-    return [&, l, out_acc_c](int step) { if (step < 4) epi_piece(out_acc_c, out, 1, 7, step); else epi_image(l, 7, step - 4); };
+    return [&, l, out_acc_c](int step) { if (step < 4) epi_piece(out_acc_c, out, 1, 7, step, l); else epi_image(l, 7, step - 4); };
   };
   // bankA: accumulation file, bankB: architectural file
   layer(std::integral_constant<int, 0>{}, ACC, bankB, bankA, none);
