@@ -200,7 +200,11 @@ __device__ __forceinline__ void patch_store(s16x4p v, const PatchLane& pl, __bf1
   }
   typedef unsigned u2v __attribute__((ext_vector_type(2)));
   const u2v o2 = __builtin_bit_cast(u2v, v);
+#ifdef TRASE_MLP_PLAIN_STORES
+  *reinterpret_cast<u2v*>(img_patch + pl.img_elem) = o2;
+#else
   __builtin_nontemporal_store(o2, reinterpret_cast<u2v*>(img_patch + pl.img_elem));
+#endif
 }
 
 // ---- inference forward, block-GEMM organisation ---------------------------------------------------------------------
