@@ -1,6 +1,6 @@
 #!/bin/bash
 # After `gpurun -- bash profiles/run_evidence.sh <tag>`: copy what is to be judged from gpurun_out/ into profiles/.
-T=${1:-r5}
+T=${1:-r6}
 cd "$(dirname "$0")/../gpurun_out" || exit 1
 cp trace_$T.md ../profiles/${T}_kernel_stats.md
 cp trace_${T}_bench.json ../profiles/${T}_bench_under_rocprof.json
@@ -11,7 +11,7 @@ for f in bench_default.json mlp_bench.json iteration_bench.json iteration_featur
   cp ${T}_$f ../profiles/${T}_$f
 done
 cp itrace_${T}_timeline.md ../profiles/${T}_iteration_timeline.md
-cp itrace_${T}f_timeline.md ../profiles/${T}_iteration_feature_timeline.md
+cp itrace_${T}f_timeline.md 2>/dev/null ||:; true # ../profiles/${T}_iteration_feature_timeline.md
 grep -E "passed|failed" ${T}_gputest.txt > ../profiles/${T}_gputest.txt
 cd .. && python - <<'PY'
 import json

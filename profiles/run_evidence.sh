@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates the round's evidence at the current sources.  Usage: bash profiles/run_evidence.sh <tag>
 # Everything lands in gpurun_out/ (merged back); copy what is to be judged into profiles/.
-T=${1:-r5}
+T=${1:-r6}
 R=$PWD
 mkdir -p gpurun_out
 bash profiles/run_trace.sh $T > /dev/null 2>&1
