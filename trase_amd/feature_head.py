@@ -81,6 +81,7 @@ def get_sample_pixel_and_mask(sam_masks, num_sampled_pixels, num_sampled_masks, 
 
 
 _COUNT_CHECKS: list = []      # (event, pinned int32[2] copy of the device count, capacity) of sync-free compactions not yet verified
+_COUNT_FREE: list = []        # verified (pinned buffer, event) pairs, reused (no pinned allocation / event creation per iteration)
 
 
 def _poll_count_checks(block: bool = False):
@@ -91,6 +92,8 @@ def _poll_count_checks(block: bool = False):
         if block:
             ev.synchronize()
         if block or ev.query():
+            if len(_COUNT_FREE) < 8:
+                _COUNT_FREE.append((pin, ev))
             if int(pin[1]) > cap:
                 _COUNT_CHECKS[:] = []
                 raise RuntimeError(f"trase_amd.feature_head: a sync-free contrastive_head call sampled {int(pin[1])} pixels but its index "
@@ -212,9 +215,8 @@ def contrastive_head(rendered_features, sam_masks, sampled_pixel, sampled_mask, 
         _lib.check(lib.trase_compact_pixels(_lib.ptr(flags), H * W, _lib.ptr(pix), cap, _lib.ptr(s_dev), _lib.ptr(cws), cws.numel(),
                                             _dev_index(dev), _stream(dev)), "trase_compact_pixels")
         if len(_COUNT_CHECKS) < 64 and not torch.cuda.is_current_stream_capturing():   # the true count is looked at later, off the critical path
-            pin = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pin, ev = _COUNT_FREE.pop() if _COUNT_FREE else (torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
             pin.copy_(s_dev, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             _COUNT_CHECKS.append((ev, pin, cap))
     else:
