@@ -1186,8 +1186,13 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   auto advance = [&](int f) {
     if (f % RC_G == 0) {                       // start of group f/16: park group +1 (fetched during the previous group), fetch group +2
       const int grp = f / RC_G;
+#ifndef RC_DBG_NOSTAGE
       if (grp + 1 < NGRP) stage_park(grp + 1);
       if (grp + 2 < NGRP) stage_load(grp + 2);
+#else
+      if (grp == 0) { stage_park(1); stage_load(2); }
+      if (grp == 1) stage_park(2);
+#endif
     }
     if (f % RC_G == RC_G / 2) lds_barrier();   // everybody has parked group +1 (and finished reading group -1): +1 is readable
     if (f + LA < RC_FWD_FRAGS) wf[(f + LA) % (LA + 1)] = frag_read(f + LA);
@@ -1317,8 +1322,15 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
       const int pp = 2 * (nb & 1) + s2;
       if (pp == 0) gw[g][nb >> 1] = w8; else gw[g][nb >> 1] |= w8 << (4 * pp);
       __bf16* const img = actsT_l2 + (size_t)l * tiles * (MW * 32) + (size_t)((u_row0 >> 4) + 2 * g) * 4096 + (size_t)(8 * nb + 4 * s2) * 64;
+#if defined(RC_DBG_L2_NOSTORE)
+      asm volatile("" :: "v"(ul), "v"(uh), "v"(img));
+#elif defined(RC_DBG_L2_PLAIN)
+      *reinterpret_cast<u2v_*>(img + l2_off[2 * s2]) = ul;
+      *reinterpret_cast<u2v_*>(img + 128 + l2_off[2 * s2 + 1]) = uh;
+#else
       __builtin_nontemporal_store(ul, reinterpret_cast<u2v_*>(img + l2_off[2 * s2]));
       __builtin_nontemporal_store(uh, reinterpret_cast<u2v_*>(img + 128 + l2_off[2 * s2 + 1]));
+#endif
     }
 #else
     if constexpr (SAVE) {
