@@ -1126,7 +1126,9 @@ __device__ __forceinline__ int rc_swz(int row) { return ((row >> 1) & 1) | (((ro
 // SAVE: training forward -- additionally writes, per layer, the transposed image of the post-ReLU activations, the ReLU gates as
 // bits and the encoding image: the SAME saved state as mlp_fwd_blk_body (the backward does not care which forward produced it).
 // FULL: every row of the workgroup's 256 exists (image stores unconditional).
-template <bool SAVE, bool FULL>
+// G: 32-row groups per wave -- 2: four waves per workgroup, one per SIMD (a weight fragment read feeds two MFMAs); 1: eight waves, two per
+// SIMD (each wave half the registers; the second wave's VALU / LDS / VMEM instructions issue under the first one's MFMAs)
+template <bool SAVE, bool FULL, int G = 2>
 __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring, float* __restrict__ s_bias, const RcNet& net,
                                                 const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
                                                 float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
@@ -1136,12 +1138,13 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
                                                 __bf16* __restrict__ peT = nullptr) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, h = lane >> 5;
-  const int row0 = blockIdx.x * RC_ROWS + wave * 64;
+  constexpr int WROWS = 32 * G, NWV = RC_ROWS / WROWS, FPW = RC_G / NWV, NP = 2 * G;   // rows per wave, waves, staged fragments per wave and group, epilogue pieces
+  const int row0 = blockIdx.x * RC_ROWS + wave * WROWS;
   // ---- biases into LDS (8.1 KB), inputs into registers --------------------------------------------------------------
-  for (int i = threadIdx.x; i < MD * MW + HEADP; i += 256) s_bias[i] = net.bias[i];
-  float px[2][4];
+  for (int i = threadIdx.x; i < MD * MW + HEADP; i += NWV * 64) s_bias[i] = net.bias[i];
+  float px[G][4];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < G; ++g) {
     int gm = min(row0 + 32 * g + m, N - 1);
     if (ro) gm = ro[gm];
     px[g][0] = x[3 * gm]; px[g][1] = x[3 * gm + 1]; px[g][2] = x[3 * gm + 2]; px[g][3] = t[(size_t)gm * t_stride];
@@ -1155,19 +1158,19 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   }
   // ---- weight stream -----------------------------------------------------------------------------------------------
   // group G holds fragments 16 G .. 16 G + 15; wave w stages fragments 4 w .. 4 w + 3 of a group (lane: its 16 bytes of each)
-  const __bf16* gsrc = net.wstream + (size_t)(wave * 4) * 512 + (size_t)lane * 8;
-  unsigned char* const wr = ring + (wave * 4) * 1024 + lane * 16;      // where this lane parks its pieces inside a slot
+  const __bf16* gsrc = net.wstream + (size_t)(wave * FPW) * 512 + (size_t)lane * 8;
+  unsigned char* const wr = ring + (wave * FPW) * 1024 + lane * 16;      // where this lane parks its pieces inside a slot
   const unsigned char* const rd = ring + lane * 16;                      // where it reads a fragment from
   uint4 st0, st1, st2, st3;                    // (named scalars: as an array the staging registers were promoted to LDS)
   auto stage_load = [&](int grp) {
     const __bf16* p = gsrc + (size_t)grp * RC_G * 512;
     st0 = *reinterpret_cast<const uint4*>(p); st1 = *reinterpret_cast<const uint4*>(p + 512);
-    st2 = *reinterpret_cast<const uint4*>(p + 1024); st3 = *reinterpret_cast<const uint4*>(p + 1536);
+    if constexpr (FPW == 4) { st2 = *reinterpret_cast<const uint4*>(p + 1024); st3 = *reinterpret_cast<const uint4*>(p + 1536); }
   };
   auto stage_park = [&](int grp) {
     unsigned char* q = wr + (grp % RC_SLOTS) * (RC_G * 1024);
     *reinterpret_cast<uint4*>(q) = st0; *reinterpret_cast<uint4*>(q + 1024) = st1;
-    *reinterpret_cast<uint4*>(q + 2048) = st2; *reinterpret_cast<uint4*>(q + 3072) = st3;
+    if constexpr (FPW == 4) { *reinterpret_cast<uint4*>(q + 2048) = st2; *reinterpret_cast<uint4*>(q + 3072) = st3; }
   };
   auto frag_read = [&](int f) -> bf16x8 {
     return *reinterpret_cast<const bf16x8*>(rd + ((f / RC_G) % RC_SLOTS) * (RC_G * 1024) + (f % RC_G) * 1024);
@@ -1202,13 +1205,13 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   // in the ARCHITECTURAL registers and one in the ACCUMULATION registers (MFMA reads its B operand from either file; the packed
   // conversion writes architectural registers only, so the odd layers' outputs are moved over by v_accvgpr_write) -- with both
   // banks in one file the allocator has no room left for the fragment look-ahead
-  bf16x8 bankA[2][16], bankB[2][16];
+  bf16x8 bankA[G][16], bankB[G][16];
   // the encoding's fragments (layers 0 and 5): generated once, parked in a wave-private 12-KB piece of LDS (lane-linear, read back
   // like a weight fragment) -- 48 registers that the hidden layers would otherwise carry for nothing
-  unsigned char* const pe_lds = pe_store + wave * (2 * RC_PE_KS * 1024) + lane * 16;
-  bf16x8 pe[2][RC_PE_KS];
+  unsigned char* const pe_lds = pe_store + wave * (G * RC_PE_KS * 1024) + lane * 16;
+  bf16x8 pe[G][RC_PE_KS];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < G; ++g) {
     pe[g][0] = blk_pe_fragment<0>(h, px[g], blender, tb); pe[g][1] = blk_pe_fragment<1>(h, px[g], blender, tb);
     pe[g][2] = blk_pe_fragment<2>(h, px[g], blender, tb); pe[g][3] = blk_pe_fragment<3>(h, px[g], blender, tb);
     pe[g][4] = blk_pe_fragment<4>(h, px[g], blender, tb); pe[g][5] = blk_pe_fragment<5>(h, px[g], blender, tb);
@@ -1217,7 +1220,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   }
   auto pe_frag = [&](int g, int k) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(pe_lds + (g * RC_PE_KS + k) * 1024); };
   // ---- SAVE: the wave's transposition scratch (64 rows x 64 bytes, slots permuted by rc_swz) ----------------------------
-  unsigned char* const scr = SAVE ? scratch + wave * 4096 : nullptr;
+  unsigned char* const scr = SAVE ? scratch + wave * (WROWS * 64) : nullptr;
   const int tiles = (N + 31) >> 5;
   const int u_row0 = __builtin_amdgcn_readfirstlane(row0);
   PatchLane pl;                                     // (only img_elem / row4 are used: patch_store)
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1273,10 +1276,10 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
           scr_write4(32 * g + m, 16 * k2 + 8 * h + 4, b4);
         }
 #pragma unroll
-      for (int which = 0; which < 4; ++which) image_store(peT, EMBP, 32 * pass, which);
+      for (int which = 0; which < NP; ++which) image_store(peT, EMBP, 32 * pass, which);
     }
   }
-  uint32_t gw[2][4];                                 // SAVE: this lane's ReLU gates of the layer, [row group][word]
+  uint32_t gw[G][4];                                 // SAVE: this lane's ReLU gates of the layer, [row group][word]
 #ifdef RC_L2
   int l2_off[4];                                     // element offset of this lane's 8-byte piece of column group q inside a 16-row image tile
   __bf16* const actsT_l2 = actsT;
@@ -1299,9 +1302,9 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   // per row group) is issued in FOUR pieces behind the first K-steps of block b + 1 -- one wave per SIMD hides up to five
   // single-issue instructions per MFMA (MI355X_MICROARCH.md), and a piece is ~10-20 of them behind two MFMAs.  The last block of a
   // layer finishes inside the first block of the next layer (its fragments are K-steps 14 / 15 there: needed last).
-  f32x16 acc[2][2];
+  f32x16 acc[2][G];
   // piece p = 2 g + s2 of the epilogue of the block in acc[slot]: fragment (g, K-step 2 nb + s2) of `out`
-  auto epi_piece = [&](auto out_acc_c, bf16x8 (&out)[2][16], int slot, int nb, int p, int l) {
+  auto epi_piece = [&](auto out_acc_c, bf16x8 (&out)[G][16], int slot, int nb, int p, int l) {
     constexpr bool OUT_ACC = decltype(out_acc_c)::value;
     const int g = p >> 1, s2 = p & 1;
     const f32x16& a = acc[slot][g];
@@ -1355,9 +1358,9 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
 #ifndef RC_L2
       image_store(actsT + (size_t)l * tiles * (MW * 32), MW, 32 * nb, w);
 #endif
-      if (nb == 7 && w == 3) {
+      if (nb == 7 && w == NP - 1) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
           const int grow = row0 + 32 * g + m;
           if (FULL || grow < N)
             *reinterpret_cast<uint4*>(gates + (((size_t)l * N + grow) * 2 + h) * 4) = make_uint4(gw[g][0], gw[g][1], gw[g][2], gw[g][3]);
@@ -1368,7 +1371,7 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   // one layer: IN -> OUT.  PE_KS encoding K-steps first (layers 0 and 5), then HID hidden K-steps out of `in`.
   // `pending(step)`: the previous layer's last block (its output bank is THIS layer's input: K-steps 14, 15) -- steps 0..3 its
   // epilogue pieces, 4..7 (SAVE) its image patches
-  auto layer = [&](auto l_c, auto out_acc_c, bf16x8 (&in)[2][16], bf16x8 (&out)[2][16], auto&& pending) {
+  auto layer = [&](auto l_c, auto out_acc_c, bf16x8 (&in)[G][16], bf16x8 (&out)[G][16], auto&& pending) {
     constexpr int L = decltype(l_c)::value;
     constexpr int PE_KS = (L == 0 || L == SKIP) ? RC_PE_KS : 0, HID = L == 0 ? 0 : 16, KS = PE_KS + HID;
     constexpr int F0 = rc_layer_frag0(L);
@@ -1384,8 +1387,8 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
       const int slot = nb & 1;
       auto prev = [&](int step) {                 // the block before this one
         if (nb == 0) pending(step);
-        else if (step < 4) epi_piece(out_acc_c, out, slot ^ 1, nb - 1, step, L);
-        else epi_image(L, nb - 1, step - 4);
+        else if (step < NP) epi_piece(out_acc_c, out, slot ^ 1, nb - 1, step, L);
+        else epi_image(L, nb - 1, step - NP);
       };
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -1393,15 +1396,18 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
         advance(f);
         const bf16x8 w = wf[f % (LA + 1)];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
           const bf16x8 a = ks < PE_KS ? pe_frag(g, ks < PE_KS ? ks : 0) : in[g][ks >= PE_KS ? ks - PE_KS : 0];
           acc[slot][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, ks == 0 ? binit : acc[slot][g], 0, 0, 0);
         }
         // the previous block's epilogue: one piece per K-step 1..4; SAVE: its image patches behind K-steps 6..9 (a short
         // block -- layer 0: six K-steps -- takes all four behind its last one)
-        if (ks >= 1 && ks <= 4) prev(ks - 1);
-        if (SAVE && KS >= 10 && ks >= 6 && ks <= 9) prev(ks - 2);
-        if (SAVE && KS < 10 && ks == KS - 1) { prev(4); prev(5); prev(6); prev(7); }
+        if (ks >= 1 && ks <= NP) prev(ks - 1);
+        if (SAVE && KS >= 10 && ks >= 6 && ks < 6 + NP) prev(NP + ks - 6);
+        if (SAVE && KS < 10 && ks == KS - 1) {
+          prev(NP); prev(NP + 1);
+          if constexpr (G == 2) { prev(NP + 2); prev(NP + 3); }
+        }
       }
     }
   };
@@ -1409,8 +1415,8 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   constexpr std::true_type ACC{};
   constexpr std::false_type ARCH{};
   // the last block (7, in acc[1]) of layer l, whose output bank is `out`
-  auto last_of = [&](auto out_acc_c, bf16x8 (&out)[2][16], int l) {
-    return [&, l, out_acc_c](int step) { if (step < 4) epi_piece(out_acc_c, out, 1, 7, step, l); else epi_image(l, 7, step - 4); };
+  auto last_of = [&](auto out_acc_c, bf16x8 (&out)[G][16], int l) {
+    return [&, l, out_acc_c](int step) { if (step < NP) epi_piece(out_acc_c, out, 1, 7, step, l); else epi_image(l, 7, step - NP); };
   };
   // bankA: accumulation file, bankB: architectural file
   layer(std::integral_constant<int, 0>{}, ACC, bankB, bankA, none);
@@ -1424,10 +1430,10 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
   {
     auto fin = last_of(ARCH, bankB, 7);             // (the last layer's last block: nothing left to hide it behind)
 #pragma unroll
-    for (int st_ = 0; st_ < (SAVE ? 8 : 4); ++st_) fin(st_);
+    for (int st_ = 0; st_ < (SAVE ? 2 * NP : NP); ++st_) fin(st_);
   }
   // heads: one 32-wide output block (10 used) out of bankB
-  f32x16 hacc[2];
+  f32x16 hacc[G];
   {
     f32x16 binit;
 #pragma unroll
@@ -1441,12 +1447,12 @@ __device__ __forceinline__ void mlp_fwd_rc_body(unsigned char* __restrict__ ring
       advance(F0 + ks);
       const bf16x8 w = wf[(F0 + ks) % (LA + 1)];
 #pragma unroll
-      for (int g = 0; g < 2; ++g) hacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, bankB[g][ks], ks == 0 ? binit : hacc[g], 0, 0, 0);
+      for (int g = 0; g < G; ++g) hacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, bankB[g][ks], ks == 0 ? binit : hacc[g], 0, 0, 0);
     }
   }
   // the ten outputs of a row sit in two lanes (h = 0: outputs 0-3, 8, 9; h = 1: 4-7): see mlp_fwd_blk_body
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < G; ++g) {
     int grow = row0 + 32 * g + m;
     const bool ok = grow < N;
     if (ok && ro) grow = ro[grow];
@@ -1492,6 +1498,31 @@ void mlp_fwd_train_rc_kernel(RcNet net, const float* __restrict__ x, const float
     mlp_fwd_rc_body<true, false>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, ro, pe_store, scratch, actsT, reinterpret_cast<uint32_t*>(gates), peT);
 }
 
+
+// G = 1: eight waves of 32 rows, two per SIMD
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_rc1_kernel(RcNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                        float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[RC_SLOTS * RC_G * 1024];
+  __shared__ __attribute__((aligned(16))) float s_bias[MD * MW + HEADP];
+  __shared__ __attribute__((aligned(1024))) unsigned char pe_store[8 * RC_PE_KS * 1024];
+  mlp_fwd_rc_body<false, false, 1>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, nullptr, pe_store);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mlp_fwd_train_rc1_kernel(RcNet net, const float* __restrict__ x, const float* __restrict__ t, int t_stride, int N,
+                              float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale,
+                              __bf16* __restrict__ actsT, uint4* __restrict__ gates, const int* __restrict__ ro, __bf16* __restrict__ peT) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[RC_SLOTS * RC_G * 1024];
+  __shared__ __attribute__((aligned(16))) float s_bias[MD * MW + HEADP];
+  __shared__ __attribute__((aligned(64))) unsigned char scratch[8 * 2048];                   // per wave: 32 rows x 64 bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char pe_store[8 * RC_PE_KS * 1024];
+  if ((int)(blockIdx.x + 1) * RC_ROWS <= N)
+    mlp_fwd_rc_body<true, true, 1>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, ro, pe_store, scratch, actsT, reinterpret_cast<uint32_t*>(gates), peT);
+  else
+    mlp_fwd_rc_body<true, false, 1>(ring, s_bias, net, x, t, t_stride, N, d_xyz, d_rot, d_scale, ro, pe_store, scratch, actsT, reinterpret_cast<uint32_t*>(gates), peT);
+}
+
 static size_t mlp_rc_ws_bytes() {
   return align_up(sizeof(__bf16) * (size_t)RC_FWD_FRAGS * 512) + align_up(sizeof(float) * (MD * MW + HEADP));
 }
@@ -1511,6 +1542,9 @@ static size_t mlp_ws_bytes() { return mlp_ws_bytes_blk() + mlp_rc_ws_bytes(); }
 // state's extra issue slots (scratch stores, gate bits, transposing reads, image stores: ~250 single-issue instructions per 32
 // MFMAs where ~160 hide) it measures 0.50 ms against the block kernel's 0.44 (profiles/r6_ab_experiments.txt)
 static bool mlp_use_rc() { static const bool on = [] { const char* e = getenv("TRASE_MLP_RC"); return !e || atoi(e) != 0; }(); return on; }
+// TRASE_MLP_RC_G: 32-row groups per wave of the RC kernels (2 = four waves, one per SIMD: the default; 1 = eight waves, two per SIMD:
+// inference -1.6 %, training forward 0.51 -> 0.43 ms = the block kernel's time -- profiles/r6_ab_experiments.txt)
+static int mlp_rc_groups() { static const int g = [] { const char* e = getenv("TRASE_MLP_RC_G"); return e ? atoi(e) : 2; }(); return g; }
 static bool mlp_use_rc_train() { static const bool on = [] { const char* e = getenv("TRASE_MLP_RC_TRAIN"); return e && atoi(e) != 0; }(); return on; }
 
 // ---- buffer plans of the training pair ---------------------------------------------------------------------
@@ -1659,7 +1693,10 @@ int trase_mlp_forward(const TraseMlpWeights* w, const float* x, const float* t, 
     if (w->is_blender) rnet.temb = t;
     {
       ProfScope ps("mlp_fwd", stream);
-      hipLaunchKernelGGL(mlp_fwd_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
+      if (mlp_rc_groups() == 1)
+        hipLaunchKernelGGL(mlp_fwd_rc1_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(512), 0, stream, rnet, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
+      else
+        hipLaunchKernelGGL(mlp_fwd_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N, d_xyz, d_rotation, d_scaling);
     }
     TRASE_POST_LAUNCH("mlp_fwd", stream, 0);
     return TRASE_OK;
@@ -1704,8 +1741,12 @@ int trase_mlp_forward_train_rows(const TraseMlpWeights* w, const float* x, const
     if (w->is_blender) rnet.temb = t;
     {
       ProfScope ps("mlp_fwd_train", stream);
-      hipLaunchKernelGGL(mlp_fwd_train_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N,
-                         d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order, sv.peT);
+      if (mlp_rc_groups() == 1)
+        hipLaunchKernelGGL(mlp_fwd_train_rc1_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(512), 0, stream, rnet, x, t, t_stride, N,
+                           d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order, sv.peT);
+      else
+        hipLaunchKernelGGL(mlp_fwd_train_rc_kernel, dim3((N + RC_ROWS - 1) / RC_ROWS), dim3(256), 0, stream, rnet, x, t, t_stride, N,
+                           d_xyz, d_rotation, d_scaling, sv.actsT, sv.gates, (const int*)row_order, sv.peT);
     }
     TRASE_POST_LAUNCH("mlp_fwd_train", stream, 0);
     return TRASE_OK;
