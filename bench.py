@@ -462,7 +462,7 @@ def main():
         except Exception:
             pass
     if not args.graph:           # (a replayed launch graph has no per-kernel events: --graph takes the kernel times of the untimed pass below)
-        R.profile_enable(2)      # HIP events around the compositing kernels only, on the launch stream
+        R.profile_enable(int(os.environ.get("TRASE_BENCH_WINDOW_PROF", "2")))      # HIP events around the compositing kernels only, on the launch stream
     import gc
     gc.disable()                 # no collector pause inside the 20-step window (NOT gc.collect(): tens of ms of idle GPU in front
                                  # of the timed steps cost 7-9 %, see above)
@@ -498,8 +498,10 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     views_per_s = (1 if tiles_mode else world) * args.steps / elapsed     # tiles mode: the whole job renders ONE view per step
-    dev_steps = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    dev_raw = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
+    dev_steps = sorted(dev_raw)
     step_ms = {"min": round(dev_steps[0], 4), "median": round(dev_steps[len(dev_steps) // 2], 4), "max": round(dev_steps[-1], 4),
+               "slowest_step": dev_raw.index(dev_steps[-1]),
                "what": "device time between the events recorded behind consecutive timed steps (this rank); ms_per_step is the host clock over all of them"}
     log(f"timed: {ms_per_step:.3f} ms/step, {views_per_s:.1f} views/s")
 
