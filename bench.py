@@ -462,7 +462,7 @@ def main():
         except Exception:
             pass
     if not args.graph:           # (a replayed launch graph has no per-kernel events: --graph takes the kernel times of the untimed pass below)
-        R.profile_enable(int(os.environ.get("TRASE_BENCH_WINDOW_PROF", "2")))      # HIP events around the compositing kernels only, on the launch stream
+        R.profile_enable(2)      # HIP events around the compositing kernels only, on the launch stream
     import gc
     gc.disable()                 # no collector pause inside the 20-step window (NOT gc.collect(): tens of ms of idle GPU in front
                                  # of the timed steps cost 7-9 %, see above)

@@ -762,7 +762,7 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1=None, lengths2=None,
 # per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg
 # --------------------------------------------------------------------------------------
 def profile_enable(mode: int):
-    """0 off, 1 every kernel, 2 only the compositing kernels (render_fwd / render_bwd), 3 only render_bwd."""
+    """0 off, 1 every kernel, 2 only the compositing kernels (render_fwd / render_bwd)."""
     _lib.check(_lib.load().trase_prof_enable(int(mode)), "trase_prof_enable")
 
 
